@@ -1,0 +1,312 @@
+#!/usr/bin/env python
+"""TEST INFRASTRUCTURE ONLY -- golden-vector generator (runs ONLY where /root/reference exists).
+
+Imports the reference's OWN Python (`/root/reference/hetmogp/*.py`, `/root/reference/likelihoods/*.py`)
+over `oracle/gpy_standin.py` and records input/output vectors as small `.npz` fixtures under
+`tests/golden/`.  The fixtures are data (inputs + expected outputs); no reference source is
+copied.  Re-run:  python oracle/make_golden.py
+
+Fixture families:
+  lik_<name>.npz    G1  per-likelihood var_exp / var_exp_derivatives          (likelihoods/*.py)
+  cov_<case>.npz    G2  Kuu, Luu (jitchol), Kuui, ladder rung                  (util.py:181-200)
+  inf_<case>.npz    G3/G4/G5  q(f_d), KL, ELBO and the raw gradient dict        (svmogp_inf.py:23-250)
+  model_<case>.npz  G6  assembled parameter gradients from the reference's own
+                        SVMOGP.parameters_changed (svmogp.py:85-166) run over the stand-in's
+                        RESTATED GPy RBF gradient formulas ("GPy-unpinned").
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("HETMOGP_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _import_reference():
+    import matplotlib
+    matplotlib.use("Agg")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, REF)
+    from oracle import gpy_standin
+    gpy_standin.install()
+    import hetmogp.svmogp_inf as inf
+    import hetmogp.util as util
+    import hetmogp.het_likelihood as hl
+    import hetmogp.svmogp as svmogp
+    from likelihoods import gaussian, bernoulli, hetgaussian, categorical, poisson, gamma, beta, exponential
+    liks = dict(Gaussian=gaussian.Gaussian, Bernoulli=bernoulli.Bernoulli, HetGaussian=hetgaussian.HetGaussian,
+                Categorical=categorical.Categorical, Poisson=poisson.Poisson, Gamma=gamma.Gamma,
+                Beta=beta.Beta, Exponential=exponential.Exponential)
+    return gpy_standin, inf, util, hl, svmogp, liks
+
+
+DIM_F = dict(Gaussian=1, Bernoulli=1, HetGaussian=2, Poisson=1, Gamma=2, Beta=2, Exponential=1)
+
+
+def dim_f(spec):
+    name, kw = spec
+    return kw["K"] - 1 if name == "Categorical" else DIM_F[name]
+
+
+def make_lik(liks, spec):
+    name, kw = spec
+    return liks[name](**kw)
+
+
+def sample_y(rng, spec, n):
+    name, kw = spec
+    if name in ("Gaussian", "HetGaussian"):
+        return rng.randn(n, 1) * 1.5
+    if name == "Bernoulli":
+        return (rng.rand(n, 1) < 0.5).astype(float)
+    if name == "Poisson":
+        return rng.poisson(3.0, size=(n, 1)).astype(float)
+    if name in ("Gamma", "Exponential"):
+        return rng.gamma(2.0, 1.0, size=(n, 1)) + 1e-3
+    if name == "Beta":
+        return np.clip(rng.beta(2.0, 3.0, size=(n, 1)), 1e-4, 1 - 1e-4)
+    if name == "Categorical":
+        return rng.randint(1, kw["K"] + 1, size=(n, 1)).astype(float)
+    raise ValueError(name)
+
+
+# --------------------------------------------------------------------------- G1
+def gen_likelihoods(liks):
+    cases = [("Gaussian", {"sigma": 0.5}), ("Gaussian", {"sigma": 1.0}), ("Bernoulli", {}), ("HetGaussian", {}),
+             ("Poisson", {}), ("Exponential", {}), ("Gamma", {}), ("Beta", {}),
+             ("Categorical", {"K": 3}), ("Categorical", {"K": 4}), ("Categorical", {"K": 5})]
+    for k, spec in enumerate(cases):
+        rng = np.random.RandomState(100 + k)
+        n = 64
+        df = dim_f(spec)
+        y = sample_y(rng, spec, n)
+        m = rng.uniform(-3, 3, size=(n, df))
+        v = np.exp(rng.uniform(np.log(1e-3), np.log(4.0), size=(n, df)))
+        # extreme rows: hit the clips (large |m|, large v)
+        m[0, :] = 12.0
+        m[1, :] = -12.0
+        v[2, :] = 25.0
+        m[3, :] = 25.0
+        v[3, :] = 9.0
+        m[4, :] = -30.0
+        v[4, :] = 1e-6
+        lik = make_lik(liks, spec)
+        ve = lik.var_exp(y, m, v)
+        dm, dv = lik.var_exp_derivatives(y, m, v)
+        tag = spec[0].lower() + ("_K%d" % spec[1]["K"] if "K" in spec[1] else "") + \
+            ("_s%g" % spec[1]["sigma"] if "sigma" in spec[1] else "")
+        np.savez_compressed(os.path.join(OUT, "lik_%s.npz" % tag), spec=json.dumps(spec), y=y, m=m, v=v,
+                            var_exp=np.asarray(ve).reshape(n, 1), var_exp_dm=np.asarray(dm).reshape(n, df),
+                            var_exp_dv=np.asarray(dv).reshape(n, df))
+        print("lik", tag, float(np.sum(ve)))
+
+
+# --------------------------------------------------------------------------- G2
+def inducing(M, P, Q, rng, jitter_blocks=True):
+    if P == 1:
+        base = np.linspace(0, 1, M)[:, None]
+    else:
+        g = int(np.ceil(M ** (1.0 / P)))
+        grid = np.stack(np.meshgrid(*[np.linspace(0, 1, g)] * P, indexing="ij"), -1).reshape(-1, P)
+        base = grid[:M]
+    Z = np.tile(base, (1, Q))
+    if jitter_blocks:
+        h = spacing(M, P)
+        Z = Z + 0.15 * h * rng.randn(*Z.shape)
+    return Z
+
+
+def spacing(M, P):
+    return 1.0 / (M - 1) if P == 1 else M ** (-1.0 / P)
+
+
+def gen_cov(stand, util):
+    cases = [("well_M16", 16, 1, 3, (0.8, 1.0, 1.3)), ("well_M40_2d", 40, 2, 2, (0.8, 1.1)),
+             ("ladder_M24", 24, 1, 2, (4.0, 6.0))]
+    for k, (tag, M, P, Q, cs) in enumerate(cases):
+        rng = np.random.RandomState(200 + k)
+        Z = inducing(M, P, Q, rng, jitter_blocks=not tag.startswith("ladder"))
+        h = spacing(M, P)
+        var = 0.5 + 0.5 * rng.rand(Q)
+        ell = np.array(cs) * h
+        kern_list = util.latent_functions_prior(Q, lenghtscale=ell, variance=var, input_dim=P)
+        rungs = []
+        orig = stand.jitchol
+        import GPy.util.linalg as gl
+        gl.jitchol = lambda A, maxtries=5: orig(A, maxtries, _record=rungs)
+        util.linalg.jitchol = gl.jitchol
+        try:
+            Kuu, Luu, Kuui = util.latent_funs_cov(Z, kern_list)
+        finally:
+            gl.jitchol = orig
+            util.linalg.jitchol = orig
+        np.savez_compressed(os.path.join(OUT, "cov_%s.npz" % tag), Z=Z, variance=var, lengthscale=ell, P=P,
+                            Kuu=Kuu, Luu=Luu, Kuui=Kuui, rung=np.array(rungs))
+        print("cov", tag, "rungs", rungs, "cond", [float(np.linalg.cond(Kuu[q])) for q in range(Q)])
+
+
+# ----------------------------------------------------------------------- G3/G4/G5/G6
+INF_CASES = [
+    # tag, likelihood specs, N_t, M, Q, P, c (lengthscale/spacing), batch_scale?, kappa>0?
+    ("notebook", [("Gaussian", {"sigma": 1.0}), ("Bernoulli", {})], [64, 47], 8, 2, 1, (1.0, 1.3), False, False),
+    ("config1", [("HetGaussian", {}), ("Bernoulli", {}), ("Categorical", {"K": 3})], [40, 33, 29], 16, 2, 1,
+     (0.8, 1.2), False, False),
+    ("config2", [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {}), ("Poisson", {}), ("Gamma", {})], [64, 17, 40, 33],
+     16, 3, 1, (0.8, 1.0, 1.3), False, False),
+    ("config2_svi", [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {}), ("Poisson", {}), ("Gamma", {})],
+     [32, 32, 17, 32], 16, 3, 1, (0.8, 1.0, 1.3), True, True),
+    ("config4", [("HetGaussian", {}), ("Categorical", {"K": 5}), ("Beta", {}), ("Exponential", {})], [17, 9, 17, 13],
+     5, 4, 1, (0.8, 1.0, 1.3, 1.1), True, False),
+    ("config5_2d", [("Categorical", {"K": 4}), ("Gaussian", {"sigma": 0.5})], [31, 64], 16, 2, 2, (0.9, 1.2), False,
+     False),
+]
+
+
+def build_case(rng, specs, Ns, M, Q, P, cs, use_bs, use_kappa):
+    T = len(specs)
+    X = [np.sort(rng.rand(n, P), axis=0) if P == 1 else rng.rand(n, P) for n in Ns]
+    Y = [sample_y(rng, s, n) for s, n in zip(specs, Ns)]
+    Z = inducing(M, P, Q, rng)
+    h = spacing(M, P)
+    var = 0.5 + 0.5 * rng.rand(Q)
+    ell = np.array(cs) * h
+    Df = sum(dim_f(s) for s in specs)
+    W = np.stack([np.where(rng.rand(Df) < 0.5, 1.0, -1.0) * (0.5 + 0.5 * rng.randn(Df)) for _ in range(Q)])  # Q x Df
+    kappa = (0.1 + 0.2 * rng.rand(Q, Df)) if use_kappa else np.zeros((Q, Df))
+    m_u = 1.5 * rng.randn(M, Q)
+    Lfull = np.stack([np.eye(M) * (0.6 + 0.4 * rng.rand(M)) + 0.05 * np.tril(rng.randn(M, M), -1) for _ in range(Q)])
+    r, c = np.tril_indices(M)
+    L_flat = np.stack([Lfull[q][r, c] for q in range(Q)], axis=1)  # (M(M+1)/2, Q) row-major tril
+    bs = [float(3.0 + t) for t in range(T)] if use_bs else None
+    return dict(X=X, Y=Y, Z=Z, variance=var, lengthscale=ell, W=W, kappa=kappa, m_u=m_u, L_flat=L_flat, batch_scale=bs)
+
+
+def gen_inference(stand, inf, util, hl, liks):
+    for k, (tag, specs, Ns, M, Q, P, cs, use_bs, use_kappa) in enumerate(INF_CASES):
+        rng = np.random.RandomState(300 + k)
+        c = build_case(rng, specs, Ns, M, Q, P, cs, use_bs, use_kappa)
+        T = len(specs)
+        lik_list = [make_lik(liks, s) for s in specs]
+        likelihood = hl.HetLikelihood(lik_list)
+        Y_metadata = likelihood.generate_metadata()
+        Df = likelihood.num_output_functions(Y_metadata)
+        kern_list = util.latent_functions_prior(Q, lenghtscale=c["lengthscale"], variance=c["variance"], input_dim=P)
+        W_list = [c["W"][q][:, None].copy() for q in range(Q)]
+        kappa_list = [c["kappa"][q].copy() for q in range(Q)]
+        _, B_list = util.LCM(input_dim=P, output_dim=Df, rank=1, kernels_list=kern_list, W_list=W_list,
+                             kappa_list=kappa_list)
+        engine = inf.SVMOGPInf()
+        elbo, grads, post, post_F = engine.inference(c["m_u"], c["L_flat"], c["X"], c["Y"], c["Z"], kern_list,
+                                                     likelihood, B_list, Y_metadata, batch_scale=c["batch_scale"])
+        # G3: q(f_d) ; G4: KL
+        Kuu, Luu, Kuui = util.latent_funs_cov(c["Z"], kern_list)
+        p_U = inf.pu(Kuu=Kuu, Luu=Luu, Kuui=Kuui)
+        q_U = inf.qu(mu_u=c["m_u"], chols_u=c["L_flat"])
+        f_index = Y_metadata["function_index"].flatten()
+        out = {}
+        for d in range(Df):
+            Xt = c["X"][f_index[d]]
+            qf = engine.calculate_q_f(X=Xt, Z=c["Z"], q_U=q_U, p_U=p_U, kern_list=kern_list, B=B_list, M=M,
+                                      N=Xt.shape[0], Q=Q, D=Df, d=d)
+            out["m_fd_%d" % d] = qf.m_fd
+            out["v_fd_%d" % d] = qf.v_fd
+        KL = engine.calculate_KL(q_U=q_U, p_U=p_U, M=M, Q=Q)
+        out["KL"] = np.asarray(KL).reshape(1, 1)
+        out["elbo"] = np.asarray(elbo).reshape(1, 1)
+        for q in range(Q):
+            out["dL_dmu_u_%d" % q] = grads["dL_dmu_u"][q]
+            out["dL_dL_u_%d" % q] = grads["dL_dL_u"][q]
+            out["dL_dKmm_%d" % q] = grads["dL_dKmm"][q]
+            for d in range(Df):
+                out["dL_dKmn_%d_%d" % (q, d)] = grads["dL_dKmn"][q][d]
+                out["dL_dKdiag_%d_%d" % (q, d)] = grads["dL_dKdiag"][q][d]
+        for t in range(T):
+            out["X_%d" % t] = c["X"][t]
+            out["Y_%d" % t] = c["Y"][t]
+        np.savez_compressed(os.path.join(OUT, "inf_%s.npz" % tag), spec=json.dumps(specs), T=T, M=M, Q=Q, P=P, Df=Df,
+                            Z=c["Z"], variance=c["variance"], lengthscale=c["lengthscale"], W=c["W"], kappa=c["kappa"],
+                            m_u=c["m_u"], L_flat=c["L_flat"],
+                            batch_scale=np.array(c["batch_scale"] if c["batch_scale"] else [1.0] * T),
+                            f_index=f_index, d_index=Y_metadata["d_index"].flatten(), **out)
+        print("inf", tag, "ELBO", float(elbo))
+
+
+MODEL_CASES = [
+    # tag, base inference case index, batch_size (None = full batch), vem_step, perturb live W (quirk Q3)
+    ("notebook_full", 0, None, True, False),
+    ("config1_full", 1, None, True, False),
+    ("config2_full", 2, None, True, False),
+    ("config2_staleW", 2, None, True, True),
+    ("config4_full", 4, None, True, False),
+    ("config5_2d_full", 5, None, True, False),
+    ("config2_svi_E", 2, 16, True, False),
+    ("config2_svi_M", 2, 16, False, False),
+]
+
+
+def gen_model(stand, util, hl, svmogp, liks):
+    for k, (tag, base, batch_size, vem_step, staleW) in enumerate(MODEL_CASES):
+        (_, specs, Ns, M, Q, P, cs, use_bs, use_kappa) = INF_CASES[base]
+        rng = np.random.RandomState(400 + k)
+        c = build_case(rng, specs, Ns, M, Q, P, cs, False, False)
+        T = len(specs)
+        likelihood = hl.HetLikelihood([make_lik(liks, s) for s in specs])
+        Y_metadata = likelihood.generate_metadata()
+        Df = likelihood.num_output_functions(Y_metadata)
+        kern_list = util.latent_functions_prior(Q, lenghtscale=c["lengthscale"], variance=c["variance"], input_dim=P)
+        W_list = [c["W"][q][:, None].copy() for q in range(Q)]
+        # SVMOGP tiles a common M x P inducing set over q (svmogp.py:52); take block 0 of the case's Z
+        Z0 = c["Z"][:, :P].copy()
+        np.random.seed(1234 + k)
+        import random
+        random.seed(99 + k)
+        model = svmogp.SVMOGP(X=c["X"], Y=c["Y"], Z=Z0, kern_list=kern_list, likelihood=likelihood,
+                              Y_metadata=Y_metadata, batch_size=batch_size, W_list=W_list)
+        # overwrite the random variational init (svmogp.py:66-69) and de-tile Z with the case's values
+        model.q_u_means[...] = c["m_u"]
+        model.q_u_chols[...] = c["L_flat"]
+        model.Z[...] = c["Z"]
+        W_live = c["W"].copy()
+        if staleW:
+            W_live = W_live + 0.3 * rng.randn(*W_live.shape)
+            for q in range(Q):
+                model.B_list[q].W[...] = W_live[q][:, None]
+        model.vem_step = vem_step
+        model.parameters_changed()
+        out = {}
+        for t in range(T):
+            out["Xall_%d" % t] = c["X"][t]
+            out["Yall_%d" % t] = c["Y"][t]
+            out["Xbatch_%d" % t] = model.Xmulti[t]
+            out["Ybatch_%d" % t] = model.Ymulti[t]
+        np.savez_compressed(
+            os.path.join(OUT, "model_%s.npz" % tag), spec=json.dumps(specs), T=T, M=M, Q=Q, P=P, Df=Df,
+            Z=c["Z"], variance=c["variance"], lengthscale=c["lengthscale"], W=W_live, W0=c["W"],
+            kappa=np.zeros((Q, Df)), m_u=c["m_u"], L_flat=c["L_flat"], stochastic=int(batch_size is not None),
+            batch_size=-1 if batch_size is None else batch_size, vem_step=int(vem_step),
+            batch_scale=np.array(model.batch_scale),
+            elbo=np.asarray(model.log_likelihood()).reshape(1, 1),
+            g_m_u=np.asarray(model.q_u_means.gradient), g_L_u=np.asarray(model.q_u_chols.gradient),
+            g_Z=np.asarray(model.Z.gradient),
+            g_variance=np.array([float(np.ravel(kq.variance.gradient)[0]) for kq in kern_list]),
+            g_lengthscale=np.array([float(np.ravel(kq.lengthscale.gradient)[0]) for kq in kern_list]),
+            g_W=np.stack([np.ravel(B.W.gradient) for B in model.B_list]),
+            g_kappa=np.stack([np.ravel(B.kappa.gradient) for B in model.B_list]), **out)
+        print("model", tag, "ELBO", float(model.log_likelihood()))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    stand, inf, util, hl, svmogp, liks = _import_reference()
+    gen_likelihoods(liks)
+    gen_cov(stand, util)
+    gen_inference(stand, inf, util, hl, liks)
+    gen_model(stand, util, hl, svmogp, liks)
+
+
+if __name__ == "__main__":
+    main()
