@@ -1,0 +1,111 @@
+"""ctypes binding of the C ABI declared in ``include/hetmogp_hip.h`` (``libhetmogp_hip.so``).
+
+The north-star asks for a "thin C-ABI cffi layer"; cffi is not installed in this image, ``ctypes`` is, and the
+boundary is the C ABI itself, so the stub below is what a maintainer of the reference would add.  There is no
+CPU fallback: if the shared library is missing, importing this module raises, loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhetmogp_hip.so")
+
+ABI_VERSION = 1
+# likelihood ids (class names of the reference's likelihoods/<name>.py)
+LIK_GAUSSIAN, LIK_BERNOULLI, LIK_HETGAUSSIAN, LIK_CATEGORICAL, LIK_POISSON, LIK_EXPONENTIAL, LIK_GAMMA, LIK_BETA = range(8)
+E_INVALID, E_NO_DEVICE, E_NOT_PD, E_SQI_UNSTABLE, E_STATE = -1, -2, -3, -4, -5
+FLAG_V_NEGATIVE = 1
+GROUP_QU, GROUP_HYPER, GROUP_Z, GROUP_ALL = 1, 2, 4, 7
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+c_uint32_p = C.POINTER(C.c_uint32)
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("T", C.c_int32), ("Q", C.c_int32), ("M", C.c_int32), ("P", C.c_int32),
+                ("Df", C.c_int32), ("lik_id", c_int32_p), ("lik_param", c_double_p), ("f_index", c_int32_p),
+                ("d_index", c_int32_p), ("device", C.c_int32), ("chunk_rows", C.c_int64)]
+
+
+class Params(C.Structure):
+    _fields_ = [("Z", c_double_p), ("m_u", c_double_p), ("L_flat", c_double_p), ("variance", c_double_p),
+                ("lengthscale", c_double_p), ("W", c_double_p), ("kappa", c_double_p), ("W0", c_double_p),
+                ("kappa0", c_double_p), ("batch_scale", c_double_p), ("row_begin", c_int64_p), ("row_end", c_int64_p),
+                ("forced_rung", c_int32_p), ("group_mask", C.c_uint32)]
+
+
+class Outputs(C.Structure):
+    _fields_ = [("elbo", c_double_p), ("g_m_u", c_double_p), ("g_L_u", c_double_p), ("g_variance", c_double_p),
+                ("g_lengthscale", c_double_p), ("g_W", c_double_p), ("g_kappa", c_double_p), ("g_Z", c_double_p),
+                ("dL_dS", c_double_p), ("rung", c_int32_p), ("flags", c_uint32_p)]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)  -- one entry per function declared in include/hetmogp_hip.h
+    "hmogp_abi_version": (C.c_int, []),
+    "hmogp_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "hmogp_destroy": (None, [C.c_void_p]),
+    "hmogp_last_error": (C.c_char_p, [C.c_void_p]),
+    "hmogp_set_task_data": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_double_p, C.c_int64]),
+    "hmogp_elbo_grad": (C.c_int, [C.c_void_p, C.POINTER(Params), C.POINTER(Outputs)]),
+    "hmogp_step_begin": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
+    "hmogp_stats_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_int64_p]),
+    "hmogp_step_finish": (C.c_int, [C.c_void_p, C.POINTER(Outputs)]),
+    "hmogp_stats_read": (C.c_int, [C.c_void_p, c_double_p]),
+    "hmogp_stats_write": (C.c_int, [C.c_void_p, c_double_p]),
+    "hmogp_posterior_u": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "hmogp_predict_f": (C.c_int, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p]),
+    "hmogp_last_timings": (C.c_int, [C.c_void_p, c_double_p, c_int64_p]),
+    "hmogp_rbf_cross_cov": (C.c_int, [C.c_int32, c_double_p, C.c_int64, c_double_p, C.c_int32, C.c_int32, C.c_double,
+                                      C.c_double, c_double_p]),
+    "hmogp_jitchol_inv": (C.c_int, [C.c_int32, c_double_p, C.c_int32, C.c_int32, c_int32_p, c_double_p, c_double_p,
+                                    c_int32_p]),
+    "hmogp_potri": (C.c_int, [C.c_int32, c_double_p, C.c_int32, C.c_int32, c_double_p]),
+    "hmogp_gemm_f64": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, c_double_p,
+                                 C.c_int32, c_double_p, C.c_int32, C.c_double, c_double_p, C.c_int32]),
+    "hmogp_var_exp": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_int64, c_double_p, c_double_p, c_double_p,
+                                c_double_p, c_double_p, c_double_p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "hetmogp_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C hetmogp_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.hmogp_abi_version() != ABI_VERSION:
+        raise ImportError("hetmogp_amd: ABI version mismatch between _lib.py and libhetmogp_hip.so")
+    return lib
+
+
+lib = _load()
+
+
+class HetMOGPError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "hetmogp_hip error %d: %s" % (code, msg))
+        self.code = code
+        self.msg = msg
+
+
+def check(rc, handle=None):
+    """Map C-ABI status codes onto the exception types the reference raises on the same conditions."""
+    if rc == 0:
+        return
+    msg = lib.hmogp_last_error(handle)
+    msg = msg.decode("utf-8", "replace") if msg else ""
+    if rc == E_NOT_PD:
+        import numpy as np
+        raise np.linalg.LinAlgError(msg)             # GPy jitchol (reached from util.py:198)
+    if rc == E_SQI_UNSTABLE:
+        raise ValueError(msg)                         # svmogp_inf.py:126-127
+    if rc == E_INVALID:
+        raise ValueError(msg)
+    raise HetMOGPError(rc, msg)

@@ -1,0 +1,87 @@
+// common.h -- shared declarations of the hetmogp HIP engine (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#define HMOGP_WAVE 64
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+// ---- host-side error plumbing -----------------------------------------------------------------------
+struct HipError {
+  hipError_t code;
+  const char* what;
+  const char* file;
+  int line;
+};
+#define HIP_TRY(expr)                                          \
+  do {                                                         \
+    hipError_t _e = (expr);                                    \
+    if (_e != hipSuccess) throw HipError{_e, #expr, __FILE__, __LINE__}; \
+  } while (0)
+
+// ---- wave-level reductions (64 lanes, shuffles -- no LDS) ---------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum of `v` for blocks of up to 1024 threads; result valid in thread 0. `scratch` >= 16 doubles.
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < nw; ++i) r += scratch[i];
+  return r;
+}
+
+// ---- GEMM ------------------------------------------------------------------------------------------
+// C[b] (M x N, row-major, ldc) = alpha * sum_k A(i,k) * s[k] * B(k,j) + beta * C[b]
+//   a_kmajor == 0 : A(i,k) = A[i*lda + k]     a_kmajor == 1 : A(i,k) = A[k*lda + i]   (A^T stored)
+//   b_kmajor == 1 : B(k,j) = B[k*ldb + j]     b_kmajor == 0 : B(k,j) = B[j*ldb + k]   (B^T stored)
+// Batched over `nbatch` (strides sA.. in elements); the LAST batch may be ragged (M_last/N_last/K_last; 0 = same).
+// A second, outer batch `nouter` (strides oA..) multiplies it (e.g. pairs x latents in the triangular inverse).
+// ksplit > 1 : K is cut in `ksplit` contiguous ranges; range s writes alpha*partial (beta ignored) to
+//              C + s*sSplit (the caller reduces the slabs).
+// lower_only : only tiles with tile_col <= tile_row are computed (M == N).
+struct GemmArgs {
+  const double* A = nullptr;
+  const double* B = nullptr;
+  double* C = nullptr;
+  const double* kscale = nullptr;
+  int M = 0, N = 0, K = 0;
+  int lda = 0, ldb = 0, ldc = 0;
+  long long sA = 0, sB = 0, sC = 0, sS = 0;
+  double alpha = 1.0, beta = 0.0;
+  int nbatch = 1;
+  int M_last = 0, N_last = 0, K_last = 0;
+  int nouter = 1;                        // outer batch (grid.y), e.g. the latent index q
+  long long oA = 0, oB = 0, oC = 0, oS = 0;
+  int ksplit = 1;
+  long long sSplit = 0;
+  int a_kmajor = 0, b_kmajor = 1;
+  int lower_only = 0;
+};
+void launch_gemm_f64(const GemmArgs& g, hipStream_t stream);
+
+// ---- linear algebra on Q x M x M batches (linalg.hip) ---------------------------------------------------
+// In-place lower Cholesky of A[q]; info[q] = 0 or the 1-based index of the first non-positive pivot (LAPACK
+// dpotrf convention; the matrix content is then undefined). Upper triangle is zeroed. dscr: Q*M*32 doubles.
+void launch_potrf_batched(double* A, int Q, int M, int* d_info, double* dscr, hipStream_t stream);
+// Linv[q] = L[q]^-1 (lower triangular, upper zero). `L` is preserved; tmp: Q*M*M doubles.
+void launch_trtri_batched(const double* L, double* Linv, double* tmp, int Q, int M, hipStream_t stream);
+// Out[q] = Linv[q]^T Linv[q]  (= (L L^T)^-1), full symmetric.
+void launch_ltl_batched(const double* Linv, double* Out, int Q, int M, hipStream_t stream);
+
+// ---- misc small kernels (linalg.hip) -------------------------------------------------------------------
+void launch_fill(double* p, long long n, double v, hipStream_t stream);
+void launch_unpack_tril(const double* L_flat /*[Mtri,Q]*/, double* L /*[Q,M,M]*/, int Q, int M, hipStream_t s);
+void launch_gemv_batched(const double* A, const double* x, double* y, int Q, int M, long long sx, int incx,
+                         hipStream_t s);  // y[q] = A[q] x[q];  x[q][i] = x[q*sx + i*incx]

@@ -1,0 +1,861 @@
+// engine.hip -- host side of the hetmogp HIP engine and its C ABI (include/hetmogp_hip.h).
+//
+// One evaluation = SVMOGP.parameters_changed() (hetmogp/svmogp.py:85-166):
+//   u_algebra   replicated M x M work before the rows are touched: K_uu, jitchol ladder, K_uu^-1, S = L L^T,
+//               a = K_uu^-1 m, C = K_uu^-1 S K_uu^-1 - K_uu^-1, S^-1            (util.py:181-200, svmogp_inf.py:192-195)
+//   row_pass    per task, per row chunk:  K^ = k_q(X, Z_q)  ->  P~ = K^ C_q (FP64 MFMA)  ->  p, c row statistics
+//               ->  q(f), variational expectations, row weights  ->  H_q += K^T diag(beta) K^ (FP64 MFMA),
+//               r_q, dZ column statistics.  Everything lands in ONE additive statistic bundle (the only thing
+//               a row-sharded multi-GPU run has to all-reduce).
+//   finish      replicated M x M post-processing of the bundle: svmogp_inf.py:111-183,227-250 and the
+//               parameter-gradient assembly of svmogp.py:101-166.
+// There is no CPU fallback anywhere in this file.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hetmogp_hip.h"
+#include "common.h"
+#include "post.h"
+#include "rowpass.h"
+
+namespace {
+
+struct EngineError {
+  int code;
+  std::string msg;
+};
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr, o.bytes = 0; }
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  void ensure(size_t b, bool zero = false) {
+    if (b <= bytes) return;
+    release();
+    HIP_TRY(hipMalloc(&p, b));
+    bytes = b;
+    if (zero) HIP_TRY(hipMemset(p, 0, b));
+  }
+  double* d() const { return static_cast<double*>(p); }
+  template <class T>
+  T* as() const { return static_cast<T*>(p); }
+};
+
+enum { CAT_TOTAL = 0, CAT_RBF, CAT_FWD, CAT_ROWSTATS, CAT_QUAD, CAT_GRAM, CAT_COLSTATS, CAT_MM, NCAT };
+
+struct Task {
+  long long N = 0;
+  DevBuf X, Y, Yaux;
+  int lik = 0, dimf = 1, d0 = 0;
+  double param = 0.0;
+  DevBuf offsets;  // device: quad scalar slot -> bundle offset
+  int nscal = 0;
+};
+
+int lik_dimf(int lik, double param) {
+  switch (lik) {
+    case HMOGP_LIK_GAUSSIAN:
+    case HMOGP_LIK_BERNOULLI:
+    case HMOGP_LIK_POISSON:
+    case HMOGP_LIK_EXPONENTIAL: return 1;
+    case HMOGP_LIK_HETGAUSSIAN:
+    case HMOGP_LIK_GAMMA:
+    case HMOGP_LIK_BETA: return 2;
+    case HMOGP_LIK_CATEGORICAL: return (int)param - 1;
+    default: return -1;
+  }
+}
+
+// ------------------------------------------------------------------------------------ batched jitchol + inverse
+// Luu <- chol(Kuu + jitter I) with GPy's ladder (GPy.util.linalg.jitchol): plain factorisation first, then
+// jitter = mean(diag) * 1e-6 * 10^k, k = 0..4.  diag(K_uu) == variance for the RBF, so mean(diag) = variance.
+// rung_io[q]: in  -2 = search, -1 / k = forced;  out = rung taken.
+void jitchol_batched(const double* Kuu, double* Luu, int Q, int M, const double* diag_mean, int* rung_io, int* d_info,
+                     double* d_jit, double* dscr, hipStream_t st) {
+  std::vector<double> jit(Q, 0.0);
+  std::vector<int> forced(Q), info(Q);
+  for (int q = 0; q < Q; ++q) {
+    forced[q] = rung_io[q] != -2;
+    if (rung_io[q] >= 0) jit[q] = diag_mean[q] * 1e-6 * std::pow(10.0, rung_io[q]);
+    if (!forced[q]) rung_io[q] = -1;
+  }
+  HIP_TRY(hipMemcpyAsync(d_jit, jit.data(), sizeof(double) * Q, hipMemcpyHostToDevice, st));
+  launch_add_diag_copy(Kuu, Luu, Q, M, d_jit, st);
+  launch_potrf_batched(Luu, Q, M, d_info, dscr, st);
+  HIP_TRY(hipMemcpyAsync(info.data(), d_info, sizeof(int) * Q, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const long long MM = (long long)M * M;
+  for (int q = 0; q < Q; ++q) {
+    if (info[q] == 0) continue;
+    if (forced[q]) throw EngineError{HMOGP_E_NOT_PD, "Cholesky failed at the forced jitter rung"};
+    if (!(diag_mean[q] > 0.0)) throw EngineError{HMOGP_E_NOT_PD, "not pd: non-positive diagonal elements"};
+    double j = diag_mean[q] * 1e-6;
+    bool ok = false;
+    for (int k = 0; k < 5 && std::isfinite(j); ++k, j *= 10.0) {
+      HIP_TRY(hipMemcpyAsync(d_jit, &j, sizeof(double), hipMemcpyHostToDevice, st));
+      launch_add_diag_copy(Kuu + q * MM, Luu + q * MM, 1, M, d_jit, st);
+      launch_potrf_batched(Luu + q * MM, 1, M, d_info, dscr, st);
+      int inf1 = 0;
+      HIP_TRY(hipMemcpyAsync(&inf1, d_info, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (inf1 == 0) {
+        rung_io[q] = k;
+        ok = true;
+        break;
+      }
+    }
+    if (!ok) throw EngineError{HMOGP_E_NOT_PD, "not positive definite, even with jitter."};
+  }
+}
+
+}  // namespace
+
+// =================================================================================================== engine
+struct hmogp_engine {
+  int T = 0, Q = 0, M = 0, P = 0, Df = 0, device = 0;
+  long long chunk = 131072;
+  std::vector<int> f_index, d_index;
+  std::vector<Task> tasks;
+  hipStream_t st = nullptr;
+  std::string err;
+
+  // bundle layout (float64 words): [0] sum VE | [1] #(v<0) | [2,2+Df) sgv ; per q: H | r | dZ | sa | sl | swk
+  long long NG = 0, per_q = 0, nstats = 0, oR = 0, oDZ = 0, oSA = 0, oSL = 0, oSWK = 0;
+
+  // parameters of the current / last evaluation
+  std::vector<double> h_var, h_ell, h_W, h_kap, h_W0, h_kap0, h_bs;
+  std::vector<long long> rb, re;
+  std::vector<int> rung;
+  unsigned group_mask = HMOGP_GROUP_ALL;
+  DevBuf dZ, dmu, dLflat, dvar, dell, dW, dkap;
+  // M x M (each Q*M*M)
+  DevBuf Kuu, Luu, Kuui, L, S, KiS, KSK, C, Sqi, tmpA, tmpB, HK, G, GSK, dKmm, dLdS;
+  DevBuf a, Kr, gmu, gL, klout, rowout, dinfo, djit, dscr;
+  // N x M workspaces and row vectors
+  long long ws_rows = 0;
+  DevBuf Kh, Pt, vp, vc, vpt, vct, valpha, vbeta, valpha0, vbeta0;
+  DevBuf stats, slabs, colpart, quadpart;
+  bool began = false, evaluated = false;
+
+  // timing
+  struct Span {
+    hipEvent_t a, b;
+    int cat;
+  };
+  std::vector<hipEvent_t> pool;
+  size_t pool_used = 0;
+  std::vector<Span> spans;
+  double ms[NCAT] = {0};
+  long long launches[NCAT] = {0};
+  hipEvent_t ev_begin0 = nullptr, ev_begin1 = nullptr, ev_fin0 = nullptr, ev_fin1 = nullptr;
+
+  hipEvent_t new_event() {
+    if (pool_used == pool.size()) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreate(&e));
+      pool.push_back(e);
+    }
+    return pool[pool_used++];
+  }
+  struct Scope {
+    hmogp_engine* e;
+    Span s;
+    Scope(hmogp_engine* eng, int cat, int nlaunch) : e(eng) {
+      s.cat = cat;
+      s.a = e->new_event();
+      s.b = e->new_event();
+      e->launches[cat] += nlaunch;
+      (void)hipEventRecord(s.a, e->st);
+    }
+    ~Scope() {
+      (void)hipEventRecord(s.b, e->st);
+      e->spans.push_back(s);
+    }
+  };
+  void collect_spans() {
+    for (auto& s : spans) {
+      float f = 0.f;
+      if (hipEventElapsedTime(&f, s.a, s.b) == hipSuccess) ms[s.cat] += f;
+    }
+    spans.clear();
+    pool_used = 0;
+  }
+
+  ~hmogp_engine() {
+    for (auto e : pool) (void)hipEventDestroy(e);
+    for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1})
+      if (e) (void)hipEventDestroy(e);
+    if (st) (void)hipStreamDestroy(st);
+  }
+
+  double* Hq(int q) { return stats.d() + NG + q * per_q; }
+
+  void init(const hmogp_config* c) {
+    if (!c || c->abi_version != HMOGP_ABI_VERSION) throw EngineError{HMOGP_E_INVALID, "bad config / ABI version"};
+    T = c->T, Q = c->Q, M = c->M, P = c->P, Df = c->Df, device = c->device;
+    if (T < 1 || Q < 1 || M < 1 || Df < 1) throw EngineError{HMOGP_E_INVALID, "T, Q, M, Df must be >= 1"};
+    if (P < 1 || P > 4) throw EngineError{HMOGP_E_INVALID, "input dimension P must be 1..4"};
+    if (Q > HMOGP_MAXQ) throw EngineError{HMOGP_E_INVALID, "Q exceeds HMOGP_MAXQ (8)"};
+    if (c->chunk_rows > 0) chunk = c->chunk_rows;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+      throw EngineError{HMOGP_E_NO_DEVICE, "no HIP device visible (this library has no CPU path)"};
+    if (device < 0 || device >= ndev) throw EngineError{HMOGP_E_NO_DEVICE, "HIP device ordinal out of range"};
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&ev_begin0, &ev_begin1, &ev_fin0, &ev_fin1}) HIP_TRY(hipEventCreate(e));
+    f_index.assign(c->f_index, c->f_index + Df);
+    d_index.assign(c->d_index, c->d_index + Df);
+    tasks.resize(T);
+    int d = 0;
+    for (int t = 0; t < T; ++t) {
+      Task& k = tasks[t];
+      k.lik = c->lik_id[t];
+      k.param = c->lik_param ? c->lik_param[t] : 0.0;
+      if (k.lik == HMOGP_LIK_GAUSSIAN && !(k.param > 0.0)) k.param = 0.5;  // gaussian.py:21-24
+      k.dimf = lik_dimf(k.lik, k.param);
+      if (k.dimf < 1 || k.dimf > HMOGP_MAXJ) throw EngineError{HMOGP_E_INVALID, "unsupported likelihood / dim_f"};
+      k.d0 = d;
+      for (int j = 0; j < k.dimf; ++j, ++d)
+        if (d >= Df || f_index[d] != t || d_index[d] != j)
+          throw EngineError{HMOGP_E_INVALID, "f_index / d_index inconsistent with the likelihood list"};
+    }
+    if (d != Df) throw EngineError{HMOGP_E_INVALID, "Df does not match the likelihood list"};
+    // bundle layout
+    const long long MM = (long long)M * M;
+    NG = 2 + Df;
+    oR = MM, oDZ = MM + M, oSA = oDZ + (long long)M * P, oSL = oSA + 1, oSWK = oSA + 2;
+    per_q = oSWK + Df;
+    nstats = NG + Q * per_q;
+    stats.ensure(sizeof(double) * nstats, true);
+    for (int t = 0; t < T; ++t) {
+      Task& k = tasks[t];
+      const int J = k.dimf;
+      k.nscal = 2 + 2 * Q + J + Q * J;
+      std::vector<long long> off(k.nscal);
+      off[0] = 0, off[1] = 1;
+      for (int q = 0; q < Q; ++q) {
+        off[2 + 2 * q] = NG + q * per_q + oSA;
+        off[3 + 2 * q] = NG + q * per_q + oSL;
+        for (int j = 0; j < J; ++j) off[2 + 2 * Q + J + q * J + j] = NG + q * per_q + oSWK + k.d0 + j;
+      }
+      for (int j = 0; j < J; ++j) off[2 + 2 * Q + j] = 2 + k.d0 + j;
+      k.offsets.ensure(sizeof(long long) * k.nscal);
+      HIP_TRY(hipMemcpy(k.offsets.p, off.data(), sizeof(long long) * k.nscal, hipMemcpyHostToDevice));
+    }
+    // parameter + M x M buffers
+    const size_t mmq = sizeof(double) * MM * Q;
+    for (DevBuf* b : {&Kuu, &Luu, &Kuui, &L, &S, &KiS, &KSK, &C, &Sqi, &tmpA, &tmpB, &HK, &G, &GSK, &dKmm, &dLdS}) b->ensure(mmq, true);
+    dZ.ensure(sizeof(double) * M * Q * P);
+    dmu.ensure(sizeof(double) * M * Q);
+    dLflat.ensure(sizeof(double) * ((long long)M * (M + 1) / 2) * Q);
+    dvar.ensure(sizeof(double) * Q), dell.ensure(sizeof(double) * Q);
+    dW.ensure(sizeof(double) * Q * Df), dkap.ensure(sizeof(double) * Q * Df);
+    a.ensure(sizeof(double) * Q * M), Kr.ensure(sizeof(double) * Q * M), gmu.ensure(sizeof(double) * Q * M);
+    gL.ensure(sizeof(double) * ((long long)M * (M + 1) / 2) * Q);
+    klout.ensure(sizeof(double) * Q * 5);
+    rowout.ensure(sizeof(double) * Q * M * (2 + P));
+    dinfo.ensure(sizeof(int) * Q), djit.ensure(sizeof(double) * Q), dscr.ensure(sizeof(double) * Q * M * 32);
+    rung.assign(Q, -1);
+  }
+
+  void set_task_data(int t, const double* X, const double* Y, long long N) {
+    if (t < 0 || t >= T || N < 0 || (N > 0 && (!X || !Y))) throw EngineError{HMOGP_E_INVALID, "bad task data"};
+    Task& k = tasks[t];
+    k.N = N;
+    began = false;
+    if (N == 0) return;
+    k.X.ensure(sizeof(double) * N * P);
+    k.Y.ensure(sizeof(double) * N);
+    HIP_TRY(hipMemcpy(k.X.p, X, sizeof(double) * N * P, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(k.Y.p, Y, sizeof(double) * N, hipMemcpyHostToDevice));
+    if (k.lik == HMOGP_LIK_POISSON) {  // gammaln(y+1) depends on the data only (poisson.py:33)
+      k.Yaux.ensure(sizeof(double) * N);
+      launch_gammaln1p(k.Y.d(), k.Yaux.d(), N, st);
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+  }
+
+  void ensure_workspace(long long rows) {
+    rows = std::max<long long>(rows, 1);
+    if (rows <= ws_rows) return;
+    const size_t nm = sizeof(double) * rows * M * Q, nv = sizeof(double) * rows * Q;
+    Kh.ensure(nm), Pt.ensure(nm);
+    for (DevBuf* b : {&vp, &vc, &vpt, &vct, &valpha, &vbeta, &valpha0, &vbeta0}) b->ensure(nv, true);
+    colpart.ensure(sizeof(double) * ((rows + 255) / 256) * M * (1 + P));
+    quadpart.ensure(sizeof(double) * (rows * 64 / 256 + 1) * HMOGP_MAXSCAL);
+    ws_rows = rows;
+  }
+
+  // ------------------------------------------------------------------------------------------ parameters
+  void upload_params(const hmogp_params* p) {
+    if (!p || !p->Z || !p->m_u || !p->L_flat || !p->variance || !p->lengthscale || !p->W || !p->kappa)
+      throw EngineError{HMOGP_E_INVALID, "missing parameter array"};
+    const long long Mtri = (long long)M * (M + 1) / 2;
+    h_var.assign(p->variance, p->variance + Q);
+    h_ell.assign(p->lengthscale, p->lengthscale + Q);
+    h_W.assign(p->W, p->W + Q * Df);
+    h_kap.assign(p->kappa, p->kappa + Q * Df);
+    h_W0.assign(p->W0 ? p->W0 : p->W, (p->W0 ? p->W0 : p->W) + Q * Df);
+    h_kap0.assign(p->kappa0 ? p->kappa0 : p->kappa, (p->kappa0 ? p->kappa0 : p->kappa) + Q * Df);
+    h_bs.assign(T, 1.0);
+    if (p->batch_scale) h_bs.assign(p->batch_scale, p->batch_scale + T);
+    rb.assign(T, 0), re.resize(T);
+    for (int t = 0; t < T; ++t) {
+      re[t] = tasks[t].N;
+      if (p->row_begin) rb[t] = p->row_begin[t];
+      if (p->row_end) re[t] = p->row_end[t];
+      if (rb[t] < 0 || re[t] > tasks[t].N || rb[t] > re[t]) throw EngineError{HMOGP_E_INVALID, "row range outside the task's data"};
+    }
+    for (int q = 0; q < Q; ++q) {
+      rung[q] = p->forced_rung ? p->forced_rung[q] : -2;
+      if (!(h_ell[q] > 0.0)) throw EngineError{HMOGP_E_INVALID, "lengthscale must be positive"};
+    }
+    group_mask = p->group_mask;
+    HIP_TRY(hipMemcpyAsync(dZ.p, p->Z, sizeof(double) * M * Q * P, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dmu.p, p->m_u, sizeof(double) * M * Q, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dLflat.p, p->L_flat, sizeof(double) * Mtri * Q, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dvar.p, h_var.data(), sizeof(double) * Q, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dell.p, h_ell.data(), sizeof(double) * Q, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dW.p, h_W.data(), sizeof(double) * Q * Df, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dkap.p, h_kap.data(), sizeof(double) * Q * Df, hipMemcpyHostToDevice, st));
+  }
+
+  // batched (over q) M x M GEMM helper
+  void mm(const double* A, bool a_k, const double* B, bool b_k, double* Cc, double alpha = 1.0, long long sA = -1,
+          int lda = -1) {
+    GemmArgs g;
+    const long long MM = (long long)M * M;
+    g.A = A, g.B = B, g.C = Cc;
+    g.M = g.N = g.K = M;
+    g.lda = lda > 0 ? lda : M, g.ldb = g.ldc = M;
+    g.nbatch = Q;
+    g.sA = sA >= 0 ? sA : MM, g.sB = g.sC = MM;
+    g.a_kmajor = a_k, g.b_kmajor = b_k;
+    g.alpha = alpha;
+    launch_gemm_f64(g, st);
+  }
+
+  // ------------------------------------------------------------------------------------------ u algebra
+  void u_algebra() {
+    Scope sc(this, CAT_MM, 0);
+    const long long MM = (long long)M * M;
+    const int ldz = Q * P;
+    for (int q = 0; q < Q; ++q)  // K_uu: both arguments passed (util.py:197) -> no forced diagonal
+      launch_rbf(dZ.d() + q * P, ldz, M, P, dZ.d() + q * P, ldz, M, h_var[q], h_ell[q], Kuu.d() + q * MM, false, st);
+    jitchol_batched(Kuu.d(), Luu.d(), Q, M, h_var.data(), rung.data(), dinfo.as<int>(), djit.d(), dscr.d(), st);
+    launch_trtri_batched(Luu.d(), tmpA.d(), tmpB.d(), Q, M, st);
+    launch_ltl_batched(tmpA.d(), Kuui.d(), Q, M, st);             // K_uu^-1          (util.py:199)
+    launch_unpack_tril(dLflat.d(), L.d(), Q, M, st);              // flat_to_triang   (svmogp_inf.py:193)
+    mm(L.d(), false, L.d(), false, S.d());                        // S = L L^T        (:194-195)
+    launch_gemv_batched(Kuui.d(), dmu.d(), a.d(), Q, M, 1, Q, st);  // a = K_uu^-1 m
+    mm(Kuui.d(), false, S.d(), true, KiS.d());
+    mm(KiS.d(), false, Kuui.d(), true, KSK.d());
+    launch_sub(KSK.d(), Kuui.d(), C.d(), MM * Q, st);             // C = K^-1 S K^-1 - K^-1
+    launch_trtri_batched(L.d(), tmpA.d(), tmpB.d(), Q, M, st);    // S^-1 = dpotri(L) (svmogp_inf.py:124)
+    launch_ltl_batched(tmpA.d(), Sqi.d(), Q, M, st);
+  }
+
+  // ------------------------------------------------------------------------------------------ row pass
+  void row_pass() {
+    const long long MM = (long long)M * M;
+    const int ldz = Q * P;
+    const bool want_hyper = (group_mask & (HMOGP_GROUP_HYPER | HMOGP_GROUP_Z)) != 0;
+    const bool want_z = (group_mask & HMOGP_GROUP_Z) != 0;
+    long long maxrows = 1;
+    for (int t = 0; t < T; ++t) maxrows = std::max(maxrows, std::min(chunk, re[t] - rb[t]));
+    ensure_workspace(maxrows);
+    const long long ldn = ws_rows;
+    HIP_TRY(hipMemsetAsync(stats.p, 0, sizeof(double) * nstats, st));
+    const int tiles = (M + 127) / 128, ntl = tiles * (tiles + 1) / 2;
+    for (int t = 0; t < T; ++t) {
+      Task& k = tasks[t];
+      for (long long r0 = rb[t]; r0 < re[t]; r0 += chunk) {
+        const long long n = std::min(chunk, re[t] - r0);
+        const double* X = k.X.d() + r0 * P;
+        for (int q = 0; q < Q; ++q) {
+          double* kh = Kh.d() + (long long)q * ldn * M;
+          double* pt = Pt.d() + (long long)q * ldn * M;
+          {
+            Scope sc(this, CAT_RBF, 1);
+            launch_rbf(X, P, n, P, dZ.d() + q * P, ldz, M, h_var[q], h_ell[q], kh, false, st);
+          }
+          {
+            Scope sc(this, CAT_FWD, 1);
+            GemmArgs g;
+            g.A = kh, g.lda = M, g.a_kmajor = 0;
+            g.B = C.d() + q * MM, g.ldb = M, g.b_kmajor = 1;
+            g.C = pt, g.ldc = M;
+            g.M = (int)n, g.N = M, g.K = M;
+            launch_gemm_f64(g, st);
+          }
+          {
+            Scope sc(this, CAT_ROWSTATS, 1);
+            launch_rowstats(kh, pt, a.d() + (long long)q * M, X, P, dZ.d() + q * P, ldz, h_ell[q], n, M, vp.d() + q * ldn,
+                            vc.d() + q * ldn, vpt.d() + q * ldn, vct.d() + q * ldn, want_hyper, st);
+          }
+        }
+        {
+          Scope sc(this, CAT_QUAD, 2);
+          QuadArgs qa;
+          qa.lik = k.lik, qa.lik_param = k.param, qa.dimf = k.dimf, qa.Q = Q, qa.N = n;
+          qa.y = k.Y.d() + r0;
+          qa.yaux = k.Yaux.p ? k.Yaux.d() + r0 : nullptr;
+          qa.p = vp.d(), qa.c = vc.d();
+          qa.pt = want_hyper ? vpt.d() : nullptr, qa.ct = want_hyper ? vct.d() : nullptr;
+          qa.ldn = ldn;
+          std::memset(qa.w, 0, sizeof(qa.w)), std::memset(qa.w0, 0, sizeof(qa.w0)), std::memset(qa.kap, 0, sizeof(qa.kap));
+          std::memset(qa.var, 0, sizeof(qa.var));
+          for (int q = 0; q < Q; ++q) {
+            qa.var[q] = h_var[q];
+            for (int j = 0; j < k.dimf; ++j) {
+              qa.w[q][j] = h_W[q * Df + k.d0 + j];
+              qa.w0[q][j] = h_W0[q * Df + k.d0 + j];
+              qa.kap[q][j] = h_kap[q * Df + k.d0 + j];
+            }
+          }
+          qa.scale = h_bs[t];
+          qa.alpha = valpha.d(), qa.beta = vbeta.d(), qa.alpha0 = valpha0.d(), qa.beta0 = vbeta0.d();
+          qa.partials = quadpart.d();
+          launch_quad(qa, st);
+          launch_reduce_rows(quadpart.d(), quad_blocks(k.lik, n), k.nscal, k.offsets.as<long long>(), stats.d(), true, st);
+        }
+        for (int q = 0; q < Q; ++q) {
+          const double* kh = Kh.d() + (long long)q * ldn * M;
+          const double* pt = Pt.d() + (long long)q * ldn * M;
+          {
+            Scope sc(this, CAT_GRAM, 2);  // H_q += K^T diag(beta) K^   (svmogp_inf.py:145-147 summed over d)
+            const long long ksteps = (n + 15) / 16;
+            int ksplit = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(64, ksteps), (1024 + ntl - 1) / ntl));
+            slabs.ensure(sizeof(double) * MM * 64, true);
+            GemmArgs g;
+            g.A = kh, g.lda = M, g.a_kmajor = 1;
+            g.B = kh, g.ldb = M, g.b_kmajor = 1;
+            g.kscale = vbeta.d() + q * ldn;
+            g.C = slabs.d(), g.ldc = M;
+            g.M = g.N = M, g.K = (int)n;
+            g.lower_only = 1;
+            g.ksplit = ksplit, g.sSplit = MM;
+            launch_gemm_f64(g, st);
+            launch_reduce_slabs(slabs.d(), ksplit, MM, MM, Hq(q), true, st);
+          }
+          {
+            Scope sc(this, CAT_COLSTATS, 2);
+            const long long len = (long long)M * (1 + P);
+            launch_colstats(kh, pt, a.d() + (long long)q * M, valpha.d() + q * ldn, valpha0.d() + q * ldn,
+                            vbeta0.d() + q * ldn, X, P, dZ.d() + q * P, ldz, n, M, 256, want_z, colpart.d(), st);
+            launch_reduce_slabs(colpart.d(), (int)((n + 255) / 256), len, len, Hq(q) + oR, true, st);
+          }
+        }
+      }
+    }
+    launch_mirror_lower(Hq(0), Q, M, per_q, st);
+  }
+
+  void begin(const hmogp_params* p) {
+    HIP_TRY(hipSetDevice(device));
+    began = false;
+    for (int c = 0; c < NCAT; ++c) ms[c] = 0.0, launches[c] = 0;
+    upload_params(p);
+    HIP_TRY(hipEventRecord(ev_begin0, st));
+    u_algebra();
+    row_pass();
+    HIP_TRY(hipEventRecord(ev_begin1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    began = true;
+  }
+
+  // ------------------------------------------------------------------------------------------ finish
+  void finish(hmogp_outputs* out) {
+    if (!began) throw EngineError{HMOGP_E_STATE, "hmogp_step_finish without hmogp_step_begin"};
+    if (!out) throw EngineError{HMOGP_E_INVALID, "null outputs"};
+    HIP_TRY(hipSetDevice(device));
+    const long long MM = (long long)M * M, Mtri = (long long)M * (M + 1) / 2;
+    const bool want_qu = (group_mask & HMOGP_GROUP_QU) != 0 || out->dL_dS != nullptr;
+    const bool want_hz = (group_mask & (HMOGP_GROUP_HYPER | HMOGP_GROUP_Z)) != 0;
+    HIP_TRY(hipEventRecord(ev_fin0, st));
+    {
+      Scope sc(this, CAT_MM, 0);
+      mm(Hq(0), false, Kuui.d(), true, HK.d(), 1.0, per_q);          // H K^-1
+      mm(Kuui.d(), false, HK.d(), true, G.d());                      // G = K^-1 H K^-1  (dVE_dS, svmogp_inf.py:148)
+      launch_gemv_batched(Kuui.d(), Hq(0) + oR, Kr.d(), Q, M, per_q, 1, st);  // K^-1 r  (dVE_dmu, :144)
+      if (want_hz) {
+        mm(G.d(), false, KiS.d(), false, GSK.d());                   // G S K^-1        (tmp_dv, :151)
+        launch_dkmm(G.d(), GSK.d(), Kuui.d(), KSK.d(), Kr.d(), a.d(), dKmm.d(), Q, M, st);
+        launch_kzz_rows(dKmm.d(), dZ.d(), Q * P, P, dvar.d(), dell.d(), Q, M, rowout.d(), st);
+      }
+      if (want_qu) {
+        launch_dlds(G.d(), Kuui.d(), Sqi.d(), dLdS.d(), MM * Q, st);
+        mm(dLdS.d(), false, L.d(), true, tmpA.d());                  // dL_dS L          (:175-177)
+        launch_pack_gl(tmpA.d(), gL.d(), Q, M, st);
+        launch_gmu(Kr.d(), a.d(), gmu.d(), Q, M, st);
+      }
+      launch_kl_terms(Kuui.d(), S.d(), dmu.d(), a.d(), Luu.d(), L.d(), Sqi.d(), Q, M, klout.d(), st);
+    }
+    // ---- device -> host ------------------------------------------------------------------------------
+    std::vector<double> hg(NG), hkl(Q * 5), htail(Q * (per_q - oDZ)), hrow(want_hz ? (size_t)Q * M * (2 + P) : 0);
+    HIP_TRY(hipMemcpyAsync(hg.data(), stats.p, sizeof(double) * NG, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hkl.data(), klout.p, sizeof(double) * Q * 5, hipMemcpyDeviceToHost, st));
+    for (int q = 0; q < Q; ++q)
+      HIP_TRY(hipMemcpyAsync(htail.data() + q * (per_q - oDZ), Hq(q) + oDZ, sizeof(double) * (per_q - oDZ),
+                             hipMemcpyDeviceToHost, st));
+    if (want_hz) HIP_TRY(hipMemcpyAsync(hrow.data(), rowout.p, sizeof(double) * hrow.size(), hipMemcpyDeviceToHost, st));
+    const bool qu = (group_mask & HMOGP_GROUP_QU) != 0;
+    if (out->g_m_u) {
+      if (qu) HIP_TRY(hipMemcpyAsync(out->g_m_u, gmu.p, sizeof(double) * M * Q, hipMemcpyDeviceToHost, st));
+      else std::memset(out->g_m_u, 0, sizeof(double) * M * Q);
+    }
+    if (out->g_L_u) {
+      if (qu) HIP_TRY(hipMemcpyAsync(out->g_L_u, gL.p, sizeof(double) * Mtri * Q, hipMemcpyDeviceToHost, st));
+      else std::memset(out->g_L_u, 0, sizeof(double) * Mtri * Q);
+    }
+    if (out->dL_dS) HIP_TRY(hipMemcpyAsync(out->dL_dS, dLdS.p, sizeof(double) * MM * Q, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(ev_fin1, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    collect_spans();
+    float f0 = 0.f, f1 = 0.f;
+    (void)hipEventElapsedTime(&f0, ev_begin0, ev_begin1);
+    (void)hipEventElapsedTime(&f1, ev_fin0, ev_fin1);
+    ms[CAT_TOTAL] = f0 + f1;
+
+    // ---- host assembly (svmogp.py:101-166) -----------------------------------------------------------
+    double KL = 0.0, ninf = 0.0;
+    for (int q = 0; q < Q; ++q) {
+      const double* k = &hkl[q * 5];
+      KL += 0.5 * k[0] + 0.5 * k[1] - 0.5 * M + k[2] - k[3];  // svmogp_inf.py:245-249
+      ninf += k[4];
+    }
+    if (out->elbo) out->elbo[0] = hg[0] - KL;
+    if (out->flags) out->flags[0] = (hg[1] > 0.0) ? HMOGP_FLAG_V_NEGATIVE : 0u;
+    if (out->rung) std::copy(rung.begin(), rung.end(), out->rung);
+    const bool hy = (group_mask & HMOGP_GROUP_HYPER) != 0, zz = (group_mask & HMOGP_GROUP_Z) != 0;
+    const double* sgv = &hg[2];
+    for (int q = 0; q < Q; ++q) {
+      const double* tail = &htail[q * (per_q - oDZ)];
+      const double* dZs = tail;
+      const double sa = tail[oSA - oDZ], sl = tail[oSL - oDZ];
+      const double* swk = tail + (oSWK - oDZ);
+      double s1 = 0.0, s2 = 0.0;
+      if (want_hz)
+        for (int m = 0; m < M; ++m) {
+          s1 += hrow[((size_t)q * M + m) * (2 + P)];
+          s2 += hrow[((size_t)q * M + m) * (2 + P) + 1];
+        }
+      const double var = h_var[q], ell = h_ell[q];
+      if (out->g_variance) {
+        double g = 0.0;
+        if (hy) {
+          g = s1 / var + sa / var;
+          for (int d = 0; d < Df; ++d) g += (h_W0[q * Df + d] * h_W0[q * Df + d] + h_kap0[q * Df + d]) * sgv[d];
+        }
+        out->g_variance[q] = g;
+      }
+      if (out->g_lengthscale) out->g_lengthscale[q] = hy ? (s2 / ell + sl / ell) : 0.0;
+      for (int d = 0; d < Df; ++d) {
+        if (out->g_W) out->g_W[q * Df + d] = hy ? (h_W[q * Df + d] * sgv[d] + swk[d]) : 0.0;  // util.py:230 + :252
+        if (out->g_kappa) out->g_kappa[q * Df + d] = hy ? sgv[d] : 0.0;                         // util.py:231
+      }
+      if (out->g_Z)
+        for (int m = 0; m < M; ++m)
+          for (int p = 0; p < P; ++p)
+            out->g_Z[(size_t)m * Q * P + q * P + p] =
+                zz ? (dZs[m * P + p] / (ell * ell) + hrow[((size_t)q * M + m) * (2 + P) + 2 + p] / (ell * ell)) : 0.0;
+    }
+    evaluated = true;
+    began = false;
+    if (ninf > 0.0) throw EngineError{HMOGP_E_SQI_UNSTABLE, "Sqi: Cholesky representation unstable"};
+  }
+
+  // ------------------------------------------------------------------------------------------ consumers
+  void posterior_u(double* wv, double* winv) {
+    if (!evaluated && !began) throw EngineError{HMOGP_E_STATE, "no evaluation to take the posterior from"};
+    HIP_TRY(hipSetDevice(device));
+    const long long MM = (long long)M * M;
+    if (wv) HIP_TRY(hipMemcpyAsync(wv, a.p, sizeof(double) * Q * M, hipMemcpyDeviceToHost, st));
+    if (winv) {
+      launch_sub(Kuui.d(), KSK.d(), tmpA.d(), MM * Q, st);  // K^-1 - K^-1 S K^-1 (GPy Posterior.woodbury_inv)
+      HIP_TRY(hipMemcpyAsync(winv, tmpA.p, sizeof(double) * MM * Q, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+
+  void predict_f(const double* Xnew, long long Nnew, double* m, double* v) {
+    if (!evaluated && !began) throw EngineError{HMOGP_E_STATE, "no evaluation to predict from"};
+    if (Nnew < 0 || (Nnew > 0 && (!Xnew || !m || !v))) throw EngineError{HMOGP_E_INVALID, "bad predict arguments"};
+    HIP_TRY(hipSetDevice(device));
+    const long long MM = (long long)M * M;
+    const int ldz = Q * P;
+    ensure_workspace(std::min(chunk, std::max<long long>(Nnew, 1)));
+    const long long ldn = ws_rows;
+    DevBuf dX, dm, dv;
+    dX.ensure(sizeof(double) * ldn * P), dm.ensure(sizeof(double) * ldn * Df), dv.ensure(sizeof(double) * ldn * Df);
+    for (long long r0 = 0; r0 < Nnew; r0 += ldn) {
+      const long long n = std::min(ldn, Nnew - r0);
+      HIP_TRY(hipMemcpyAsync(dX.p, Xnew + r0 * P, sizeof(double) * n * P, hipMemcpyHostToDevice, st));
+      for (int q = 0; q < Q; ++q) {
+        double* kh = Kh.d() + (long long)q * ldn * M;
+        double* pt = Pt.d() + (long long)q * ldn * M;
+        launch_rbf(dX.d(), P, n, P, dZ.d() + q * P, ldz, M, h_var[q], h_ell[q], kh, false, st);
+        GemmArgs g;
+        g.A = kh, g.lda = M, g.a_kmajor = 0;
+        g.B = C.d() + q * MM, g.ldb = M, g.b_kmajor = 1;
+        g.C = pt, g.ldc = M;
+        g.M = (int)n, g.N = M, g.K = M;
+        launch_gemm_f64(g, st);
+        launch_rowstats(kh, pt, a.d() + (long long)q * M, dX.d(), P, dZ.d() + q * P, ldz, h_ell[q], n, M, vp.d() + q * ldn,
+                        vc.d() + q * ldn, nullptr, nullptr, false, st);
+      }
+      launch_qf_combine(vp.d(), vc.d(), ldn, n, Q, Df, dW.d(), dkap.d(), dvar.d(), dm.d(), dv.d(), st);
+      HIP_TRY(hipMemcpyAsync(m + r0 * Df, dm.p, sizeof(double) * n * Df, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(v + r0 * Df, dv.p, sizeof(double) * n * Df, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+  }
+};
+
+// =================================================================================================== C ABI
+namespace {
+
+template <class F>
+int guarded(hmogp_engine* h, F&& f) {
+  std::string* err = h ? &h->err : &g_create_error;
+  try {
+    f();
+    return HMOGP_OK;
+  } catch (const EngineError& e) {
+    *err = e.msg;
+    return e.code;
+  } catch (const HipError& e) {
+    char buf[512];
+    std::snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d in %s", (int)e.code, hipGetErrorString(e.code), e.file, e.line,
+                  e.what);
+    *err = buf;
+    return HMOGP_E_NO_DEVICE;
+  } catch (const std::exception& e) {
+    *err = e.what();
+    return HMOGP_E_INVALID;
+  }
+}
+
+void need_device(int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    throw EngineError{HMOGP_E_NO_DEVICE, "no HIP device visible (this library has no CPU path)"};
+  if (device < 0 || device >= ndev) throw EngineError{HMOGP_E_NO_DEVICE, "HIP device ordinal out of range"};
+  HIP_TRY(hipSetDevice(device));
+}
+
+}  // namespace
+
+extern "C" {
+
+int hmogp_abi_version(void) { return HMOGP_ABI_VERSION; }
+
+int hmogp_create(const hmogp_config* cfg, hmogp_handle* out) {
+  if (!out) return HMOGP_E_INVALID;
+  *out = nullptr;
+  hmogp_engine* e = nullptr;
+  int rc = guarded(nullptr, [&] {
+    e = new hmogp_engine();
+    e->init(cfg);
+  });
+  if (rc != HMOGP_OK) {
+    delete e;
+    return rc;
+  }
+  *out = e;
+  return HMOGP_OK;
+}
+
+void hmogp_destroy(hmogp_handle h) { delete h; }
+
+const char* hmogp_last_error(hmogp_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int hmogp_set_task_data(hmogp_handle h, int32_t t, const double* X, const double* Y, int64_t N) {
+  if (!h) return HMOGP_E_INVALID;
+  return guarded(h, [&] { h->set_task_data(t, X, Y, N); });
+}
+
+int hmogp_step_begin(hmogp_handle h, const hmogp_params* p) {
+  if (!h) return HMOGP_E_INVALID;
+  return guarded(h, [&] { h->begin(p); });
+}
+
+int hmogp_stats_buffer(hmogp_handle h, void** device_ptr, int64_t* count) {
+  if (!h || !device_ptr || !count) return HMOGP_E_INVALID;
+  *device_ptr = h->stats.p;
+  *count = h->nstats;
+  return HMOGP_OK;
+}
+
+int hmogp_stats_read(hmogp_handle h, double* host) {
+  if (!h || !host) return HMOGP_E_INVALID;
+  return guarded(h, [&] {
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy(host, h->stats.p, sizeof(double) * h->nstats, hipMemcpyDeviceToHost));
+  });
+}
+
+int hmogp_stats_write(hmogp_handle h, const double* host) {
+  if (!h || !host) return HMOGP_E_INVALID;
+  return guarded(h, [&] {
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpy(h->stats.p, host, sizeof(double) * h->nstats, hipMemcpyHostToDevice));
+  });
+}
+
+int hmogp_step_finish(hmogp_handle h, hmogp_outputs* out) {
+  if (!h) return HMOGP_E_INVALID;
+  return guarded(h, [&] { h->finish(out); });
+}
+
+int hmogp_elbo_grad(hmogp_handle h, const hmogp_params* p, hmogp_outputs* out) {
+  if (!h) return HMOGP_E_INVALID;
+  return guarded(h, [&] {
+    h->begin(p);
+    h->finish(out);
+  });
+}
+
+int hmogp_posterior_u(hmogp_handle h, double* woodbury_vector, double* woodbury_inv) {
+  if (!h) return HMOGP_E_INVALID;
+  return guarded(h, [&] { h->posterior_u(woodbury_vector, woodbury_inv); });
+}
+
+int hmogp_predict_f(hmogp_handle h, const double* Xnew, int64_t Nnew, double* m, double* v) {
+  if (!h) return HMOGP_E_INVALID;
+  return guarded(h, [&] { h->predict_f(Xnew, Nnew, m, v); });
+}
+
+int hmogp_last_timings(hmogp_handle h, double* out_ms8, int64_t* launches8) {
+  if (!h || !out_ms8) return HMOGP_E_INVALID;
+  for (int c = 0; c < NCAT; ++c) {
+    out_ms8[c] = h->ms[c];
+    if (launches8) launches8[c] = h->launches[c];
+  }
+  return HMOGP_OK;
+}
+
+// ---- building blocks -----------------------------------------------------------------------------------
+int hmogp_rbf_cross_cov(int32_t device, const double* X, int64_t N, const double* Z, int32_t M, int32_t P, double variance,
+                        double lengthscale, double* K) {
+  return guarded(nullptr, [&] {
+    need_device(device);
+    if (N <= 0 || M <= 0 || !X || !Z || !K) throw EngineError{HMOGP_E_INVALID, "bad arguments"};
+    DevBuf dX, dZ, dK;
+    dX.ensure(sizeof(double) * N * P), dZ.ensure(sizeof(double) * M * P), dK.ensure(sizeof(double) * N * M);
+    HIP_TRY(hipMemcpy(dX.p, X, sizeof(double) * N * P, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dZ.p, Z, sizeof(double) * M * P, hipMemcpyHostToDevice));
+    launch_rbf(dX.d(), P, N, P, dZ.d(), P, M, variance, lengthscale, dK.d(), false, nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(K, dK.p, sizeof(double) * N * M, hipMemcpyDeviceToHost));
+  });
+}
+
+int hmogp_jitchol_inv(int32_t device, const double* A, int32_t Q, int32_t M, const int32_t* forced_rung, double* L,
+                      double* Ainv, int32_t* rung) {
+  return guarded(nullptr, [&] {
+    need_device(device);
+    if (Q <= 0 || M <= 0 || !A) throw EngineError{HMOGP_E_INVALID, "bad arguments"};
+    const long long MM = (long long)M * M;
+    DevBuf dA, dL, dLi, dT, dO, info, jit, scr;
+    for (DevBuf* b : {&dA, &dL, &dLi, &dT, &dO}) b->ensure(sizeof(double) * MM * Q, true);
+    info.ensure(sizeof(int) * Q), jit.ensure(sizeof(double) * Q), scr.ensure(sizeof(double) * Q * M * 32);
+    HIP_TRY(hipMemcpy(dA.p, A, sizeof(double) * MM * Q, hipMemcpyHostToDevice));
+    std::vector<double> dmean(Q);
+    std::vector<int> r(Q);
+    for (int q = 0; q < Q; ++q) {
+      double s = 0.0;
+      for (int i = 0; i < M; ++i) s += A[q * MM + (long long)i * M + i];
+      dmean[q] = s / M;
+      r[q] = forced_rung ? forced_rung[q] : -2;
+    }
+    jitchol_batched(dA.d(), dL.d(), Q, M, dmean.data(), r.data(), info.as<int>(), jit.d(), scr.d(), nullptr);
+    if (rung) std::copy(r.begin(), r.end(), rung);
+    if (L) HIP_TRY(hipMemcpy(L, dL.p, sizeof(double) * MM * Q, hipMemcpyDeviceToHost));
+    if (Ainv) {
+      launch_trtri_batched(dL.d(), dLi.d(), dT.d(), Q, M, nullptr);
+      launch_ltl_batched(dLi.d(), dO.d(), Q, M, nullptr);
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipMemcpy(Ainv, dO.p, sizeof(double) * MM * Q, hipMemcpyDeviceToHost));
+    }
+  });
+}
+
+int hmogp_potri(int32_t device, const double* L, int32_t Q, int32_t M, double* Sinv) {
+  return guarded(nullptr, [&] {
+    need_device(device);
+    if (Q <= 0 || M <= 0 || !L || !Sinv) throw EngineError{HMOGP_E_INVALID, "bad arguments"};
+    const long long MM = (long long)M * M;
+    DevBuf dL, dLi, dT, dO;
+    for (DevBuf* b : {&dL, &dLi, &dT, &dO}) b->ensure(sizeof(double) * MM * Q, true);
+    HIP_TRY(hipMemcpy(dL.p, L, sizeof(double) * MM * Q, hipMemcpyHostToDevice));
+    launch_trtri_batched(dL.d(), dLi.d(), dT.d(), Q, M, nullptr);
+    launch_ltl_batched(dLi.d(), dO.d(), Q, M, nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(Sinv, dO.p, sizeof(double) * MM * Q, hipMemcpyDeviceToHost));
+  });
+}
+
+int hmogp_gemm_f64(int32_t device, int32_t transA, int32_t transB, int32_t M, int32_t N, int32_t K, double alpha,
+                   const double* A, int32_t lda, const double* B, int32_t ldb, double beta, double* C, int32_t ldc) {
+  return guarded(nullptr, [&] {
+    need_device(device);
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) throw EngineError{HMOGP_E_INVALID, "bad arguments"};
+    const long long na = (long long)(transA ? K : M) * lda, nb = (long long)(transB ? N : K) * ldb, nc = (long long)M * ldc;
+    DevBuf dA, dB, dC;
+    dA.ensure(sizeof(double) * na), dB.ensure(sizeof(double) * nb), dC.ensure(sizeof(double) * nc);
+    HIP_TRY(hipMemcpy(dA.p, A, sizeof(double) * na, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dB.p, B, sizeof(double) * nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dC.p, C, sizeof(double) * nc, hipMemcpyHostToDevice));
+    GemmArgs g;
+    g.A = dA.d(), g.B = dB.d(), g.C = dC.d();
+    g.M = M, g.N = N, g.K = K;
+    g.lda = lda, g.ldb = ldb, g.ldc = ldc;
+    g.a_kmajor = transA ? 1 : 0;  // op(A) = A^T: A stored [k][i]
+    g.b_kmajor = transB ? 0 : 1;  // op(B) = B^T: B stored [j][k]
+    g.alpha = alpha, g.beta = beta;
+    launch_gemm_f64(g, nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(C, dC.p, sizeof(double) * nc, hipMemcpyDeviceToHost));
+  });
+}
+
+int hmogp_var_exp(int32_t device, int32_t lik_id, double lik_param, int64_t N, const double* y, const double* m,
+                  const double* v, double* ve, double* dm, double* dv) {
+  return guarded(nullptr, [&] {
+    need_device(device);
+    if (lik_id == HMOGP_LIK_GAUSSIAN && !(lik_param > 0.0)) lik_param = 0.5;
+    const int J = lik_dimf(lik_id, lik_param);
+    if (J < 1 || J > HMOGP_MAXJ || N <= 0 || !y || !m || !v || !ve || !dm || !dv)
+      throw EngineError{HMOGP_E_INVALID, "bad arguments"};
+    DevBuf dy, dmm, dvv, dve, ddm, ddv;
+    dy.ensure(sizeof(double) * N), dve.ensure(sizeof(double) * N);
+    for (DevBuf* b : {&dmm, &dvv, &ddm, &ddv}) b->ensure(sizeof(double) * N * J);
+    HIP_TRY(hipMemcpy(dy.p, y, sizeof(double) * N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dmm.p, m, sizeof(double) * N * J, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dvv.p, v, sizeof(double) * N * J, hipMemcpyHostToDevice));
+    launch_var_exp(lik_id, J, lik_param, N, dy.d(), dmm.d(), dvv.d(), dve.d(), ddm.d(), ddv.d(), nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(ve, dve.p, sizeof(double) * N, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dm, ddm.p, sizeof(double) * N * J, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dv, ddv.p, sizeof(double) * N * J, hipMemcpyDeviceToHost));
+  });
+}
+
+}  // extern "C"

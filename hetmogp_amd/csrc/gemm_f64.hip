@@ -1,0 +1,231 @@
+// gemm_f64.hip -- FP64 GEMM on the CDNA4 matrix cores (v_mfma_f64_16x16x4_f64), gfx950 only.
+//
+// One kernel serves every dense contraction of the svmogp_inf path:
+//   forward   P~ = K^ C_q                 (N x M x M, A row-major -> transposing LDS stage)
+//   backward  H += K^T diag(beta) K^      (M x M x N, both operands k-major, k-scaled, split over N, lower tiles)
+//   M x M     Kuu^-1 S, G = Kuu^-1 H Kuu^-1, trailing Cholesky updates, triangular-inverse merges, ...
+//
+// Tiling (wave64, 4 waves = one per SIMD): block tile 128 x 128 x 16, wave tile 64 x 64 = 4 x 4 MFMA tiles of
+// 16 x 16, 16 independent accumulators per wave (128 VGPRs) so the 64-cycle FP64 MFMA issues back to back.
+// Both operands are staged k-major in LDS ([k][row], leading dimension 144 doubles): the MFMA A/B fragment of
+// lane l is element [k = l>>4][row = l&15], so a wave reads 4 runs of 16 consecutive doubles; 144*8 B = 288
+// dwords == 32 banks (mod 64) puts the two k-rows of each 32-lane half on disjoint banks (ds_read_b64 is
+// conflict-free).  LDS is double buffered; the next tile's global loads are issued before the MFMA block.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDS_LD = 144, NTHREADS = 256;
+
+struct Tile {
+  double a[2][BK][LDS_LD];
+  double b[2][BK][LDS_LD];
+};
+
+// Load 8 consecutive doubles p[0..7] (16-byte vector loads) -- caller guarantees alignment and bounds.
+__device__ __forceinline__ void load8_fast(const double* __restrict__ p, double (&v)[8]) {
+  const f64x2* q = reinterpret_cast<const f64x2*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f64x2 t = q[i];
+    v[2 * i] = t.x;
+    v[2 * i + 1] = t.y;
+  }
+}
+
+// Operand stored [row][k] (k contiguous): thread loads row r = t>>1, 8 k's starting at (t&1)*8.
+__device__ __forceinline__ void load_rowmajor(const double* __restrict__ base, int ld, int row0, int nrows, int k0,
+                                              int kend, bool fast, double (&v)[8]) {
+  const int t = threadIdx.x, r = t >> 1, kh = (t & 1) * 8;
+  const double* p = base + (long long)(row0 + r) * ld + (k0 + kh);
+  if (fast) {
+    load8_fast(p, v);
+  } else {
+    const bool rok = (row0 + r) < nrows;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (rok && (k0 + kh + i) < kend) ? p[i] : 0.0;
+  }
+}
+__device__ __forceinline__ void store_rowmajor(double (*s)[LDS_LD], const double (&v)[8]) {
+  const int t = threadIdx.x, r = t >> 1, kh = (t & 1) * 8;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[kh + i][r] = v[i];
+}
+
+// Operand stored [k][col] (col contiguous): thread loads k = t>>4, 8 cols starting at (t&15)*8.
+__device__ __forceinline__ void load_kmajor(const double* __restrict__ base, int ld, int col0, int ncols, int k0,
+                                            int kend, bool fast, double (&v)[8]) {
+  const int t = threadIdx.x, k = t >> 4, c8 = (t & 15) * 8;
+  const double* p = base + (long long)(k0 + k) * ld + (col0 + c8);
+  if (fast) {
+    load8_fast(p, v);
+  } else {
+    const bool kok = (k0 + k) < kend;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (kok && (col0 + c8 + i) < ncols) ? p[i] : 0.0;
+  }
+}
+__device__ __forceinline__ void store_kmajor(double (*s)[LDS_LD], const double (&v)[8]) {
+  const int t = threadIdx.x, k = t >> 4, c8 = (t & 15) * 8;
+  f64x2* q = reinterpret_cast<f64x2*>(&s[k][c8]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = f64x2{v[2 * i], v[2 * i + 1]};
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int tiles_n, int ntiles) {
+  __shared__ __attribute__((aligned(16))) Tile lds;
+
+  // ---- which tile / batch / k-range -----------------------------------------------------------------
+  int v = blockIdx.x;
+  if ((ntiles & 7) == 0) {  // XCD-aware order: block b runs on XCD b%8; give each XCD a contiguous tile range
+    const int cpx = ntiles >> 3;
+    v = (v & 7) * cpx + (v >> 3);
+  }
+  int ti, tj;
+  if (g.lower_only) {
+    ti = (int)((sqrt(8.0 * (double)v + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= v) ++ti;
+    while (ti * (ti + 1) / 2 > v) --ti;
+    tj = v - ti * (ti + 1) / 2;
+  } else {
+    ti = v / tiles_n;
+    tj = v - ti * tiles_n;
+  }
+  const int batch = blockIdx.z / g.ksplit, split = blockIdx.z - batch * g.ksplit;
+  int M = g.M, N = g.N, K = g.K;
+  if (batch == g.nbatch - 1) {
+    if (g.M_last > 0) M = g.M_last;
+    if (g.N_last > 0) N = g.N_last;
+    if (g.K_last > 0) K = g.K_last;
+  }
+  const int i0 = ti * BM, j0 = tj * BN;
+  if (i0 >= M || j0 >= N) return;
+  const int ksteps = (K + BK - 1) / BK;
+  const int per = (ksteps + g.ksplit - 1) / g.ksplit;
+  const int kbeg = split * per * BK;
+  const int kend = min(K, kbeg + per * BK);
+
+  const long long ob = blockIdx.y;
+  const double* __restrict__ A = g.A + (long long)batch * g.sA + ob * g.oA;
+  const double* __restrict__ B = g.B + (long long)batch * g.sB + ob * g.oB;
+  const double* __restrict__ S = g.kscale ? g.kscale + (long long)batch * g.sS + ob * g.oS : nullptr;
+  double* __restrict__ C = g.C + (long long)batch * g.sC + ob * g.oC + (long long)split * g.sSplit;
+
+  // vector-load eligibility (uniform per block)
+  const bool alignA = ((g.lda & 1) == 0) && ((((uintptr_t)A) & 15) == 0);
+  const bool alignB = ((g.ldb & 1) == 0) && ((((uintptr_t)B) & 15) == 0);
+  const bool fullA = alignA && (i0 + BM <= M);
+  const bool fullB = alignB && (j0 + BN <= N);
+
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1, lr = lane & 15, lk = lane >> 4;
+
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  double ra[8], rb[8];
+  auto load = [&](int k0) {
+    const bool fk = (k0 + BK <= kend);
+    if (A_KMAJOR)
+      load_kmajor(A, g.lda, i0, M, k0, kend, fullA && fk, ra);
+    else
+      load_rowmajor(A, g.lda, i0, M, k0, kend, fullA && fk, ra);
+    if (B_KMAJOR) {
+      load_kmajor(B, g.ldb, j0, N, k0, kend, fullB && fk, rb);
+      if (S) {
+        const int k = k0 + (t >> 4);
+        const double s = (k < kend) ? S[k] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rb[i] *= s;
+      }
+    } else {
+      load_rowmajor(B, g.ldb, j0, N, k0, kend, fullB && fk, rb);
+      if (S) {
+        const int kh = k0 + (t & 1) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rb[i] *= ((kh + i) < kend) ? S[kh + i] : 0.0;
+      }
+    }
+  };
+  auto stage = [&](int buf) {
+    if (A_KMAJOR)
+      store_kmajor(lds.a[buf], ra);
+    else
+      store_rowmajor(lds.a[buf], ra);
+    if (B_KMAJOR)
+      store_kmajor(lds.b[buf], rb);
+    else
+      store_rowmajor(lds.b[buf], rb);
+  };
+
+  int cur = 0;
+  if (kbeg < kend) {
+    load(kbeg);
+    stage(0);
+  }
+  __syncthreads();
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = (k0 + BK) < kend;
+    if (more) load(k0 + BK);
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const double* pa = &lds.a[cur][kk * 4 + lk][wm * 64 + lr];
+      const double* pb = &lds.b[cur][kk * 4 + lk][wn * 64 + lr];
+      double fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = pa[i * 16];
+        fb[i] = pb[i * 16];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+    if (more) stage(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: D fragment of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg -----------
+  const double alpha = g.alpha, beta = (g.ksplit > 1) ? 0.0 : g.beta;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i0 + wm * 64 + a * 16 + 4 * r + lk;
+      if (row >= M) continue;
+      double* crow = C + (long long)row * g.ldc;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int col = j0 + wn * 64 + b * 16 + lr;
+        if (col < N) {
+          double val = alpha * acc[a][b][r];
+          if (beta != 0.0) val += beta * crow[col];
+          crow[col] = val;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+void launch_gemm_f64(const GemmArgs& g, hipStream_t stream) {
+  if (g.M <= 0 || g.N <= 0 || g.nbatch <= 0 || g.nouter <= 0) return;
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  const int ntiles = g.lower_only ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
+  dim3 grid(ntiles, g.nouter, g.nbatch * g.ksplit), block(NTHREADS);
+  if (g.a_kmajor && g.b_kmajor)
+    hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, block, 0, stream, g, tiles_n, ntiles);
+  else if (g.a_kmajor && !g.b_kmajor)
+    hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, block, 0, stream, g, tiles_n, ntiles);
+  else if (!g.a_kmajor && g.b_kmajor)
+    hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, block, 0, stream, g, tiles_n, ntiles);
+  else
+    hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, 0, stream, g, tiles_n, ntiles);
+}

@@ -1,0 +1,19 @@
+// post.h -- launchers of the element-wise / reduction kernels of the replicated M x M algebra (post.hip).
+#pragma once
+#include "common.h"
+
+void launch_add_diag_copy(const double* src, double* dst, int Q, int M, const double* d_jit, hipStream_t s);
+void launch_sub(const double* A, const double* B, double* C, long long n, hipStream_t s);
+// out[q*5 + {0..4}] = sum(Kuui.*S), m^T a, sum log|diag Luu|, sum log|diag L|, #inf(Sqi)   (Sqi may be nullptr)
+void launch_kl_terms(const double* Kuui, const double* S, const double* m_u, const double* a, const double* Luu,
+                     const double* L, const double* Sqi, int Q, int M, double* out, hipStream_t s);
+void launch_dkmm(const double* G, const double* GSK, const double* Kuui, const double* KSK, const double* Kr, const double* a,
+                 double* out, int Q, int M, hipStream_t s);
+void launch_dlds(const double* G, const double* Kuui, const double* Sqi, double* out, long long n, hipStream_t s);
+void launch_pack_gl(const double* T, double* gL, int Q, int M, hipStream_t s);
+void launch_gmu(const double* Kr, const double* a, double* g, int Q, int M, hipStream_t s);
+// rowout[q][m][0..2+P) = { sum_j EK, sum_j EK r2, sum_j (EK + EK^T)(z_j - z_m)[p] }
+void launch_kzz_rows(const double* dKmm, const double* Z, int ldz, int P, const double* d_var, const double* d_ell, int Q,
+                     int M, double* rowout, hipStream_t s);
+void launch_qf_combine(const double* p, const double* c, long long ldn, long long N, int Q, int Df, const double* W,
+                       const double* kappa, const double* var, double* m, double* v, hipStream_t s);

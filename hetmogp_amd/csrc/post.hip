@@ -1,0 +1,197 @@
+// post.hip -- element-wise / reduction kernels of the replicated M x M algebra (gfx950): the pieces of
+// SVMOGPInf.calculate_KL (svmogp_inf.py:227-250), calculate_gradients (:111-183) and of the K_uu half of
+// SVMOGP.parameters_changed (svmogp.py:116,154) that are not GEMMs.
+#include "post.h"
+#include "rbf_device.h"
+
+namespace {
+
+// dst[q] = src[q] + jit[q] * I     (GPy jitchol adds the jitter to the factorised copy only, util.py:198)
+__global__ void add_diag_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int M,
+                                     const double* __restrict__ jit) {
+  const int q = blockIdx.z, r = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= M) return;
+  const long long i = ((long long)q * M + r) * M + c;
+  dst[i] = src[i] + ((r == c) ? jit[q] : 0.0);
+}
+
+__global__ void sub_kernel(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) C[i] = A[i] - B[i];
+}
+
+// out[q][0] = sum(Kuui .* S), [1] = m^T a, [2] = sum log|diag Luu|, [3] = sum log|diag L|, [4] = #inf in Sqi
+__global__ __launch_bounds__(256) void kl_terms_kernel(const double* __restrict__ Kuui, const double* __restrict__ S,
+                                                       const double* __restrict__ m_u, const double* __restrict__ a,
+                                                       const double* __restrict__ Luu, const double* __restrict__ L,
+                                                       const double* __restrict__ Sqi, int Q, int M,
+                                                       double* __restrict__ out) {
+  __shared__ double scratch[16];
+  const int q = blockIdx.x, t = threadIdx.x;
+  const long long MM = (long long)M * M, base = (long long)q * MM;
+  double tr = 0.0, ninf = 0.0;
+  for (long long i = t; i < MM; i += 256) {
+    tr += Kuui[base + i] * S[base + i];
+    if (Sqi) ninf += isinf(Sqi[base + i]) ? 1.0 : 0.0;
+  }
+  double ma = 0.0, l1 = 0.0, l2 = 0.0;
+  for (int i = t; i < M; i += 256) {
+    ma += m_u[(long long)i * Q + q] * a[(long long)q * M + i];
+    l1 += log(fabs(Luu[base + (long long)i * M + i]));
+    l2 += log(fabs(L[base + (long long)i * M + i]));
+  }
+  tr = block_sum(tr, scratch);
+  ma = block_sum(ma, scratch);
+  l1 = block_sum(l1, scratch);
+  l2 = block_sum(l2, scratch);
+  ninf = block_sum(ninf, scratch);
+  if (t == 0) {
+    out[q * 5 + 0] = tr;
+    out[q * 5 + 1] = ma;
+    out[q * 5 + 2] = l1;
+    out[q * 5 + 3] = l2;
+    out[q * 5 + 4] = ninf;
+  }
+}
+
+// dL_dKmm (svmogp_inf.py:130-133,151-154,166,170):
+//   X = G - GSK - GSK^T - (Kuui r) a^T ;  dVE = (X + X^T)/2 ;  dKL = Kuui/2 - KSK/2 - a a^T/2 ;  out = dVE - dKL
+__global__ void dkmm_kernel(const double* __restrict__ G, const double* __restrict__ GSK, const double* __restrict__ Kuui,
+                            const double* __restrict__ KSK, const double* __restrict__ Kr, const double* __restrict__ a,
+                            double* __restrict__ out, int M) {
+  const int q = blockIdx.z, i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= M) return;
+  const long long b = (long long)q * M * M, ij = b + (long long)i * M + j, ji = b + (long long)j * M + i;
+  const double* kr = Kr + (long long)q * M;
+  const double* av = a + (long long)q * M;
+  const double xij = G[ij] - GSK[ij] - GSK[ji] - kr[i] * av[j];
+  const double xji = G[ji] - GSK[ji] - GSK[ij] - kr[j] * av[i];
+  const double dve = 0.5 * (xij + xji);
+  const double dkl = 0.5 * Kuui[ij] - 0.5 * KSK[ij] - 0.5 * (av[i] * av[j]);
+  out[ij] = dve - dkl;
+}
+
+// dL_dS = G - (Kuui - Sqi)/2        (svmogp_inf.py:131,169)
+__global__ void dlds_kernel(const double* __restrict__ G, const double* __restrict__ Kuui, const double* __restrict__ Sqi,
+                            double* __restrict__ out, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = G[i] - 0.5 * (Kuui[i] - Sqi[i]);
+}
+
+// gL[(r(r+1)/2 + c) * Q + q] = 2 * T[q][r][c], c <= r      (svmogp_inf.py:175-178, GPy triang_to_flat)
+__global__ void pack_gl_kernel(const double* __restrict__ T, double* __restrict__ gL, int Q, int M) {
+  const int q = blockIdx.z, r = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > r || c >= M) return;
+  gL[((long long)r * (r + 1) / 2 + c) * Q + q] = 2.0 * T[((long long)q * M + r) * M + c];
+}
+
+// g_m_u[m*Q + q] = Kr[q][m] - a[q][m]     (svmogp_inf.py:130,144,168)
+__global__ void gmu_kernel(const double* __restrict__ Kr, const double* __restrict__ a, double* __restrict__ g, int Q, int M) {
+  const int q = blockIdx.y, m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m < M) g[(long long)m * Q + q] = Kr[(long long)q * M + m] - a[(long long)q * M + m];
+}
+
+// K_uu half of the kernel-hyper / Z gradients (GPy RBF.update_gradients_full(dL_dKmm, Zq) and
+// gradients_X(dL_dKmm, Zq) with X2=None: diagonal distance forced to 0, dL_dK + dL_dK^T).  One wave per row m:
+//   rowout[q][m] = { sum_j EK_mj , sum_j EK_mj r2_mj , sum_j (EK_mj + EK_jm)(z_j - z_m)[p] ... }   EK = dKmm .* Kzz
+template <int P>
+__global__ __launch_bounds__(256) void kzz_rows_kernel(const double* __restrict__ dKmm, const double* __restrict__ Z, int ldz,
+                                                       const double* __restrict__ var, const double* __restrict__ ell,
+                                                       int M, double* __restrict__ rowout) {
+  const int q = blockIdx.y, m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (m >= M) return;
+  const double* Zq = Z + (long long)q * P;
+  const double* D = dKmm + (long long)q * M * M;
+  const double v = var[q], l = ell[q];
+  double zm[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) zm[p] = Zq[(long long)m * ldz + p];
+  const double zmsq = sumsq<P>(zm);
+  double s1 = 0.0, s2 = 0.0, gz[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) gz[p] = 0.0;
+  for (int j = lane; j < M; j += 64) {
+    double zj[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) zj[p] = Zq[(long long)j * ldz + p];
+    double r2 = rbf_r2<P>(zm, zmsq, zj, sumsq<P>(zj), l);
+    if (j == m) r2 = 0.0;
+    const double kz = v * exp(-0.5 * r2);
+    const double ek = D[(long long)m * M + j] * kz, ekt = D[(long long)j * M + m] * kz;
+    s1 += ek;
+    s2 += ek * r2;
+#pragma unroll
+    for (int p = 0; p < P; ++p) gz[p] += (ek + ekt) * (zj[p] - zm[p]);
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+#pragma unroll
+  for (int p = 0; p < P; ++p) gz[p] = wave_sum(gz[p]);
+  if (lane == 0) {
+    double* o = rowout + ((long long)q * M + m) * (2 + P);
+    o[0] = s1;
+    o[1] = s2;
+#pragma unroll
+    for (int p = 0; p < P; ++p) o[2 + p] = gz[p];
+  }
+}
+
+// q(f_d) at arbitrary inputs (svmogp_inf.py:212-218): m[n][d] = sum_q W p_q ; v[n][d] = sum_q (B sigma2 + W^2 c_q)
+__global__ void qf_combine_kernel(const double* __restrict__ p, const double* __restrict__ c, long long ldn, long long N,
+                                  int Q, int Df, const double* __restrict__ W, const double* __restrict__ kappa,
+                                  const double* __restrict__ var, double* __restrict__ m, double* __restrict__ v) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  for (int d = 0; d < Df; ++d) {
+    double mm = 0.0, vv = 0.0;
+    for (int q = 0; q < Q; ++q) {
+      const double w = W[q * Df + d];
+      mm += w * p[q * ldn + n];
+      vv += (w * w + kappa[q * Df + d]) * var[q] + w * w * c[q * ldn + n];
+    }
+    m[n * Df + d] = mm;
+    v[n * Df + d] = vv;
+  }
+}
+
+}  // namespace
+
+void launch_add_diag_copy(const double* src, double* dst, int Q, int M, const double* d_jit, hipStream_t s) {
+  hipLaunchKernelGGL(add_diag_copy_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, src, dst, M, d_jit);
+}
+void launch_sub(const double* A, const double* B, double* C, long long n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(sub_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, s, A, B, C, n);
+}
+void launch_kl_terms(const double* Kuui, const double* S, const double* m_u, const double* a, const double* Luu,
+                     const double* L, const double* Sqi, int Q, int M, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(kl_terms_kernel, dim3(Q), dim3(256), 0, s, Kuui, S, m_u, a, Luu, L, Sqi, Q, M, out);
+}
+void launch_dkmm(const double* G, const double* GSK, const double* Kuui, const double* KSK, const double* Kr, const double* a,
+                 double* out, int Q, int M, hipStream_t s) {
+  hipLaunchKernelGGL(dkmm_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, G, GSK, Kuui, KSK, Kr, a, out, M);
+}
+void launch_dlds(const double* G, const double* Kuui, const double* Sqi, double* out, long long n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(dlds_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, s, G, Kuui, Sqi,
+                     out, n);
+}
+void launch_pack_gl(const double* T, double* gL, int Q, int M, hipStream_t s) {
+  hipLaunchKernelGGL(pack_gl_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, T, gL, Q, M);
+}
+void launch_gmu(const double* Kr, const double* a, double* g, int Q, int M, hipStream_t s) {
+  hipLaunchKernelGGL(gmu_kernel, dim3((M + 255) / 256, Q), dim3(256), 0, s, Kr, a, g, Q, M);
+}
+void launch_kzz_rows(const double* dKmm, const double* Z, int ldz, int P, const double* d_var, const double* d_ell, int Q,
+                     int M, double* rowout, hipStream_t s) {
+  dim3 grid((M + 3) / 4, Q);
+  DISPATCH_P(P, hipLaunchKernelGGL((kzz_rows_kernel<PP>), grid, dim3(256), 0, s, dKmm, Z, ldz, d_var, d_ell, M, rowout));
+}
+void launch_qf_combine(const double* p, const double* c, long long ldn, long long N, int Q, int Df, const double* W,
+                       const double* kappa, const double* var, double* m, double* v, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(qf_combine_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, p, c, ldn, N, Q, Df, W, kappa,
+                     var, m, v);
+}

@@ -1,0 +1,53 @@
+// rowpass.h -- launchers of the row-streaming kernels (rowpass.hip).
+#pragma once
+#include "common.h"
+
+#define HMOGP_MAXJ 8  // max latent functions per task (Categorical K <= 9)
+#define HMOGP_MAXQ 8  // max latent GPs
+// scalar statistics one quad block emits: [0] sum ve, [1] #(v<0), [2+2q] sa_q, [3+2q] sl_q, then J x sgv, then Q x J x swk
+#define HMOGP_MAXSCAL (2 + 2 * HMOGP_MAXQ + HMOGP_MAXJ + HMOGP_MAXQ * HMOGP_MAXJ)
+
+struct QuadArgs {
+  int lik = 0;
+  double lik_param = 0.0;
+  int dimf = 1, Q = 1;
+  long long N = 0;                 // rows of this chunk
+  const double* y = nullptr;       // [N]
+  const double* yaux = nullptr;    // [N] gammaln(y+1) (Poisson) or nullptr
+  const double* p = nullptr;       // [Q][ldn]  K^ a
+  const double* c = nullptr;       // [Q][ldn]  rowsum(P~ .* K^)
+  const double* pt = nullptr;      // [Q][ldn]  r2-weighted twins (nullptr when no hyper-gradients are wanted)
+  const double* ct = nullptr;
+  long long ldn = 0;
+  double w[HMOGP_MAXQ][HMOGP_MAXJ];    // live W[q][d(j)]
+  double w0[HMOGP_MAXQ][HMOGP_MAXJ];   // construction-time W (quirk Q3)
+  double kap[HMOGP_MAXQ][HMOGP_MAXJ];  // live kappa
+  double var[HMOGP_MAXQ];              // RBF variances
+  double scale = 1.0;                  // batch_scale[t]
+  double* alpha = nullptr;             // [Q][ldn] outputs: row weights of the backward pass
+  double* beta = nullptr;
+  double* alpha0 = nullptr;
+  double* beta0 = nullptr;
+  double* partials = nullptr;          // [nblocks][nscal]
+  double* out_mu = nullptr;            // optional [N][dimf]: q(f) mean / variance (prediction, parity tests)
+  double* out_v = nullptr;
+};
+
+long long quad_blocks(int lik, long long N);
+void launch_quad(const QuadArgs& a, hipStream_t s);
+void launch_var_exp(int lik, int J, double param, long long N, const double* y, const double* m, const double* v, double* ve,
+                    double* dm, double* dv, hipStream_t s);
+// K[n][m] = var * exp(-r2/2); X rows have stride ldx, Z rows stride ldz (block q of the M x Q*P inducing array)
+void launch_rbf(const double* X, int ldx, long long N, int P, const double* Z, int ldz, int M, double var, double ell,
+                double* K, bool same, hipStream_t s);
+void launch_rowstats(const double* Kh, const double* Pt, const double* a, const double* X, int P, const double* Z, int ldz,
+                     double ell, long long N, int M, double* p, double* c, double* pt, double* ct, bool hyper, hipStream_t s);
+void launch_colstats(const double* Kh, const double* Pt, const double* a, const double* alpha, const double* alpha0,
+                     const double* beta0, const double* X, int P, const double* Z, int ldz, long long N, int M, int rows,
+                     bool want_z, double* partials, hipStream_t s);
+void launch_reduce_rows(const double* partials, long long nrows, int len, const long long* off, double* dst, bool accumulate,
+                        hipStream_t s);
+void launch_reduce_slabs(const double* slabs, int nslabs, long long stride, long long len, double* dst, bool accumulate,
+                         hipStream_t s);
+void launch_mirror_lower(double* A, int Q, int M, long long stride, hipStream_t s);
+void launch_gammaln1p(const double* y, double* out, long long N, hipStream_t s);

@@ -1,0 +1,429 @@
+// rowpass.hip -- the row-streaming kernels of the svmogp_inf path (gfx950): everything that touches N x M data
+// except the two FP64-MFMA contractions (gemm_f64.hip).
+//
+//   rbf_cross_cov   K^[n,m] = s2 exp(-r2/2)          HBM-bound writer (N*M*8 B), util.py:145-164 / GPy RBF.K
+//   rowstats        p = K^ a, c = rowsum(P~ .* K^), and their r2-weighted twins           (reads K^, P~ once)
+//   quad            q(f) mean/variance (svmogp_inf.py:212-218) -> variational expectations (het_likelihood.py:
+//                   101-131) -> row weights alpha/beta for the backward pass + scalar statistics
+//   colstats        r = K^T alpha, dZ numerators = colsum(E^ .* (x - z))                     (reads K^, P~ once)
+//   reducers        deterministic two-level sums (block partials -> bundle), no floating-point atomics
+#include "rowpass.h"
+#include "lik_device.h"
+#include "rbf_device.h"
+
+namespace {
+
+constexpr int RBF_ROWS = 32;  // rows per block; 256 threads x 2 columns = 512 columns per block
+
+template <int P>
+__global__ __launch_bounds__(256) void rbf_kernel(const double* __restrict__ X, int ldx, long long N,
+                                                  const double* __restrict__ Z, int ldz, int M, double var, double ell,
+                                                  double* __restrict__ K, int same) {
+  __shared__ double xs[RBF_ROWS][P + 1];
+  const int t = threadIdx.x;
+  const long long n0 = (long long)blockIdx.x * RBF_ROWS;
+  const int c = blockIdx.y * 512 + 2 * t;
+  for (int e = t; e < RBF_ROWS * P; e += 256) {
+    const int r = e / P, p = e % P;
+    xs[r][p] = (n0 + r < N) ? X[(n0 + r) * ldx + p] : 0.0;
+  }
+  __syncthreads();
+  if (t < RBF_ROWS) {
+    double xv[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) xv[p] = xs[t][p];
+    xs[t][P] = sumsq<P>(xv);
+  }
+  __syncthreads();
+  if (c >= M) return;
+  const bool two = (c + 1) < M;
+  double z0[P], z1[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    z0[p] = Z[(long long)c * ldz + p];
+    z1[p] = two ? Z[(long long)(c + 1) * ldz + p] : 0.0;
+  }
+  const double zs0 = sumsq<P>(z0), zs1 = sumsq<P>(z1);
+  const bool vec = two && ((M & 1) == 0);
+  const int nr = (int)min((long long)RBF_ROWS, N - n0);
+  for (int r = 0; r < nr; ++r) {
+    double xv[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) xv[p] = xs[r][p];
+    const double xsq = xs[r][P];
+    double r20 = rbf_r2<P>(xv, xsq, z0, zs0, ell), r21 = rbf_r2<P>(xv, xsq, z1, zs1, ell);
+    if (same) {  // GPy's X2=None branch forces the diagonal distance to 0 (kern/stationary)
+      if (n0 + r == c) r20 = 0.0;
+      if (n0 + r == c + 1) r21 = 0.0;
+    }
+    const double k0 = var * exp(-0.5 * r20), k1 = var * exp(-0.5 * r21);
+    double* out = K + (n0 + r) * M + c;
+    if (vec)
+      *reinterpret_cast<f64x2*>(out) = f64x2{k0, k1};
+    else {
+      out[0] = k0;
+      if (two) out[1] = k1;
+    }
+  }
+}
+
+// ---- rowstats: one wave per row ---------------------------------------------------------------------------
+template <int P, bool HYPER>
+__global__ __launch_bounds__(256) void rowstats_kernel(const double* __restrict__ Kh, const double* __restrict__ Pt,
+                                                       const double* __restrict__ a, const double* __restrict__ X,
+                                                       const double* __restrict__ Z, int ldz, double ell, long long N,
+                                                       int M, double* __restrict__ p, double* __restrict__ c,
+                                                       double* __restrict__ pt, double* __restrict__ ct) {
+  const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const double* k = Kh + n * M;
+  const double* q = Pt + n * M;
+  double xv[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) xv[i] = X[n * P + i];
+  const double xsq = sumsq<P>(xv);
+  double sp = 0.0, sc = 0.0, spt = 0.0, sct = 0.0;
+  for (int m = lane; m < M; m += 64) {
+    const double kv = k[m], pv = q[m], av = a[m];
+    sp += kv * av;
+    sc += pv * kv;
+    if (HYPER) {
+      double zv[P];
+#pragma unroll
+      for (int i = 0; i < P; ++i) zv[i] = Z[(long long)m * ldz + i];
+      const double r2 = rbf_r2<P>(xv, xsq, zv, sumsq<P>(zv), ell);
+      spt += kv * av * r2;
+      sct += pv * kv * r2;
+    }
+  }
+  sp = wave_sum(sp);
+  sc = wave_sum(sc);
+  if (HYPER) {
+    spt = wave_sum(spt);
+    sct = wave_sum(sct);
+  }
+  if (lane == 0) {
+    p[n] = sp;
+    c[n] = sc;
+    if (HYPER) {
+      pt[n] = spt;
+      ct[n] = sct;
+    }
+  }
+}
+
+// ---- quad -----------------------------------------------------------------------------------------------
+template <int LIK>
+__global__ __launch_bounds__(256) void quad_kernel(QuadArgs a) {
+  constexpr int G = lik_lanes(LIK);
+  __shared__ double etab[4][HMOGP_MAXJ * 10];
+  __shared__ double red[4][HMOGP_MAXSCAL];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const long long n = ((long long)blockIdx.x * 256 + t) / G;
+  const bool valid = n < a.N;                       // uniform per wave when G == 64
+  const bool lead = valid && (G == 1 || lane == 0);  // the lane that owns the row's outputs
+  const int Q = a.Q, J = a.dimf;
+  const int nscal = 2 + 2 * Q + J + Q * J;
+  // contribution of this lane to block scalar `slot` (uniform slot; every lane of the wave calls)
+  auto emit = [&](int slot, double val) {
+    const double s = (G == 1) ? wave_sum(val) : val;
+    if (lane == 0) red[w][slot] = s;
+  };
+
+  double mu[HMOGP_MAXJ], vv[HMOGP_MAXJ], pq[HMOGP_MAXQ], cq[HMOGP_MAXQ];
+#pragma unroll
+  for (int q = 0; q < HMOGP_MAXQ; ++q) {
+    pq[q] = (valid && q < Q) ? a.p[q * a.ldn + n] : 0.0;
+    cq[q] = (valid && q < Q) ? a.c[q * a.ldn + n] : 0.0;
+  }
+  bool neg = false;
+#pragma unroll
+  for (int j = 0; j < HMOGP_MAXJ; ++j) {
+    double m = 0.0, v = 0.0;
+    if (j < J) {
+#pragma unroll
+      for (int q = 0; q < HMOGP_MAXQ; ++q)
+        if (q < Q) {
+          const double wq = a.w[q][j];
+          m += wq * pq[q];
+          v += (wq * wq + a.kap[q][j]) * a.var[q] + wq * wq * cq[q];
+        }
+      neg |= (v < 0.0);
+    }
+    mu[j] = m;
+    vv[j] = v;
+  }
+  LikOut o;
+  o.ve = 0.0;
+#pragma unroll
+  for (int j = 0; j < HMOGP_MAXJ; ++j) o.gm[j] = o.gv[j] = 0.0;
+  if (valid) lik_eval<LIK>(a.y[n], a.yaux ? a.yaux[n] : 0.0, mu, vv, a.lik_param, lane, etab[w], o);
+  if (a.out_mu && lead) {
+    for (int j = 0; j < J; ++j) {
+      a.out_mu[n * J + j] = mu[j];
+      a.out_v[n * J + j] = vv[j];
+    }
+  }
+  const double s = lead ? a.scale : 0.0;  // non-owning lanes contribute zeros
+  o.ve *= s;
+#pragma unroll
+  for (int j = 0; j < HMOGP_MAXJ; ++j) {
+    o.gm[j] *= s;
+    o.gv[j] *= s;
+  }
+  emit(0, o.ve);
+  emit(1, (lead && neg) ? 1.0 : 0.0);
+#pragma unroll
+  for (int q = 0; q < HMOGP_MAXQ; ++q) {
+    if (q < Q) {
+      double al = 0.0, be = 0.0, al0 = 0.0, be0 = 0.0;
+#pragma unroll
+      for (int j = 0; j < HMOGP_MAXJ; ++j)
+        if (j < J) {
+          const double wq = a.w[q][j], w0 = a.w0[q][j];
+          al += wq * o.gm[j];
+          be += wq * wq * o.gv[j];
+          al0 += w0 * o.gm[j];
+          be0 += w0 * wq * o.gv[j];
+          emit(2 + 2 * Q + J + q * J + j, o.gm[j] * pq[q] + 2.0 * wq * (o.gv[j] * cq[q]));  // swk[q][j]
+        }
+      if (lead) {
+        a.alpha[q * a.ldn + n] = al;
+        a.beta[q * a.ldn + n] = be;
+        a.alpha0[q * a.ldn + n] = al0;
+        a.beta0[q * a.ldn + n] = be0;
+      }
+      const double ptq = (lead && a.pt) ? a.pt[q * a.ldn + n] : 0.0;
+      const double ctq = (lead && a.ct) ? a.ct[q * a.ldn + n] : 0.0;
+      emit(2 + 2 * q, al0 * pq[q] + 2.0 * be0 * cq[q]);  // sa_q
+      emit(3 + 2 * q, al0 * ptq + 2.0 * be0 * ctq);      // sl_q
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < HMOGP_MAXJ; ++j)
+    if (j < J) emit(2 + 2 * Q + j, o.gv[j]);  // sgv[j]
+  __syncthreads();
+  if (t < nscal) a.partials[(long long)blockIdx.x * nscal + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+}
+
+// ---- colstats: thread = 2 columns, block = 512 columns x `rows` rows ----------------------------------------
+template <int P>
+__global__ __launch_bounds__(256) void colstats_kernel(const double* __restrict__ Kh, const double* __restrict__ Pt,
+                                                       const double* __restrict__ a, const double* __restrict__ alpha,
+                                                       const double* __restrict__ alpha0, const double* __restrict__ beta0,
+                                                       const double* __restrict__ X, const double* __restrict__ Z, int ldz,
+                                                       long long N, int M, int rows, int want_z,
+                                                       double* __restrict__ partials) {
+  const int t = threadIdx.x, c = blockIdx.x * 512 + 2 * t;
+  if (c >= M) return;
+  const bool two = (c + 1) < M;
+  const bool vec = two && ((M & 1) == 0);
+  const long long n0 = (long long)blockIdx.y * rows, n1 = min(N, n0 + rows);
+  double z0[P], z1[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    z0[p] = Z[(long long)c * ldz + p];
+    z1[p] = two ? Z[(long long)(c + 1) * ldz + p] : 0.0;
+  }
+  const double a0 = a[c], a1 = two ? a[c + 1] : 0.0;
+  double r0 = 0.0, r1 = 0.0, d0[P], d1[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) d0[p] = d1[p] = 0.0;
+  for (long long n = n0; n < n1; ++n) {
+    double k0, k1, q0, q1;
+    if (vec) {
+      const f64x2 kv = *reinterpret_cast<const f64x2*>(Kh + n * M + c);
+      const f64x2 qv = *reinterpret_cast<const f64x2*>(Pt + n * M + c);
+      k0 = kv.x, k1 = kv.y, q0 = qv.x, q1 = qv.y;
+    } else {
+      k0 = Kh[n * M + c];
+      q0 = Pt[n * M + c];
+      k1 = two ? Kh[n * M + c + 1] : 0.0;
+      q1 = two ? Pt[n * M + c + 1] : 0.0;
+    }
+    const double al = alpha[n];
+    r0 += k0 * al;
+    r1 += k1 * al;
+    if (want_z) {
+      const double al0 = alpha0[n], be0 = 2.0 * beta0[n];
+      const double e0 = (al0 * a0 + be0 * q0) * k0, e1 = (al0 * a1 + be0 * q1) * k1;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const double x = X[n * P + p];
+        d0[p] += e0 * (x - z0[p]);
+        d1[p] += e1 * (x - z1[p]);
+      }
+    }
+  }
+  // partial layout per row-split: [ r (M) | dZ (M*P) ]
+  double* out = partials + (long long)blockIdx.y * ((long long)M * (1 + P));
+  out[c] = r0;
+  if (two) out[c + 1] = r1;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    out[M + (long long)c * P + p] = d0[p];
+    if (two) out[M + (long long)(c + 1) * P + p] = d1[p];
+  }
+}
+
+// ---- reducers ---------------------------------------------------------------------------------------------
+// dst[off[k]] += sum_b partials[b*len + k]   (off == nullptr: dst[k])
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const double* __restrict__ partials, long long nrows, int len,
+                                                          const long long* __restrict__ off, double* __restrict__ dst,
+                                                          int accumulate) {
+  __shared__ double scratch[16];
+  const int k = blockIdx.x;
+  double s = 0.0;
+  for (long long b = threadIdx.x; b < nrows; b += blockDim.x) s += partials[b * len + k];
+  s = block_sum(s, scratch);
+  if (threadIdx.x == 0) {
+    double* d = dst + (off ? off[k] : k);
+    *d = accumulate ? (*d + s) : s;
+  }
+}
+// dst[i] (+)= sum_s slabs[s*stride + i], i < len ; coalesced over i
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const double* __restrict__ slabs, int nslabs, long long stride,
+                                                           long long len, double* __restrict__ dst, int accumulate) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= len) return;
+  double s = 0.0;
+  for (int b = 0; b < nslabs; ++b) s += slabs[b * stride + i];
+  dst[i] = accumulate ? dst[i] + s : s;
+}
+// lower tiles of H were computed: mirror to the upper triangle
+__global__ void mirror_lower_kernel(double* __restrict__ A, int M, long long stride) {
+  double* a = A + (long long)blockIdx.z * stride;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c < M && c > r) a[(long long)r * M + c] = a[(long long)c * M + r];
+}
+
+__global__ void gammaln1p_kernel(const double* __restrict__ y, double* __restrict__ out, long long N) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < N) out[i] = lgamma(y[i] + 1.0);
+}
+
+// ---- stand-alone variational expectations (hmogp_var_exp; also the predictive building block) -------------------
+template <int LIK>
+__global__ __launch_bounds__(256) void var_exp_kernel(int J, double param, long long N, const double* __restrict__ y,
+                                                      const double* __restrict__ m, const double* __restrict__ v,
+                                                      double* __restrict__ ve, double* __restrict__ dm,
+                                                      double* __restrict__ dv) {
+  constexpr int G = lik_lanes(LIK);
+  __shared__ double etab[4][HMOGP_MAXJ * 10];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const long long n = ((long long)blockIdx.x * 256 + t) / G;
+  if (n >= N) return;
+  double mu[HMOGP_MAXJ], vv[HMOGP_MAXJ];
+#pragma unroll
+  for (int j = 0; j < HMOGP_MAXJ; ++j) {
+    mu[j] = (j < J) ? m[n * J + j] : 0.0;
+    vv[j] = (j < J) ? v[n * J + j] : 0.0;
+  }
+  LikOut o;
+#pragma unroll
+  for (int j = 0; j < HMOGP_MAXJ; ++j) o.gm[j] = o.gv[j] = 0.0;
+  const double yy = y[n];
+  lik_eval<LIK>(yy, (LIK == HMOGP_LIK_POISSON) ? lgamma(yy + 1.0) : 0.0, mu, vv, param, lane, etab[w], o);
+  if (G == 1 || lane == 0) {
+    ve[n] = o.ve;
+    for (int j = 0; j < J; ++j) {
+      dm[n * J + j] = o.gm[j];
+      dv[n * J + j] = o.gv[j];
+    }
+  }
+}
+
+}  // namespace
+
+// =============================================================================================== launchers
+void launch_rbf(const double* X, int ldx, long long N, int P, const double* Z, int ldz, int M, double var, double ell,
+                double* K, bool same, hipStream_t s) {
+  if (N <= 0 || M <= 0) return;
+  dim3 grid((unsigned)((N + RBF_ROWS - 1) / RBF_ROWS), (M + 511) / 512);
+  DISPATCH_P(P, hipLaunchKernelGGL((rbf_kernel<PP>), grid, dim3(256), 0, s, X, ldx, N, Z, ldz, M, var, ell, K, same ? 1 : 0));
+}
+
+void launch_rowstats(const double* Kh, const double* Pt, const double* a, const double* X, int P, const double* Z, int ldz,
+                     double ell, long long N, int M, double* p, double* c, double* pt, double* ct, bool hyper,
+                     hipStream_t s) {
+  if (N <= 0) return;
+  dim3 grid((unsigned)((N + 3) / 4));
+  if (hyper) {
+    DISPATCH_P(P, hipLaunchKernelGGL((rowstats_kernel<PP, true>), grid, dim3(256), 0, s, Kh, Pt, a, X, Z, ldz, ell, N, M, p,
+                                     c, pt, ct));
+  } else {
+    DISPATCH_P(P, hipLaunchKernelGGL((rowstats_kernel<PP, false>), grid, dim3(256), 0, s, Kh, Pt, a, X, Z, ldz, ell, N, M,
+                                     p, c, pt, ct));
+  }
+}
+
+long long quad_blocks(int lik, long long N) { return (N * lik_lanes(lik) + 255) / 256; }
+
+void launch_quad(const QuadArgs& a, hipStream_t s) {
+  if (a.N <= 0) return;
+  dim3 grid((unsigned)quad_blocks(a.lik, a.N));
+#define QK(L) hipLaunchKernelGGL((quad_kernel<L>), grid, dim3(256), 0, s, a)
+  switch (a.lik) {
+    case HMOGP_LIK_GAUSSIAN: QK(HMOGP_LIK_GAUSSIAN); break;
+    case HMOGP_LIK_BERNOULLI: QK(HMOGP_LIK_BERNOULLI); break;
+    case HMOGP_LIK_HETGAUSSIAN: QK(HMOGP_LIK_HETGAUSSIAN); break;
+    case HMOGP_LIK_CATEGORICAL: QK(HMOGP_LIK_CATEGORICAL); break;
+    case HMOGP_LIK_POISSON: QK(HMOGP_LIK_POISSON); break;
+    case HMOGP_LIK_EXPONENTIAL: QK(HMOGP_LIK_EXPONENTIAL); break;
+    case HMOGP_LIK_GAMMA: QK(HMOGP_LIK_GAMMA); break;
+    case HMOGP_LIK_BETA: QK(HMOGP_LIK_BETA); break;
+    default: throw HipError{hipErrorInvalidValue, "unknown likelihood id", __FILE__, __LINE__};
+  }
+#undef QK
+}
+
+void launch_var_exp(int lik, int J, double param, long long N, const double* y, const double* m, const double* v, double* ve,
+                    double* dm, double* dv, hipStream_t s) {
+  if (N <= 0) return;
+  dim3 grid((unsigned)quad_blocks(lik, N));
+#define VK(L) hipLaunchKernelGGL((var_exp_kernel<L>), grid, dim3(256), 0, s, J, param, N, y, m, v, ve, dm, dv)
+  switch (lik) {
+    case HMOGP_LIK_GAUSSIAN: VK(HMOGP_LIK_GAUSSIAN); break;
+    case HMOGP_LIK_BERNOULLI: VK(HMOGP_LIK_BERNOULLI); break;
+    case HMOGP_LIK_HETGAUSSIAN: VK(HMOGP_LIK_HETGAUSSIAN); break;
+    case HMOGP_LIK_CATEGORICAL: VK(HMOGP_LIK_CATEGORICAL); break;
+    case HMOGP_LIK_POISSON: VK(HMOGP_LIK_POISSON); break;
+    case HMOGP_LIK_EXPONENTIAL: VK(HMOGP_LIK_EXPONENTIAL); break;
+    case HMOGP_LIK_GAMMA: VK(HMOGP_LIK_GAMMA); break;
+    case HMOGP_LIK_BETA: VK(HMOGP_LIK_BETA); break;
+    default: throw HipError{hipErrorInvalidValue, "unknown likelihood id", __FILE__, __LINE__};
+  }
+#undef VK
+}
+
+void launch_colstats(const double* Kh, const double* Pt, const double* a, const double* alpha, const double* alpha0,
+                     const double* beta0, const double* X, int P, const double* Z, int ldz, long long N, int M, int rows,
+                     bool want_z, double* partials, hipStream_t s) {
+  if (N <= 0) return;
+  dim3 grid((M + 511) / 512, (unsigned)((N + rows - 1) / rows));
+  DISPATCH_P(P, hipLaunchKernelGGL((colstats_kernel<PP>), grid, dim3(256), 0, s, Kh, Pt, a, alpha, alpha0, beta0, X, Z, ldz,
+                                   N, M, rows, want_z ? 1 : 0, partials));
+}
+
+void launch_reduce_rows(const double* partials, long long nrows, int len, const long long* off, double* dst, bool accumulate,
+                        hipStream_t s) {
+  if (len <= 0) return;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(len), dim3(256), 0, s, partials, nrows, len, off, dst, accumulate ? 1 : 0);
+}
+
+void launch_reduce_slabs(const double* slabs, int nslabs, long long stride, long long len, double* dst, bool accumulate,
+                         hipStream_t s) {
+  if (len <= 0) return;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, slabs, nslabs, stride, len,
+                     dst, accumulate ? 1 : 0);
+}
+
+void launch_mirror_lower(double* A, int Q, int M, long long stride, hipStream_t s) {
+  hipLaunchKernelGGL(mirror_lower_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, A, M, stride);
+}
+
+void launch_gammaln1p(const double* y, double* out, long long N, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(gammaln1p_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, y, out, N);
+}

@@ -1,0 +1,248 @@
+"""NumPy-level wrapper of the C ABI (one object = one ``hmogp_handle``): the inner layer of the facade.
+
+Mirrors what ``SVMOGP.parameters_changed`` needs from ``SVMOGPInf.inference`` + the gradient assembly
+(reference: hetmogp/svmogp.py:85-166, hetmogp/svmogp_inf.py:23-250): parameters in, ELBO and parameter
+gradients out.  All arithmetic happens in ``libhetmogp_hip.so``; this file only marshals arrays.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check
+
+LIK_IDS = dict(Gaussian=_lib.LIK_GAUSSIAN, Bernoulli=_lib.LIK_BERNOULLI, HetGaussian=_lib.LIK_HETGAUSSIAN,
+               Categorical=_lib.LIK_CATEGORICAL, Poisson=_lib.LIK_POISSON, Exponential=_lib.LIK_EXPONENTIAL,
+               Gamma=_lib.LIK_GAMMA, Beta=_lib.LIK_BETA)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(_lib.c_double_p)
+
+
+def lik_dim_f(name, **kw):
+    """Number of latent parameter functions (the reference's ``get_metadata()[1]``)."""
+    if name == "Categorical":
+        return int(kw["K"]) - 1
+    return dict(Gaussian=1, Bernoulli=1, HetGaussian=2, Poisson=1, Exponential=1, Gamma=2, Beta=2)[name]
+
+
+def lik_param(name, **kw):
+    if name == "Gaussian":
+        s = kw.get("sigma")
+        return 0.5 if s is None else float(s)          # gaussian.py:21-24
+    if name == "Categorical":
+        return float(kw["K"])
+    return 0.0
+
+
+class Engine(object):
+    """specs: list of (likelihood class name, kwargs) per task, e.g. [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {})]."""
+
+    def __init__(self, specs, Q, M, P, device=0, chunk_rows=0):
+        self.specs = [(n, dict(k)) for n, k in specs]
+        self.T, self.Q, self.M, self.P = len(specs), int(Q), int(M), int(P)
+        f_index, d_index = [], []
+        for t, (name, kw) in enumerate(self.specs):
+            df = lik_dim_f(name, **kw)
+            f_index += [t] * df
+            d_index += list(range(df))
+        self.f_index = np.array(f_index, dtype=np.int32)
+        self.d_index = np.array(d_index, dtype=np.int32)
+        self.Df = len(f_index)
+        self.Mtri = self.M * (self.M + 1) // 2
+        lik_id = np.array([LIK_IDS[n] for n, _ in self.specs], dtype=np.int32)
+        lik_par = np.array([lik_param(n, **k) for n, k in self.specs], dtype=np.float64)
+        cfg = _lib.Config(_lib.ABI_VERSION, self.T, self.Q, self.M, self.P, self.Df,
+                          lik_id.ctypes.data_as(_lib.c_int32_p), _p(lik_par),
+                          self.f_index.ctypes.data_as(_lib.c_int32_p), self.d_index.ctypes.data_as(_lib.c_int32_p),
+                          int(device), int(chunk_rows))
+        self._h = C.c_void_p()
+        check(lib.hmogp_create(C.byref(cfg), C.byref(self._h)), None)
+        self.N = [0] * self.T
+        self.last = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib.hmogp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------ data
+    def set_task_data(self, t, X, Y):
+        X, Y = _f64(X).reshape(-1, self.P), _f64(Y).reshape(-1)
+        if X.shape[0] != Y.shape[0]:
+            raise ValueError("X and Y of task %d have different lengths" % t)
+        check(lib.hmogp_set_task_data(self._h, t, _p(X), _p(Y), X.shape[0]), self._h)
+        self.N[t] = X.shape[0]
+
+    def set_data(self, X_list, Y_list):
+        for t, (X, Y) in enumerate(zip(X_list, Y_list)):
+            self.set_task_data(t, X, Y)
+
+    # ------------------------------------------------------------------------------------------ params
+    def _params(self, Z, m_u, L_flat, variance, lengthscale, W, kappa, W0=None, kappa0=None, batch_scale=None,
+                row_begin=None, row_end=None, forced_rung=None, group_mask=_lib.GROUP_ALL):
+        keep = []
+
+        def arr(a, shape, dtype=np.float64):
+            if a is None:
+                return None
+            b = np.ascontiguousarray(a, dtype=dtype).reshape(shape)
+            keep.append(b)
+            return b
+
+        Q, M, P, Df, T = self.Q, self.M, self.P, self.Df, self.T
+        a = dict(Z=arr(Z, (M, Q * P)), m_u=arr(m_u, (M, Q)), L_flat=arr(L_flat, (self.Mtri, Q)),
+                 variance=arr(variance, (Q,)), lengthscale=arr(lengthscale, (Q,)), W=arr(W, (Q, Df)),
+                 kappa=arr(kappa, (Q, Df)), W0=arr(W0, (Q, Df)), kappa0=arr(kappa0, (Q, Df)),
+                 batch_scale=arr(batch_scale, (T,)))
+        rbg, ren = arr(row_begin, (T,), np.int64), arr(row_end, (T,), np.int64)
+        fr = arr(forced_rung, (Q,), np.int32)
+        p = _lib.Params()
+        for k, v in a.items():
+            setattr(p, k, _p(v) if v is not None else None)
+        p.row_begin = rbg.ctypes.data_as(_lib.c_int64_p) if rbg is not None else None
+        p.row_end = ren.ctypes.data_as(_lib.c_int64_p) if ren is not None else None
+        p.forced_rung = fr.ctypes.data_as(_lib.c_int32_p) if fr is not None else None
+        p.group_mask = int(group_mask)
+        return p, keep
+
+    def _outputs(self, want_dL_dS=False):
+        Q, M, P, Df = self.Q, self.M, self.P, self.Df
+        o = dict(elbo=np.zeros(1), g_m_u=np.zeros((M, Q)), g_L_u=np.zeros((self.Mtri, Q)), g_variance=np.zeros(Q),
+                 g_lengthscale=np.zeros(Q), g_W=np.zeros((Q, Df)), g_kappa=np.zeros((Q, Df)), g_Z=np.zeros((M, Q * P)))
+        if want_dL_dS:
+            o["dL_dS"] = np.zeros((Q, M, M))
+        rung = np.zeros(Q, dtype=np.int32)
+        flags = np.zeros(1, dtype=np.uint32)
+        c = _lib.Outputs()
+        for k, v in o.items():
+            setattr(c, k, _p(v))
+        if not want_dL_dS:
+            c.dL_dS = None
+        c.rung = rung.ctypes.data_as(_lib.c_int32_p)
+        c.flags = flags.ctypes.data_as(_lib.c_uint32_p)
+        o["rung"], o["flags"] = rung, flags
+        return c, o
+
+    def _wrap(self, o):
+        res = dict(o)
+        res["elbo"] = float(o["elbo"][0])
+        res["rungs"] = [int(r) for r in o["rung"]]
+        res["v_negative"] = bool(int(o["flags"][0]) & _lib.FLAG_V_NEGATIVE)
+        self.last = res
+        return res
+
+    # ------------------------------------------------------------------------------------------ hot path
+    def elbo_grad(self, want_dL_dS=False, **params):
+        """One ``parameters_changed()``: returns dict(elbo, g_m_u, g_L_u, g_variance, g_lengthscale, g_W, g_kappa,
+        g_Z, rungs, v_negative[, dL_dS])."""
+        p, keep = self._params(**params)
+        c, o = self._outputs(want_dL_dS)
+        check(lib.hmogp_elbo_grad(self._h, C.byref(p), C.byref(c)), self._h)
+        return self._wrap(o)
+
+    def step_begin(self, **params):
+        p, keep = self._params(**params)
+        check(lib.hmogp_step_begin(self._h, C.byref(p)), self._h)
+
+    def stats_buffer(self):
+        """(device pointer, float64 count) of the additive statistic bundle -- what a multi-GPU run all-reduces."""
+        ptr, n = C.c_void_p(), C.c_int64()
+        check(lib.hmogp_stats_buffer(self._h, C.byref(ptr), C.byref(n)), self._h)
+        return ptr.value, n.value
+
+    def stats_read(self):
+        _, n = self.stats_buffer()
+        out = np.zeros(n)
+        check(lib.hmogp_stats_read(self._h, _p(out)), self._h)
+        return out
+
+    def stats_write(self, host):
+        host = _f64(host)
+        check(lib.hmogp_stats_write(self._h, _p(host)), self._h)
+
+    def step_finish(self, want_dL_dS=False):
+        c, o = self._outputs(want_dL_dS)
+        check(lib.hmogp_step_finish(self._h, C.byref(c)), self._h)
+        return self._wrap(o)
+
+    # ------------------------------------------------------------------------------------------ consumers
+    def posterior_u(self):
+        wv = np.zeros((self.Q, self.M))
+        wi = np.zeros((self.Q, self.M, self.M))
+        check(lib.hmogp_posterior_u(self._h, _p(wv), _p(wi)), self._h)
+        return wv, wi
+
+    def predict_f(self, Xnew):
+        Xnew = _f64(Xnew).reshape(-1, self.P)
+        m = np.zeros((Xnew.shape[0], self.Df))
+        v = np.zeros((Xnew.shape[0], self.Df))
+        check(lib.hmogp_predict_f(self._h, _p(Xnew), Xnew.shape[0], _p(m), _p(v)), self._h)
+        return m, v
+
+    def timings(self):
+        ms = np.zeros(8)
+        n = np.zeros(8, dtype=np.int64)
+        check(lib.hmogp_last_timings(self._h, _p(ms), n.ctypes.data_as(_lib.c_int64_p)), self._h)
+        names = ["total", "rbf_cross_cov", "forward_gemm", "rowstats", "quadrature", "gram_gemm", "colstats", "mxm_algebra"]
+        return dict(zip(names, ms.tolist())), dict(zip(names, n.tolist()))
+
+
+# ---------------------------------------------------------------------------------------------- building blocks
+def rbf_cross_cov(X, Z, variance, lengthscale, device=0):
+    X, Z = _f64(X), _f64(Z)
+    X = X.reshape(X.shape[0], -1)
+    Z = Z.reshape(Z.shape[0], -1)
+    K = np.zeros((X.shape[0], Z.shape[0]))
+    check(lib.hmogp_rbf_cross_cov(device, _p(X), X.shape[0], _p(Z), Z.shape[0], X.shape[1], float(variance),
+                                  float(lengthscale), _p(K)))
+    return K
+
+
+def jitchol_inv(A, forced_rung=None, device=0):
+    A = _f64(A)
+    Q, M = A.shape[0], A.shape[1]
+    L, Ai = np.zeros_like(A), np.zeros_like(A)
+    rung = np.zeros(Q, dtype=np.int32)
+    fr = None if forced_rung is None else np.ascontiguousarray(forced_rung, dtype=np.int32)
+    check(lib.hmogp_jitchol_inv(device, _p(A), Q, M, fr.ctypes.data_as(_lib.c_int32_p) if fr is not None else None,
+                                _p(L), _p(Ai), rung.ctypes.data_as(_lib.c_int32_p)))
+    return L, Ai, [int(r) for r in rung]
+
+
+def potri(L, device=0):
+    L = _f64(L)
+    out = np.zeros_like(L)
+    check(lib.hmogp_potri(device, _p(L), L.shape[0], L.shape[1], _p(out)))
+    return out
+
+
+def gemm(A, B, transA=False, transB=False, alpha=1.0, beta=0.0, C0=None, device=0):
+    A, B = _f64(A), _f64(B)
+    M, K = (A.shape[1], A.shape[0]) if transA else A.shape
+    N = B.shape[0] if transB else B.shape[1]
+    Cm = np.zeros((M, N)) if C0 is None else _f64(C0).copy()
+    check(lib.hmogp_gemm_f64(device, int(transA), int(transB), M, N, K, float(alpha), _p(A), A.shape[1], _p(B), B.shape[1],
+                             float(beta), _p(Cm), N))
+    return Cm
+
+
+def var_exp(name, y, m, v, device=0, **kw):
+    y, m, v = _f64(y).reshape(-1), _f64(m), _f64(v)
+    J = lik_dim_f(name, **kw)
+    m, v = m.reshape(-1, J), v.reshape(-1, J)
+    ve, dm, dv = np.zeros(y.shape[0]), np.zeros_like(m), np.zeros_like(v)
+    check(lib.hmogp_var_exp(device, LIK_IDS[name], lik_param(name, **kw), y.shape[0], _p(y), _p(m), _p(v), _p(ve), _p(dm),
+                            _p(dv)))
+    return ve, dm, dv

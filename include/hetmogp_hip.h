@@ -1,0 +1,184 @@
+/*
+ * hetmogp_hip.h -- C ABI of the MI355X-native SVI engine for heterogeneous multi-output GPs.
+ *
+ * Drop-in boundary for ONE hot path of pmorenoz/HetMOGP: the ELBO-and-gradient evaluation that the
+ * reference performs in SVMOGP.parameters_changed()  (hetmogp/svmogp.py:85-166), i.e.
+ *   SVMOGPInf.inference()            hetmogp/svmogp_inf.py:23-109
+ *     util.latent_funs_cov           hetmogp/util.py:181-200      (K_uu, jitchol, K_uu^-1)
+ *     SVMOGPInf.calculate_q_f        hetmogp/svmogp_inf.py:186-225 (q(f_d) mean / variance)
+ *     HetLikelihood.var_exp(_derivatives)  hetmogp/het_likelihood.py:101-131 -> likelihoods/<name>.py
+ *     SVMOGPInf.calculate_KL         hetmogp/svmogp_inf.py:227-250
+ *     SVMOGPInf.calculate_gradients  hetmogp/svmogp_inf.py:111-183
+ *   + the parameter-gradient assembly hetmogp/svmogp.py:101-166, util.py:228-231,248-255.
+ *
+ * The reference has no FFI (it is pure Python over GPy); the binding a maintainer would add is the
+ * ctypes stub shown in INTEGRATION.md.  Why the boundary sits at the OUTER level (parameters in,
+ * parameter gradients out) and not at SVMOGPInf.inference(): the inner protocol returns dL_dKmn as
+ * Q*Df dense M x N matrices (24.6 GB at N=200k, M=1024) for Python to reduce.
+ *
+ * Conventions: every array is C-contiguous float64 (int32 / int64 where stated) in HOST memory owned by
+ * the caller; the engine copies in / out and keeps data and workspaces resident in HBM between calls.
+ * One handle = one host thread = one HIP device.  Every function returns 0 on success or a negative
+ * HMOGP_E_* code; hmogp_last_error() gives the message.  The library has no CPU fallback: without a
+ * HIP device hmogp_create fails with HMOGP_E_NO_DEVICE.
+ */
+#ifndef HETMOGP_HIP_H
+#define HETMOGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMOGP_ABI_VERSION 1
+
+/* likelihood ids (class names of /root/reference/likelihoods/<name>.py) */
+enum {
+  HMOGP_LIK_GAUSSIAN = 0,    /* gaussian.py     param = sigma (default 0.5)          dim_f = 1   */
+  HMOGP_LIK_BERNOULLI = 1,   /* bernoulli.py                                          dim_f = 1   */
+  HMOGP_LIK_HETGAUSSIAN = 2, /* hetgaussian.py                                        dim_f = 2   */
+  HMOGP_LIK_CATEGORICAL = 3, /* categorical.py  param = K (labels 1..K)               dim_f = K-1 */
+  HMOGP_LIK_POISSON = 4,     /* poisson.py                                            dim_f = 1   */
+  HMOGP_LIK_EXPONENTIAL = 5, /* exponential.py                                        dim_f = 1   */
+  HMOGP_LIK_GAMMA = 6,       /* gamma.py                                              dim_f = 2   */
+  HMOGP_LIK_BETA = 7         /* beta.py                                               dim_f = 2   */
+};
+
+/* error codes; the Python facade maps them onto the reference's exception types */
+enum {
+  HMOGP_OK = 0,
+  HMOGP_E_INVALID = -1,     /* bad argument                                                        */
+  HMOGP_E_NO_DEVICE = -2,   /* no HIP device / HIP runtime error                                    */
+  HMOGP_E_NOT_PD = -3,      /* LinAlgError("not positive definite, even with jitter.") / non-positive
+                               diagonal -- GPy jitchol, reached from util.py:198                    */
+  HMOGP_E_SQI_UNSTABLE = -4,/* ValueError("Sqi: Cholesky representation unstable") svmogp_inf.py:126 */
+  HMOGP_E_STATE = -5        /* call order violated (finish without begin, data not set, ...)        */
+};
+
+/* output flags (hmogp_outputs.flags) */
+#define HMOGP_FLAG_V_NEGATIVE 1u /* some v_fd < 0: the reference prints 'v negative!' (svmogp_inf.py:221) */
+
+/* gradient-group mask (hmogp_params.group_mask): which parameter groups receive a gradient.  Mirrors the
+ * VEM gating of svmogp.py:104-110,131-137,145-151,160-166 and Z.is_fixed (:153,158).                    */
+#define HMOGP_GROUP_QU 1u     /* m_u, L_u            (zeroed in stochastic M-steps)                 */
+#define HMOGP_GROUP_HYPER 2u  /* variance, lengthscale, W, kappa (zeroed in stochastic E-steps)      */
+#define HMOGP_GROUP_Z 4u      /* inducing inputs     (zeroed in stochastic E-steps or when fixed)    */
+#define HMOGP_GROUP_ALL 7u
+
+typedef struct hmogp_engine* hmogp_handle;
+
+/* Static description of the model: SVMOGP.__init__ (svmogp.py:17-79) + HetLikelihood.generate_metadata
+ * (het_likelihood.py:24-44).                                                                          */
+typedef struct {
+  int32_t abi_version;      /* HMOGP_ABI_VERSION                                                     */
+  int32_t T;                /* number of likelihoods / tasks  = len(Y)                               */
+  int32_t Q;                /* number of latent GPs u_q       = len(kern_list)                       */
+  int32_t M;                /* inducing points per latent GP  = Z.shape[0]                           */
+  int32_t P;                /* input dimension (Xdim)                                                */
+  int32_t Df;               /* number of latent parameter functions f_d = sum_t dim_f(t)             */
+  const int32_t* lik_id;    /* [T]  HMOGP_LIK_*                                                      */
+  const double* lik_param;  /* [T]  sigma (Gaussian) | K (Categorical) | ignored                     */
+  const int32_t* f_index;   /* [Df] task owning function d      (Y_metadata['function_index'])        */
+  const int32_t* d_index;   /* [Df] column of d inside its task (Y_metadata['d_index'])               */
+  int32_t device;           /* HIP device ordinal                                                    */
+  int64_t chunk_rows;       /* rows of one task processed per pass (0 = default 131072); bounds the
+                               N x M workspaces: 2 * Q * chunk_rows * M * 8 bytes                    */
+} hmogp_config;
+
+/* All model parameters of one evaluation: the arrays paramz hands to parameters_changed().             */
+typedef struct {
+  const double* Z;            /* [M, Q*P]  block q = inducing inputs of u_q (svmogp.py:52)            */
+  const double* m_u;          /* [M, Q]    q_u_means                                                  */
+  const double* L_flat;       /* [M(M+1)/2, Q] q_u_chols, GPy row-major tril packing                  */
+  const double* variance;     /* [Q]  RBF variance of k_q                                             */
+  const double* lengthscale;  /* [Q]  RBF lengthscale of k_q                                          */
+  const double* W;            /* [Q, Df] live coregionalisation weights  B_list[q].W                  */
+  const double* kappa;        /* [Q, Df] live kappa                      B_list[q].kappa              */
+  const double* W0;           /* [Q, Df] or NULL (= W): construction-time W_list used for the chain
+                                 factors at svmogp.py:98,141,143,156             */
+  const double* kappa0;       /* [Q, Df] or NULL (= kappa)                                            */
+  const double* batch_scale;  /* [T] or NULL (= 1): N_all[t] / N_batch[t]  (svmogp.py:89-90)          */
+  const int64_t* row_begin;   /* [T] or NULL (= 0):   first row of task t used in this evaluation     */
+  const int64_t* row_end;     /* [T] or NULL (= N_t): one past the last row (contiguous minibatch
+                                 slices of util.py:52-72; also the row shard of this rank)            */
+  const int32_t* forced_rung; /* [Q] or NULL: -2 = run GPy's jitter ladder, -1 = no jitter,
+                                 k>=0 = jitter mean(diag)*1e-6*10^k (compare CPU/GPU at equal rung)   */
+  uint32_t group_mask;        /* HMOGP_GROUP_*                                                        */
+} hmogp_params;
+
+typedef struct {
+  double* elbo;          /* [1]   log_marginal (svmogp_inf.py:88)                                     */
+  double* g_m_u;         /* [M, Q]                                                                    */
+  double* g_L_u;         /* [M(M+1)/2, Q]                                                             */
+  double* g_variance;    /* [Q]                                                                       */
+  double* g_lengthscale; /* [Q]                                                                       */
+  double* g_W;           /* [Q, Df]                                                                   */
+  double* g_kappa;       /* [Q, Df]                                                                   */
+  double* g_Z;           /* [M, Q*P]                                                                  */
+  double* dL_dS;         /* [Q, M, M] or NULL: dL/dS_q (svmogp_inf.py:169), for natural gradients     */
+  int32_t* rung;         /* [Q] jitter rung taken per latent (-1 = none)                              */
+  uint32_t* flags;       /* [1] HMOGP_FLAG_*                                                          */
+} hmogp_outputs;
+
+/* ---- life cycle ------------------------------------------------------------------------------------ */
+int hmogp_create(const hmogp_config* cfg, hmogp_handle* out);
+void hmogp_destroy(hmogp_handle h);
+const char* hmogp_last_error(hmogp_handle h); /* h may be NULL: error of the last failed hmogp_create    */
+int hmogp_abi_version(void);
+
+/* Upload (replace) the full data of task t: X [N, P], Y [N] (Xmulti_all[t], Ymulti_all[t]).            */
+int hmogp_set_task_data(hmogp_handle h, int32_t t, const double* X, const double* Y, int64_t N);
+
+/* ---- the hot path ----------------------------------------------------------------------------------- */
+/* One full evaluation = parameters_changed(): ELBO + all parameter gradients (single device).           */
+int hmogp_elbo_grad(hmogp_handle h, const hmogp_params* p, hmogp_outputs* out);
+
+/* The same, split at the one exchange point of the path for row-sharded multi-GPU runs:
+ *   begin  : upload parameters, replicated M x M pre-algebra, row pass over [row_begin,row_end) of every
+ *            task -> additive statistic bundle left in device memory (synchronous at return);
+ *   (caller sum-all-reduces the bundle in place across ranks, e.g. torch.distributed over RCCL)
+ *   finish : replicated M x M post-processing of the bundle -> outputs.                                 */
+int hmogp_step_begin(hmogp_handle h, const hmogp_params* p);
+int hmogp_stats_buffer(hmogp_handle h, void** device_ptr, int64_t* count); /* float64 words            */
+int hmogp_step_finish(hmogp_handle h, hmogp_outputs* out);
+/* Host-staged access to the bundle (tests; all-reduce over a CPU backend when RCCL is not used).        */
+int hmogp_stats_read(hmogp_handle h, double* host /* [count] */);
+int hmogp_stats_write(hmogp_handle h, const double* host /* [count] */);
+
+/* ---- posterior / prediction (consumers: svmogp.py:238-251, 280-306) --------------------------------- */
+/* woodbury_vector[q] = Kuu^-1 m_q  [Q, M];  woodbury_inv[q] = Kuu^-1 - Kuu^-1 S_q Kuu^-1  [Q, M, M]
+ * of the parameters of the last evaluation.                                                             */
+int hmogp_posterior_u(hmogp_handle h, double* woodbury_vector, double* woodbury_inv);
+/* q(f_d) at new inputs for all functions: m [Nnew, Df], v [Nnew, Df] (= predictive_new's (mu, |var|)
+ * before the abs; svmogp_inf.py:186-225 with X := Xnew), using the parameters of the last evaluation.   */
+int hmogp_predict_f(hmogp_handle h, const double* Xnew, int64_t Nnew, double* m, double* v);
+
+/* ---- timing --------------------------------------------------------------------------------------- */
+/* Milliseconds the kernels of the last evaluation spent, measured with HIP events on the engine's stream:
+ * out[0] whole evaluation, [1] K_uf construction (rbf_cross_cov), [2] forward N x M x M products,
+ * [3] row statistics, [4] quadrature, [5] weighted Gram (backward), [6] column statistics,
+ * [7] replicated M x M algebra.  launches[i] = number of kernel launches behind out[i] (i = 1..7).       */
+int hmogp_last_timings(hmogp_handle h, double* out_ms8, int64_t* launches8);
+
+/* ---- building blocks, exposed for parity tests ("inner protocol" at small sizes) ---------------------- */
+/* K = variance * exp(-0.5 * |x - z|^2 / lengthscale^2), GPy RBF.K(X, Z) semantics (util.py:161,197).      */
+int hmogp_rbf_cross_cov(int32_t device, const double* X, int64_t N, const double* Z, int32_t M, int32_t P,
+                        double variance, double lengthscale, double* K /* [N, M] */);
+/* Batched lower Cholesky with GPy's jitter ladder + inverse: A [Q,M,M] -> L, Ainv; rung[q] as above.     */
+int hmogp_jitchol_inv(int32_t device, const double* A, int32_t Q, int32_t M, const int32_t* forced_rung,
+                      double* L, double* Ainv, int32_t* rung);
+/* (L L^T)^-1 from lower factors (GPy dpotri): L [Q,M,M] -> Sinv [Q,M,M].                                 */
+int hmogp_potri(int32_t device, const double* L, int32_t Q, int32_t M, double* Sinv);
+/* C = alpha * op(A) op(B) + beta * C on the FP64-MFMA GEMM; transA/transB in {0,1}; row-major.           */
+int hmogp_gemm_f64(int32_t device, int32_t transA, int32_t transB, int32_t M, int32_t N, int32_t K,
+                   double alpha, const double* A, int32_t lda, const double* B, int32_t ldb, double beta,
+                   double* C, int32_t ldc);
+/* Variational expectations of one likelihood: y [N], m,v [N, dim_f] -> ve [N], dm, dv [N, dim_f].         */
+int hmogp_var_exp(int32_t device, int32_t lik_id, double lik_param, int64_t N, const double* y,
+                  const double* m, const double* v, double* ve, double* dm, double* dv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HETMOGP_HIP_H */

@@ -288,12 +288,14 @@ def assemble_literal(prm, prob, X, grads, stochastic=False, vem_step=True, z_fix
 
 # ================================================================= baseline B: fused algebra
 def stats_layout(prob):
-    """Offsets (in float64 words) of the additive statistic bundle, per latent q after one global slot.
-    [0] = sum of scaled VE;  per q: H (M*M) | r (M) | dZ (M*P) | sa (1) | sl (1) | sgv (Df) | swk (Df)."""
+    """Offsets (float64 words) of the additive statistic bundle (same layout as the HIP engine):
+    global  [0] sum of scaled VE | [1] number of rows with v<0 | [2, 2+Df) sgv[d] = sum_n gv_nd
+    per q   H (M*M) | r (M) | dZ (M*P) | sa | sl | swk (Df)          starting at  NG + q*per_q."""
     Q, M, P, Df = prob["Q"], prob["M"], prob["P"], prob["Df"]
-    per_q = M * M + M + M * P + 2 + 2 * Df
-    return dict(per_q=per_q, size=1 + Q * per_q, H=0, r=M * M, dZ=M * M + M, sa=M * M + M + M * P,
-                sl=M * M + M + M * P + 1, sgv=M * M + M + M * P + 2, swk=M * M + M + M * P + 2 + Df)
+    per_q = M * M + M + M * P + 2 + Df
+    NG = 2 + Df
+    return dict(NG=NG, per_q=per_q, size=NG + Q * per_q, H=0, r=M * M, dZ=M * M + M, sa=M * M + M + M * P,
+                sl=M * M + M + M * P + 1, swk=M * M + M + M * P + 2, sgv=2)
 
 
 def u_algebra(prm, prob, forced_rungs=None):
@@ -346,8 +348,11 @@ def local_stats(prm, prob, u, X, Y, batch_scale=None):
         ve, gm, gv = lo.var_exp_all(name, Y[t], mu, vv, **kw)
         ve, gm, gv = ve * batch_scale[t], gm * batch_scale[t], gv * batch_scale[t]
         stats[0] += ve.sum()
+        stats[1] += float((vv < 0).sum())
+        for j, d in enumerate(ds):
+            stats[lay["sgv"] + d] += gv[:, j].sum()
         for q in range(Q):
-            o = 1 + q * lay["per_q"]
+            o = lay["NG"] + q * lay["per_q"]
             w = prm["W"][q, ds]
             alpha, beta = gm @ w, gv @ (w * w)
             alpha0, beta0 = gm @ W0[q, ds], gv @ (W0[q, ds] * w)
@@ -362,7 +367,6 @@ def local_stats(prm, prob, u, X, Y, batch_scale=None):
             stats[o + lay["sa"]] += alpha0 @ p[q] + 2.0 * beta0 @ c[q]
             stats[o + lay["sl"]] += alpha0 @ pt[q] + 2.0 * beta0 @ ct[q]
             for j, d in enumerate(ds):
-                stats[o + lay["sgv"] + d] += gv[:, j].sum()
                 stats[o + lay["swk"] + d] += gm[:, j] @ p[q] + 2.0 * prm["W"][q, d] * (gv[:, j] @ c[q])
     return stats, v_neg
 
@@ -379,13 +383,13 @@ def finish(prm, prob, u, stats, stochastic=False, vem_step=True, z_fixed=False):
                g_lengthscale=np.zeros(Q), g_W=np.zeros((Q, Df)), g_kappa=np.zeros((Q, Df)),
                g_Z=np.zeros((M, Q * P)), dL_dS=[])
     KL = 0.0
+    sgv = stats[lay["sgv"]:lay["sgv"] + Df]
     for q in range(Q):
-        o = 1 + q * lay["per_q"]
+        o = lay["NG"] + q * lay["per_q"]
         H = stats[o:o + M * M].reshape(M, M)
         r = stats[o + lay["r"]:o + lay["r"] + M]
         dZs = stats[o + lay["dZ"]:o + lay["dZ"] + M * P].reshape(M, P)
         sa, sl = stats[o + lay["sa"]], stats[o + lay["sl"]]
-        sgv = stats[o + lay["sgv"]:o + lay["sgv"] + Df]
         swk = stats[o + lay["swk"]:o + lay["swk"] + Df]
         Ki, S, L_q, a = u["Kuui"][q], u["S"][q], u["L"][q], u["a"][q]
         m = prm["m_u"][:, q]
