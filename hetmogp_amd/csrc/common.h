@@ -68,6 +68,7 @@ struct GemmArgs {
   long long sSplit = 0;
   int a_kmajor = 0, b_kmajor = 1;
   int lower_only = 0;
+  int role = 0;  // 0 generic, 1 forward contraction, 2 weighted Gram (names the kernel instantiation for profiles)
 };
 void launch_gemm_f64(const GemmArgs& g, hipStream_t stream);
 

@@ -268,7 +268,7 @@ struct hmogp_engine {
     dW.ensure(sizeof(double) * Q * Df), dkap.ensure(sizeof(double) * Q * Df);
     a.ensure(sizeof(double) * Q * M), Kr.ensure(sizeof(double) * Q * M), gmu.ensure(sizeof(double) * Q * M);
     gL.ensure(sizeof(double) * ((long long)M * (M + 1) / 2) * Q);
-    klout.ensure(sizeof(double) * Q * 5);
+    klout.ensure(sizeof(double) * Q * KL_BLOCKS * 5);
     rowout.ensure(sizeof(double) * Q * M * (2 + P));
     dinfo.ensure(sizeof(int) * Q), djit.ensure(sizeof(double) * Q), dscr.ensure(sizeof(double) * Q * M * 32);
     rung.assign(Q, -1);
@@ -402,6 +402,7 @@ struct hmogp_engine {
             g.B = C.d() + q * MM, g.ldb = M, g.b_kmajor = 1;
             g.C = pt, g.ldc = M;
             g.M = (int)n, g.N = M, g.K = M;
+            g.role = 1;
             launch_gemm_f64(g, st);
           }
           {
@@ -440,8 +441,12 @@ struct hmogp_engine {
           const double* pt = Pt.d() + (long long)q * ldn * M;
           {
             Scope sc(this, CAT_GRAM, 2);  // H_q += K^T diag(beta) K^   (svmogp_inf.py:145-147 summed over d)
+            // row ranges per launch: a multiple of 8 (one range per XCD at a time), each >= 32 k-steps of 16 rows,
+            // enough blocks (lower tiles x ranges) for >= 8 rounds over the 256 CUs, at most 64 slabs
             const long long ksteps = (n + 15) / 16;
-            int ksplit = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(64, ksteps), (1024 + ntl - 1) / ntl));
+            long long want = (8 * 256 + ntl - 1) / ntl;
+            want = std::min<long long>(std::min<long long>(64, std::max<long long>(1, ksteps / 32)), want);
+            int ksplit = (int)(want >= 8 ? (want / 8) * 8 : std::max<long long>(1, want));
             slabs.ensure(sizeof(double) * MM * 64, true);
             GemmArgs g;
             g.A = kh, g.lda = M, g.a_kmajor = 1;
@@ -451,6 +456,7 @@ struct hmogp_engine {
             g.M = g.N = M, g.K = (int)n;
             g.lower_only = 1;
             g.ksplit = ksplit, g.sSplit = MM;
+            g.role = 2;
             launch_gemm_f64(g, st);
             launch_reduce_slabs(slabs.d(), ksplit, MM, MM, Hq(q), true, st);
           }
@@ -508,9 +514,9 @@ struct hmogp_engine {
       launch_kl_terms(Kuui.d(), S.d(), dmu.d(), a.d(), Luu.d(), L.d(), Sqi.d(), Q, M, klout.d(), st);
     }
     // ---- device -> host ------------------------------------------------------------------------------
-    std::vector<double> hg(NG), hkl(Q * 5), htail(Q * (per_q - oDZ)), hrow(want_hz ? (size_t)Q * M * (2 + P) : 0);
+    std::vector<double> hg(NG), hkl((size_t)Q * KL_BLOCKS * 5), htail(Q * (per_q - oDZ)), hrow(want_hz ? (size_t)Q * M * (2 + P) : 0);
     HIP_TRY(hipMemcpyAsync(hg.data(), stats.p, sizeof(double) * NG, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(hkl.data(), klout.p, sizeof(double) * Q * 5, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hkl.data(), klout.p, sizeof(double) * hkl.size(), hipMemcpyDeviceToHost, st));
     for (int q = 0; q < Q; ++q)
       HIP_TRY(hipMemcpyAsync(htail.data() + q * (per_q - oDZ), Hq(q) + oDZ, sizeof(double) * (per_q - oDZ),
                              hipMemcpyDeviceToHost, st));
@@ -536,7 +542,9 @@ struct hmogp_engine {
     // ---- host assembly (svmogp.py:101-166) -----------------------------------------------------------
     double KL = 0.0, ninf = 0.0;
     for (int q = 0; q < Q; ++q) {
-      const double* k = &hkl[q * 5];
+      double k[5] = {0, 0, 0, 0, 0};
+      for (int b = 0; b < KL_BLOCKS; ++b)
+        for (int i = 0; i < 5; ++i) k[i] += hkl[((size_t)q * KL_BLOCKS + b) * 5 + i];
       KL += 0.5 * k[0] + 0.5 * k[1] - 0.5 * M + k[2] - k[3];  // svmogp_inf.py:245-249
       ninf += k[4];
     }

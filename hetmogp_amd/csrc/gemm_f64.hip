@@ -72,13 +72,24 @@ __device__ __forceinline__ void store_kmajor(double (*s)[LDS_LD], const double (
   for (int i = 0; i < 4; ++i) q[i] = f64x2{v[2 * i], v[2 * i + 1]};
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR>
+// ROLE only names the instantiation (0 = generic M x M algebra, 1 = forward P~ = K^ C, 2 = weighted Gram) so that
+// rocprofv3 reports the two row-pass contractions separately from the small replicated GEMMs.
+template <bool A_KMAJOR, bool B_KMAJOR, int ROLE>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int tiles_n, int ntiles) {
   __shared__ __attribute__((aligned(16))) Tile lds;
 
   // ---- which tile / batch / k-range -----------------------------------------------------------------
-  int v = blockIdx.x;
-  if ((ntiles & 7) == 0) {  // XCD-aware order: block b runs on XCD b%8; give each XCD a contiguous tile range
+  // Block b is observed to run on XCD b % 8 (speed only, never correctness).  Without a K split every XCD gets a
+  // contiguous range of tiles (the column tiles of one row panel share its A panel through that XCD's L2).  With a
+  // K split, all tiles of one K range go to ONE XCD: they stream the same rows of the operand concurrently, so the
+  // operand is fetched from HBM once per range instead of once per tile.
+  int v = blockIdx.x, split = 0;
+  if (g.ksplit > 1) {
+    const int xcd = v & 7, idx = v >> 3;
+    split = (idx / ntiles) * 8 + xcd;
+    v = idx % ntiles;
+    if (split >= g.ksplit) return;
+  } else if ((ntiles & 7) == 0) {
     const int cpx = ntiles >> 3;
     v = (v & 7) * cpx + (v >> 3);
   }
@@ -92,7 +103,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
     ti = v / tiles_n;
     tj = v - ti * tiles_n;
   }
-  const int batch = blockIdx.z / g.ksplit, split = blockIdx.z - batch * g.ksplit;
+  const int batch = blockIdx.z;
   int M = g.M, N = g.N, K = g.K;
   if (batch == g.nbatch - 1) {
     if (g.M_last > 0) M = g.M_last;
@@ -219,13 +230,18 @@ void launch_gemm_f64(const GemmArgs& g, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0 || g.nbatch <= 0 || g.nouter <= 0) return;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   const int ntiles = g.lower_only ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
-  dim3 grid(ntiles, g.nouter, g.nbatch * g.ksplit), block(NTHREADS);
-  if (g.a_kmajor && g.b_kmajor)
-    hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, block, 0, stream, g, tiles_n, ntiles);
+  const int gx = (g.ksplit > 1) ? ntiles * ((g.ksplit + 7) / 8) * 8 : ntiles;
+  dim3 grid(gx, g.nouter, g.nbatch), block(NTHREADS);
+  if (g.role == 1 && !g.a_kmajor && g.b_kmajor)
+    hipLaunchKernelGGL((gemm_f64_kernel<false, true, 1>), grid, block, 0, stream, g, tiles_n, ntiles);
+  else if (g.role == 2 && g.a_kmajor && g.b_kmajor)
+    hipLaunchKernelGGL((gemm_f64_kernel<true, true, 2>), grid, block, 0, stream, g, tiles_n, ntiles);
+  else if (g.a_kmajor && g.b_kmajor)
+    hipLaunchKernelGGL((gemm_f64_kernel<true, true, 0>), grid, block, 0, stream, g, tiles_n, ntiles);
   else if (g.a_kmajor && !g.b_kmajor)
-    hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, block, 0, stream, g, tiles_n, ntiles);
+    hipLaunchKernelGGL((gemm_f64_kernel<true, false, 0>), grid, block, 0, stream, g, tiles_n, ntiles);
   else if (!g.a_kmajor && g.b_kmajor)
-    hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, block, 0, stream, g, tiles_n, ntiles);
+    hipLaunchKernelGGL((gemm_f64_kernel<false, true, 0>), grid, block, 0, stream, g, tiles_n, ntiles);
   else
-    hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, 0, stream, g, tiles_n, ntiles);
+    hipLaunchKernelGGL((gemm_f64_kernel<false, false, 0>), grid, block, 0, stream, g, tiles_n, ntiles);
 }

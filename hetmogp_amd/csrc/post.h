@@ -4,7 +4,9 @@
 
 void launch_add_diag_copy(const double* src, double* dst, int Q, int M, const double* d_jit, hipStream_t s);
 void launch_sub(const double* A, const double* B, double* C, long long n, hipStream_t s);
-// out[q*5 + {0..4}] = sum(Kuui.*S), m^T a, sum log|diag Luu|, sum log|diag L|, #inf(Sqi)   (Sqi may be nullptr)
+#define KL_BLOCKS 64
+// out[(q*KL_BLOCKS + b)*5 + {0..4}] = block partials of sum(Kuui.*S), m^T a, sum log|diag Luu|, sum log|diag L|,
+// #inf(Sqi) (Sqi may be nullptr); the host adds the KL_BLOCKS partials in order
 void launch_kl_terms(const double* Kuui, const double* S, const double* m_u, const double* a, const double* Luu,
                      const double* L, const double* Sqi, int Q, int M, double* out, hipStream_t s);
 void launch_dkmm(const double* G, const double* GSK, const double* Kuui, const double* KSK, const double* Kr, const double* a,

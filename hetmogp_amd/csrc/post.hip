@@ -28,15 +28,15 @@ __global__ __launch_bounds__(256) void kl_terms_kernel(const double* __restrict_
                                                        const double* __restrict__ Sqi, int Q, int M,
                                                        double* __restrict__ out) {
   __shared__ double scratch[16];
-  const int q = blockIdx.x, t = threadIdx.x;
+  const int q = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
   const long long MM = (long long)M * M, base = (long long)q * MM;
   double tr = 0.0, ninf = 0.0;
-  for (long long i = t; i < MM; i += 256) {
+  for (long long i = (long long)b * 256 + t; i < MM; i += 256LL * KL_BLOCKS) {
     tr += Kuui[base + i] * S[base + i];
     if (Sqi) ninf += isinf(Sqi[base + i]) ? 1.0 : 0.0;
   }
   double ma = 0.0, l1 = 0.0, l2 = 0.0;
-  for (int i = t; i < M; i += 256) {
+  for (int i = b * 256 + t; i < M; i += 256 * KL_BLOCKS) {
     ma += m_u[(long long)i * Q + q] * a[(long long)q * M + i];
     l1 += log(fabs(Luu[base + (long long)i * M + i]));
     l2 += log(fabs(L[base + (long long)i * M + i]));
@@ -47,11 +47,8 @@ __global__ __launch_bounds__(256) void kl_terms_kernel(const double* __restrict_
   l2 = block_sum(l2, scratch);
   ninf = block_sum(ninf, scratch);
   if (t == 0) {
-    out[q * 5 + 0] = tr;
-    out[q * 5 + 1] = ma;
-    out[q * 5 + 2] = l1;
-    out[q * 5 + 3] = l2;
-    out[q * 5 + 4] = ninf;
+    double* o = out + ((long long)q * KL_BLOCKS + b) * 5;
+    o[0] = tr, o[1] = ma, o[2] = l1, o[3] = l2, o[4] = ninf;
   }
 }
 
@@ -167,7 +164,7 @@ void launch_sub(const double* A, const double* B, double* C, long long n, hipStr
 }
 void launch_kl_terms(const double* Kuui, const double* S, const double* m_u, const double* a, const double* Luu,
                      const double* L, const double* Sqi, int Q, int M, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(kl_terms_kernel, dim3(Q), dim3(256), 0, s, Kuui, S, m_u, a, Luu, L, Sqi, Q, M, out);
+  hipLaunchKernelGGL(kl_terms_kernel, dim3(KL_BLOCKS, Q), dim3(256), 0, s, Kuui, S, m_u, a, Luu, L, Sqi, Q, M, out);
 }
 void launch_dkmm(const double* G, const double* GSK, const double* Kuui, const double* KSK, const double* Kr, const double* a,
                  double* out, int Q, int M, hipStream_t s) {

@@ -1,0 +1,80 @@
+"""Row sharding and the one exchange step of the path: every data-dependent quantity of the ELBO
+and its gradients is a sum over rows, so each rank runs `step_begin` on its own contiguous row range of every
+task, the additive statistic bundle is sum-all-reduced once, and `step_finish` (replicated M x M algebra) runs on
+every rank.  torch.distributed is plumbing only: backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the
+CPU tests of this module and as the host-staged fallback."""
+import numpy as np
+
+
+def shard_rows(n_rows, rank, world):
+    """Contiguous, balanced [begin, end) of `n_rows` rows for `rank` of `world` (first `n_rows % world` ranks get one
+    extra row).  Mirrors the reference's contiguous minibatch slices (util.py:52-72) at the rank level."""
+    base, extra = divmod(int(n_rows), int(world))
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def shard_ranges(row_begin, row_end, rank, world):
+    """Split every task's active range [row_begin[t], row_end[t]) across ranks."""
+    rb, re = [], []
+    for b, e in zip(row_begin, row_end):
+        s0, s1 = shard_rows(e - b, rank, world)
+        rb.append(b + s0)
+        re.append(b + s1)
+    return rb, re
+
+
+def all_reduce_host(vec, group=None):
+    """Sum-all-reduce a host float64 vector through torch.distributed (any backend that accepts CPU tensors)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.float64))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.numpy()
+
+
+class _DevicePtr(object):
+    """Minimal __cuda_array_interface__ carrier so torch can alias engine-owned HBM without a copy."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+class StatsReducer(object):
+    """All-reduce of one engine's statistic bundle.  mode "device": the bundle is aliased as a torch CUDA tensor and
+    reduced in place by RCCL (no host copy); mode "host": read -> CPU all-reduce -> write back (gloo)."""
+
+    def __init__(self, engine, device=0, mode=None, group=None):
+        import torch
+        import torch.distributed as dist
+        self.engine, self.group = engine, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if mode is None:
+            mode = "device" if (dist.is_initialized() and dist.get_backend(group) == "nccl") else "host"
+        self.mode = mode
+        self.tensor = None
+        if mode == "device":
+            ptr, n = engine.stats_buffer()
+            self.tensor = torch.as_tensor(_DevicePtr(ptr, n), device="cuda:%d" % device)
+
+    def __call__(self):
+        if self.world == 1:
+            return
+        import torch
+        import torch.distributed as dist
+        if self.mode == "device":
+            dist.all_reduce(self.tensor, op=dist.ReduceOp.SUM, group=self.group)
+            torch.cuda.synchronize(self.tensor.device)
+        else:
+            self.engine.stats_write(all_reduce_host(self.engine.stats_read(), self.group))
+
+
+def sharded_elbo_grad(engine, reducer, rank, world, row_begin=None, row_end=None, want_dL_dS=False, **params):
+    """One evaluation over `world` ranks: begin on this rank's rows -> all-reduce -> finish."""
+    T = engine.T
+    row_begin = [0] * T if row_begin is None else list(row_begin)
+    row_end = list(engine.N) if row_end is None else list(row_end)
+    rb, re = shard_ranges(row_begin, row_end, rank, world)
+    engine.step_begin(row_begin=rb, row_end=re, **params)
+    reducer()
+    return engine.step_finish(want_dL_dS=want_dL_dS)
