@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libhetmogp_hip.so")
 ABI_VERSION = 1
 # likelihood ids (class names of the reference's likelihoods/<name>.py)
 LIK_GAUSSIAN, LIK_BERNOULLI, LIK_HETGAUSSIAN, LIK_CATEGORICAL, LIK_POISSON, LIK_EXPONENTIAL, LIK_GAMMA, LIK_BETA = range(8)
+LIK_IDS_BY_NAME = dict(Gaussian=0, Bernoulli=1, HetGaussian=2, Categorical=3, Poisson=4, Exponential=5, Gamma=6, Beta=7)
 E_INVALID, E_NO_DEVICE, E_NOT_PD, E_SQI_UNSTABLE, E_STATE = -1, -2, -3, -4, -5
 FLAG_V_NEGATIVE = 1
 GROUP_QU, GROUP_HYPER, GROUP_Z, GROUP_ALL = 1, 2, 4, 7

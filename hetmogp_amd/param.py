@@ -1,0 +1,92 @@
+"""Minimal parameter containers with the slice of the paramz surface the reference touches
+(hetmogp/svmogp.py:66-75,106-113,153-166; hetmogp/util.py:285-317): ndarray values, a `.gradient` of the same shape
+that basic slices write through to, `.fix()` / `.unfix()` / `.is_fixed`, and the Logexp positive transform paramz
+applies to `variance`, `lengthscale` and `kappa` in the optimiser's view.  paramz itself is not a dependency."""
+import re
+
+import numpy as np
+
+
+class Param(np.ndarray):
+    def __new__(cls, name, input_array, positive=False):
+        obj = np.array(np.atleast_1d(input_array), dtype=np.float64).view(cls)   # copy: detached from the caller
+        obj.name = name
+        obj._grad = np.zeros(obj.shape)
+        obj._fixed = [False]
+        obj.positive = positive
+        return obj
+
+    def __array_finalize__(self, obj):
+        self.name = getattr(obj, "name", None)
+        self._grad = None
+        self._fixed = getattr(obj, "_fixed", [False])
+        self.positive = getattr(obj, "positive", False)
+
+    def __getitem__(self, idx):
+        out = np.ndarray.__getitem__(self, idx)
+        if isinstance(out, Param) and getattr(self, "_grad", None) is not None:
+            try:
+                out._grad = self._grad[idx]
+            except Exception:
+                out._grad = None
+        return out
+
+    @property
+    def gradient(self):
+        return self._grad
+
+    @gradient.setter
+    def gradient(self, val):
+        if self._grad is None:
+            self._grad = np.zeros(self.shape)
+        self._grad[...] = np.asarray(val, dtype=np.float64).reshape(self._grad.shape)
+
+    @property
+    def values(self):
+        return np.asarray(self)
+
+    @property
+    def is_fixed(self):
+        return self._fixed[0]
+
+    def fix(self):
+        self._fixed[0] = True
+
+    def unfix(self):
+        self._fixed[0] = False
+
+
+class ParamGroup(object):
+    """What `model['.*.lengthscale']` returns: fix()/unfix() over every matching parameter (util.py:285-317)."""
+
+    def __init__(self, params):
+        self.params = list(params)
+
+    def fix(self):
+        for p in self.params:
+            p.fix()
+
+    def unfix(self):
+        for p in self.params:
+            p.unfix()
+
+    def __len__(self):
+        return len(self.params)
+
+
+def match(named_params, pattern):
+    rx = re.compile(pattern)
+    return ParamGroup(p for n, p in named_params if rx.search(n) or rx.fullmatch(n))
+
+
+# paramz Logexp: theta = log(1 + exp(x)); gradient factor d theta / d x = 1 - exp(-theta)
+def logexp_f(x):
+    return np.where(x > 36.0, x, np.log1p(np.exp(np.minimum(x, 36.0))))
+
+
+def logexp_finv(theta):
+    return np.where(theta > 36.0, theta, np.log(np.expm1(np.minimum(theta, 36.0))))
+
+
+def logexp_gradfactor(theta):
+    return np.where(theta > 36.0, 1.0, -np.expm1(-theta))

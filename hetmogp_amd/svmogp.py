@@ -1,0 +1,274 @@
+"""`SVMOGP` -- the reference's model class (hetmogp/svmogp.py:16-217) on top of the HIP engine.
+
+Same constructor, `log_likelihood()`, `parameters_changed()`, `set_data` / `new_batch` / `stochastic_grad` / `callback`,
+same attributes (`q_u_means`, `q_u_chols`, `Z`, `kern_list`, `B_list`, `elbo`, `vem_step`, `ve_count`, `batch_scale`,
+`posteriors`), same gradient gating.  Everything numerical happens in `libhetmogp_hip.so`; GPy / paramz / climin are
+not dependencies: the small part of paramz the reference's drivers use (`optimizer_array`, `_grads`, `optimize`,
+`model['regex'].fix()`) is provided here.  README of the reference calls the class `HetMOGP`; both names are exported.
+"""
+import numpy as np
+
+from . import _lib
+from . import util
+from .engine import Engine
+from .param import Param, match, logexp_f, logexp_finv, logexp_gradfactor
+
+
+class Posterior(object):
+    """What `model.posteriors[q]` exposes to the reference's `_raw_predict` (svmogp.py:238-251)."""
+
+    def __init__(self, mean, woodbury_vector, woodbury_inv):
+        self.mean, self.woodbury_vector, self.woodbury_inv = mean, woodbury_vector, woodbury_inv
+
+
+class SVMOGP(object):
+    def __init__(self, X, Y, Z, kern_list, likelihood, Y_metadata, name="SVMOGP", batch_size=None, W_list=None,
+                 device=0, chunk_rows=0):
+        self.name = name
+        self.batch_size = batch_size
+        self.kern_list = kern_list
+        self.likelihood = likelihood
+        self.Y_metadata = Y_metadata
+        self.num_inducing = Z.shape[0]                                   # M
+        self.num_latent_funcs = len(kern_list)                           # Q
+        self.num_output_funcs = likelihood.num_output_functions(Y_metadata)
+        if W_list is None:
+            self.W_list, self.kappa_list = util.random_W_kappas(self.num_latent_funcs, self.num_output_funcs, rank=1)
+        else:
+            self.W_list = W_list
+            _, self.kappa_list = util.random_W_kappas(self.num_latent_funcs, self.num_output_funcs, rank=1)
+
+        self.Xmulti_all = [np.ascontiguousarray(x, dtype=float).reshape(x.shape[0], -1) for x in X]
+        self.Ymulti_all = [np.ascontiguousarray(y, dtype=float).reshape(-1, 1) for y in Y]
+        T = len(self.Ymulti_all)
+        self.Xdim = Z.shape[1]
+        self._engine = Engine(likelihood.specs(), self.num_latent_funcs, self.num_inducing, self.Xdim, device=device,
+                              chunk_rows=chunk_rows)
+        self._engine.set_data(self.Xmulti_all, self.Ymulti_all)
+        self._rows = [(0, x.shape[0]) for x in self.Xmulti_all]
+        self._last_batch = None
+        if batch_size is None:
+            self.stochastic = False
+            self.Xmulti, self.Ymulti = self.Xmulti_all, self.Ymulti_all
+        else:
+            self.stochastic = True                                         # contiguous slicers, svmogp.py:43-47
+            self.slicer_list = [util.draw_mini_slices(x.shape[0], self.batch_size) for x in self.Xmulti_all]
+            self.set_data(*self.new_batch())
+
+        Ztiled = np.tile(Z, (1, self.num_latent_funcs))                   # svmogp.py:52
+        self.Z = Param("inducing inputs", Ztiled)
+        _, self.B_list = util.LCM(input_dim=self.Xdim, output_dim=self.num_output_funcs, rank=1,
+                                  kernels_list=self.kern_list, W_list=self.W_list, kappa_list=self.kappa_list)
+        M, Q = self.num_inducing, self.num_latent_funcs
+        self.q_u_means = Param("m_u", 2.5 * np.random.randn(M, Q))        # svmogp.py:66-67
+        r, c = np.tril_indices(M)
+        chols = np.zeros((M * (M + 1) // 2, Q))
+        chols[r == c, :] = 1.0                                             # triang_to_flat(identity), :68
+        self.q_u_chols = Param("L_u", chols)
+        self.vem_step = True                                               # True = VE step, False = VM step
+        self.ve_count = 0
+        self.elbo = np.zeros((1, 1))
+        self._log_marginal_likelihood = np.zeros((1, 1))
+        self.posteriors = None
+        self.batch_scale = [1.0] * T
+        self.forced_rung = None
+        self.last = None
+        self.parameters_changed()
+
+    # ------------------------------------------------------------------------------------------ reference surface
+    def log_likelihood(self):
+        """svmogp.py:82-83: a (1,1) ndarray, as the reference returns it."""
+        return self._log_marginal_likelihood
+
+    def _construction_W(self):
+        """The chain factors of svmogp.py:98,141,143,156 come from the construction-time `self.W_list` /
+        `self.kappa_list`, the ELBO from the live B_list."""
+        W0 = np.stack([np.ravel(w) for w in self.W_list])
+        k0 = np.stack([np.ravel(k) for k in self.kappa_list])
+        return W0, k0
+
+    def parameters_changed(self):
+        """svmogp.py:85-166 -- one call into the engine, then the same gated writes to the `.gradient` fields."""
+        T = len(self.Ymulti_all)
+        self.batch_scale = [float(self.Xmulti_all[t].shape[0]) / float(self.Xmulti[t].shape[0]) for t in range(T)]
+        if self.stochastic:
+            mask = _lib.GROUP_QU if self.vem_step else (_lib.GROUP_HYPER | _lib.GROUP_Z)
+        else:
+            mask = _lib.GROUP_ALL
+        if self.Z.is_fixed:
+            mask &= ~_lib.GROUP_Z
+        W0, k0 = self._construction_W()
+        out = self._engine.elbo_grad(
+            Z=self.Z.values, m_u=self.q_u_means.values, L_flat=self.q_u_chols.values,
+            variance=[float(k.variance[0]) for k in self.kern_list],
+            lengthscale=[float(k.lengthscale[0]) for k in self.kern_list],
+            W=np.stack([np.ravel(B.W.values) for B in self.B_list]),
+            kappa=np.stack([np.ravel(B.kappa.values) for B in self.B_list]), W0=W0, kappa0=k0,
+            batch_scale=self.batch_scale, row_begin=[r[0] for r in self._rows], row_end=[r[1] for r in self._rows],
+            forced_rung=self.forced_rung, group_mask=mask)
+        self.last = out
+        self._log_marginal_likelihood = np.array([[out["elbo"]]])
+        self.q_u_means.gradient = out["g_m_u"]
+        self.q_u_chols.gradient = out["g_L_u"]
+        for q, (k, B) in enumerate(zip(self.kern_list, self.B_list)):
+            k.gradient = [out["g_variance"][q], out["g_lengthscale"][q]]
+            B.gradient = np.hstack([out["g_W"][q], out["g_kappa"][q]])
+        if not self.Z.is_fixed:
+            self.Z.gradient = out["g_Z"]
+        self.posteriors = None                                               # built lazily (prediction only)
+
+    def set_data(self, X, Y):
+        """svmogp.py:168-173.  Batches produced by `new_batch()` are row ranges of the data already in HBM; anything
+        else is uploaded."""
+        if self._last_batch is not None and X is self._last_batch[0] and Y is self._last_batch[1]:
+            self._rows = list(self._last_batch[2])
+        else:
+            Xc = [np.ascontiguousarray(x, dtype=float).reshape(x.shape[0], -1) for x in X]
+            Yc = [np.ascontiguousarray(y, dtype=float).reshape(-1, 1) for y in Y]
+            self._engine.set_data(Xc, Yc)
+            self._rows = [(0, x.shape[0]) for x in Xc]
+            X, Y = Xc, Yc
+        self.Xmulti, self.Ymulti = X, Y
+
+    def new_batch(self):
+        """svmogp.py:175-186: the next contiguous slice of every task."""
+        Xb, Yb, rows = [], [], []
+        for t in range(len(self.Ymulti_all)):
+            sl = next(self.slicer_list[t])
+            n = self.Xmulti_all[t].shape[0]
+            rows.append((min(sl.start, n), min(sl.stop, n)))
+            Xb.append(self.Xmulti_all[t][sl])
+            Yb.append(self.Ymulti_all[t][sl])
+        self._last_batch = (Xb, Yb, rows)
+        return Xb, Yb
+
+    def stochastic_grad(self, parameters):
+        """svmogp.py:188-199: 4 consecutive E-step gradients, then 1 M-step gradient."""
+        self.set_data(*self.new_batch())
+        g = self._grads(parameters)
+        if self.vem_step:
+            if self.ve_count > 2:
+                self.ve_count = 0
+                self.vem_step = False
+            else:
+                self.ve_count += 1
+        else:
+            self.vem_step = True
+        return g
+
+    def callback(self, i, max_iter, verbose=True, verbose_plot=False):
+        """svmogp.py:201-217."""
+        self.elbo[i["n_iter"] - 1, 0] = float(self.log_likelihood()[0, 0])
+        if verbose and i["n_iter"] % 50 == 0:
+            print("svi - iteration " + str(i["n_iter"]) + "/" + str(int(max_iter)))
+        return i["n_iter"] > max_iter
+
+    # ------------------------------------------------------------------------------------------ paramz-like view
+    def _named_params(self):
+        """Link order of svmogp.py:71-75: Z (index 0), m_u, L_u, kernels (variance, lengthscale), B_q (W, kappa)."""
+        out = [("%s.inducing_inputs" % self.name, self.Z), ("%s.m_u" % self.name, self.q_u_means),
+               ("%s.L_u" % self.name, self.q_u_chols)]
+        for q, k in enumerate(self.kern_list):
+            out += [("%s.kern_q%d.variance" % (self.name, q), k.variance), ("%s.kern_q%d.lengthscale" % (self.name, q), k.lengthscale)]
+        for q, B in enumerate(self.B_list):
+            out += [("%s.B_q%d.W" % (self.name, q), B.W), ("%s.B_q%d.kappa" % (self.name, q), B.kappa)]
+        return out
+
+    def __getitem__(self, pattern):
+        return match(self._named_params(), pattern)
+
+    @property
+    def optimizer_array(self):
+        """Free parameters, positive ones through paramz's Logexp inverse.  The returned array is a persistent buffer
+        (optimisers such as Adadelta update it in place, util.py:327)."""
+        parts = [logexp_finv(p.values.ravel()) if p.positive else p.values.ravel() for _, p in self._named_params() if not p.is_fixed]
+        x = np.concatenate(parts) if parts else np.zeros(0)
+        if getattr(self, "_opt_buf", None) is None or self._opt_buf.shape != x.shape:
+            self._opt_buf = x.copy()
+        else:
+            self._opt_buf[...] = x
+        return self._opt_buf
+
+    @optimizer_array.setter
+    def optimizer_array(self, x):
+        x = np.asarray(x, dtype=float)
+        i = 0
+        for _, p in self._named_params():
+            if p.is_fixed:
+                continue
+            n = p.size
+            v = x[i:i + n].reshape(p.shape)
+            p[...] = logexp_f(v) if p.positive else v
+            i += n
+        self.parameters_changed()
+
+    def _transformed_gradient(self):
+        parts = []
+        for _, p in self._named_params():
+            if p.is_fixed:
+                continue
+            g = np.asarray(p.gradient, dtype=float).ravel()
+            parts.append(g * logexp_gradfactor(p.values.ravel()) if p.positive else g)
+        return np.concatenate(parts) if parts else np.zeros(0)
+
+    def _grads(self, x):
+        """paramz Model._grads: set the optimiser vector (fires parameters_changed) and return the gradient of the
+        OBJECTIVE (- log likelihood)."""
+        self.optimizer_array = x
+        return -self._transformed_gradient()
+
+    def objective_function(self):
+        return -float(self._log_marginal_likelihood[0, 0])
+
+    def optimize(self, messages=False, max_iters=100, **kw):
+        """paramz Model.optimize default: scipy L-BFGS-B on (objective, gradient) over the free parameters."""
+        from scipy.optimize import minimize
+
+        def f(x):
+            g = self._grads(x)
+            return self.objective_function(), g
+
+        x0 = self.optimizer_array.copy()
+        if x0.size == 0:
+            return self
+        res = minimize(f, x0, jac=True, method="L-BFGS-B", options={"maxiter": int(max_iters), "disp": bool(messages)})
+        self.optimizer_array = res.x
+        return self
+
+    # ------------------------------------------------------------------------------------------ prediction
+    def _ensure_posteriors(self):
+        if self.posteriors is None:
+            wv, wi = self._engine.posterior_u()
+            self.posteriors = [Posterior(self.q_u_means.values[:, q:q + 1], wv[q][:, None], wi[q])
+                               for q in range(self.num_latent_funcs)]
+        return self.posteriors
+
+    def _raw_predict(self, Xnew, latent_function_ind=None, full_cov=False, kern=None):
+        """svmogp.py:219-253: posterior of the latent u_q at Xnew (mean, |variance|)."""
+        q = 0 if latent_function_ind is None else latent_function_ind
+        kern = self.kern_list[q] if kern is None else kern
+        post = self._ensure_posteriors()[q]
+        Zq = self.Z.values[:, q * self.Xdim:(q + 1) * self.Xdim]
+        Kx = kern.K(Zq, np.asarray(Xnew, dtype=float).reshape(-1, self.Xdim))
+        mu = Kx.T @ post.woodbury_vector
+        if full_cov:
+            var = kern.K(Xnew) - Kx.T @ post.woodbury_inv @ Kx
+        else:
+            var = (kern.Kdiag(Xnew) - np.sum((post.woodbury_inv @ Kx) * Kx, 0))[:, None]
+        return mu, np.abs(var)
+
+    def predictive_new(self, Xnew, output_function_ind=None, kern_list=None):
+        """svmogp.py:280-306: algebraically (m_fd(Xnew), |v_fd(Xnew)|) of calculate_q_f -- computed on the device."""
+        d = 0 if output_function_ind is None else output_function_ind
+        m, v = self._engine.predict_f(np.asarray(Xnew, dtype=float).reshape(-1, self.Xdim))
+        return m[:, d:d + 1], np.abs(v[:, d:d + 1])
+
+    def predict_f(self, Xnew):
+        """q(f_d) at Xnew for every function d: (mean [N, Df], variance [N, Df])."""
+        return self._engine.predict_f(np.asarray(Xnew, dtype=float).reshape(-1, self.Xdim))
+
+    def timings(self):
+        return self._engine.timings()
+
+
+HetMOGP = SVMOGP  # the README's name for the class (README.md:35); the reference's code only defines SVMOGP

@@ -1,0 +1,145 @@
+"""Host-side helpers with the reference's names and calling conventions (hetmogp/util.py): model construction
+(`latent_functions_prior`, `random_W_kappas`, `LCM`), the contiguous minibatch slicer (`mini_slices`,
+`draw_mini_slices`) and the VEM driver (`vem_algorithm`: L-BFGS-B alternation or Adadelta SVI).  No arithmetic of the
+ELBO lives here -- that is `SVMOGP.parameters_changed()` -> libhetmogp_hip.so."""
+import random
+from functools import partial
+
+import numpy as np
+
+from .kern import RBF, Coregionalize
+
+
+def get_batch_scales(X_all, X):
+    """util.py:15-19."""
+    return [float(xa.shape[0]) / float(x.shape[0]) for xa, x in zip(X_all, X)]
+
+
+def mini_slices(n_samples, batch_size):
+    """util.py:52-59: contiguous slices, the last one may be short."""
+    n_batches, rest = divmod(n_samples, batch_size)
+    if rest != 0:
+        n_batches += 1
+    return [slice(i * batch_size, (i + 1) * batch_size) for i in range(n_batches)]
+
+
+def draw_mini_slices(n_samples, batch_size, with_replacement=False):
+    """util.py:62-72.  The reference shuffles a temporary copy of the index list (`random.shuffle(list(idxs))`), so the
+    slices are always visited in order; reproduced as is."""
+    slices = mini_slices(n_samples, batch_size)
+    idxs = list(range(len(slices)))
+    if with_replacement:
+        yield random.choice(slices)
+    else:
+        while True:
+            random.shuffle(list(idxs))
+            for i in idxs:
+                yield slices[i]
+
+
+def latent_functions_prior(Q, lenghtscale=None, variance=None, input_dim=None):
+    """util.py:75-90 (the misspelt keyword is the reference's)."""
+    lenghtscale = np.random.rand(Q) if lenghtscale is None else lenghtscale
+    variance = np.random.rand(Q) if variance is None else variance
+    kern_list = []
+    for q in range(Q):
+        k = RBF(input_dim=input_dim, lengthscale=lenghtscale[q], variance=variance[q], name="rbf")
+        k.name = "kern_q" + str(q)
+        kern_list.append(k)
+    return kern_list
+
+
+def random_W_kappas(Q, D, rank, experiment=False):
+    """util.py:92-103: W = +/- N(0.5, 0.5^2) / sqrt(rank), kappa = 0."""
+    W_list, kappa_list = [], []
+    for q in range(Q):
+        p = np.random.binomial(n=1, p=0.5 * np.ones((D, 1)))
+        Ws = p * np.random.normal(loc=0.5, scale=0.5, size=(D, 1)) - (p - 1) * np.random.normal(loc=-0.5, scale=0.5, size=(D, 1))
+        W_list.append(Ws / np.sqrt(rank))
+        kappa_list.append(np.zeros(D))
+    return W_list, kappa_list
+
+
+def LCM(input_dim, output_dim, kernels_list, W_list, kappa_list, rank, name="B_q"):
+    """util.py:126-143: one Coregionalize object per latent GP (the product kernel K itself is never evaluated by the
+    reference's inference; None is returned in its place)."""
+    B_q = []
+    for q in range(len(kernels_list)):
+        B = Coregionalize(input_dim=input_dim, output_dim=output_dim, rank=rank, W=W_list[q], kappa=kappa_list[q])
+        B.name = "%s%s" % (name, q)
+        B_q.append(B)
+    return None, B_q
+
+
+class Adadelta(object):
+    """climin.Adadelta as the reference calls it (util.py:327): wrt is updated IN PLACE.
+    step1 = m*step; wrt -= step1; g = f'(wrt); gms = d*gms + (1-d) g^2; step2 = sqrt(sms+o)/sqrt(gms+o) * g * rate;
+    wrt -= step2; step = step1 + step2; sms = d*sms + (1-d) step^2."""
+
+    def __init__(self, wrt, fprime, step_rate=1.0, decay=0.9, momentum=0.0, offset=1e-4):
+        self.wrt, self.fprime = wrt, fprime
+        self.step_rate, self.decay, self.momentum, self.offset = step_rate, decay, momentum, offset
+        self.gms = np.zeros_like(wrt)
+        self.sms = np.zeros_like(wrt)
+        self.step = np.zeros_like(wrt)
+        self.n_iter = 0
+
+    def __iter__(self):
+        while True:
+            d, o, m = self.decay, self.offset, self.momentum
+            step1 = self.step * m
+            self.wrt -= step1
+            g = self.fprime(self.wrt)
+            self.gms = d * self.gms + (1 - d) * g ** 2
+            step2 = np.sqrt(self.sms + o) / np.sqrt(self.gms + o) * g * self.step_rate
+            self.wrt -= step2
+            self.step = step1 + step2
+            self.sms = d * self.sms + (1 - d) * self.step ** 2
+            self.n_iter += 1
+            yield dict(n_iter=self.n_iter, gradient=g, step=self.step)
+
+    def minimize_until(self, criterion):
+        for info in self:
+            if criterion(info):
+                return info
+
+
+def vem_algorithm(model, stochastic=False, vem_iters=None, step_rate=None, verbose=False, optZ=True, verbose_plot=False,
+                  non_chained=True):
+    """util.py:284-331."""
+    model[".*.lengthscale"].fix()
+    if vem_iters is None:
+        vem_iters = 5
+    model[".*.kappa"].fix()  # must be always fixed
+    model.elbo = np.empty((vem_iters, 1))
+    if stochastic is False:
+        for i in range(vem_iters):
+            # variational E-step
+            model[".*.lengthscale"].fix()
+            model[".*.variance"].fix()
+            model.Z.fix()
+            model[".*.W"].fix()
+            model.q_u_means.unfix()
+            model.q_u_chols.unfix()
+            model.optimize(messages=verbose, max_iters=100)
+            print("iteration (" + str(i + 1) + ") VE step, ELBO=" + str(model.log_likelihood().flatten()))
+            # variational M-step
+            model[".*.lengthscale"].unfix()
+            model[".*.variance"].unfix()
+            if optZ:
+                model.Z.unfix()
+            if non_chained:
+                model[".*.W"].unfix()
+            model.q_u_means.fix()
+            model.q_u_chols.fix()
+            model.optimize(messages=verbose, max_iters=100)
+            print("iteration (" + str(i + 1) + ") VM step, ELBO=" + str(model.log_likelihood().flatten()))
+    else:
+        if step_rate is None:
+            step_rate = 0.01
+        sto_iters = vem_iters
+        model.elbo = np.empty((sto_iters + 1, 1))
+        optimizer = Adadelta(model.optimizer_array, model.stochastic_grad, step_rate=step_rate, momentum=0.9)
+        c_full = partial(model.callback, max_iter=sto_iters, verbose=verbose, verbose_plot=verbose_plot)
+        optimizer.minimize_until(c_full)
+    return model
