@@ -66,6 +66,7 @@ EXPORTS = {
     "hmogp_potri": (C.c_int, [C.c_int32, c_double_p, C.c_int32, C.c_int32, c_double_p]),
     "hmogp_gemm_f64": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, c_double_p,
                                  C.c_int32, c_double_p, C.c_int32, C.c_double, c_double_p, C.c_int32]),
+    "hmogp_bench_contraction": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, c_double_p]),
     "hmogp_var_exp": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_int64, c_double_p, c_double_p, c_double_p,
                                 c_double_p, c_double_p, c_double_p]),
 }

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -81,6 +82,17 @@ int lik_dimf(int lik, double param) {
   }
 }
 
+// Row ranges per weighted-Gram launch: a multiple of 8 (one range per XCD at a time), each >= 32 k-steps of 16 rows,
+// enough blocks (lower tiles x ranges) for >= 8 rounds over the 256 CUs, at most 64 slabs.
+int gram_ksplit(long long n, int M) {
+  if (const char* e = std::getenv("HMOGP_GRAM_KSPLIT")) return std::max(1, std::atoi(e));  // tuning experiments only
+  const int tiles = (M + 127) / 128, ntl = tiles * (tiles + 1) / 2;
+  const long long ksteps = (n + 15) / 16;
+  long long want = (8 * 256 + ntl - 1) / ntl;
+  want = std::min<long long>(std::min<long long>(64, std::max<long long>(1, ksteps / 32)), want);
+  return (int)(want >= 8 ? (want / 8) * 8 : std::max<long long>(1, want));
+}
+
 // ------------------------------------------------------------------------------------ batched jitchol + inverse
 // Luu <- chol(Kuu + jitter I) with GPy's ladder (GPy.util.linalg.jitchol): plain factorisation first, then
 // jitter = mean(diag) * 1e-6 * 10^k, k = 0..4.  diag(K_uu) == variance for the RBF, so mean(diag) = variance.
@@ -128,7 +140,7 @@ void jitchol_batched(const double* Kuu, double* Luu, int Q, int M, const double*
 // =================================================================================================== engine
 struct hmogp_engine {
   int T = 0, Q = 0, M = 0, P = 0, Df = 0, device = 0;
-  long long chunk = 131072;
+  long long chunk = 262144;
   std::vector<int> f_index, d_index;
   std::vector<Task> tasks;
   hipStream_t st = nullptr;
@@ -441,12 +453,7 @@ struct hmogp_engine {
           const double* pt = Pt.d() + (long long)q * ldn * M;
           {
             Scope sc(this, CAT_GRAM, 2);  // H_q += K^T diag(beta) K^   (svmogp_inf.py:145-147 summed over d)
-            // row ranges per launch: a multiple of 8 (one range per XCD at a time), each >= 32 k-steps of 16 rows,
-            // enough blocks (lower tiles x ranges) for >= 8 rounds over the 256 CUs, at most 64 slabs
-            const long long ksteps = (n + 15) / 16;
-            long long want = (8 * 256 + ntl - 1) / ntl;
-            want = std::min<long long>(std::min<long long>(64, std::max<long long>(1, ksteps / 32)), want);
-            int ksplit = (int)(want >= 8 ? (want / 8) * 8 : std::max<long long>(1, want));
+            const int ksplit = gram_ksplit(n, M);
             slabs.ensure(sizeof(double) * MM * 64, true);
             GemmArgs g;
             g.A = kh, g.lda = M, g.a_kmajor = 1;
@@ -863,6 +870,58 @@ int hmogp_var_exp(int32_t device, int32_t lik_id, double lik_param, int64_t N, c
     HIP_TRY(hipMemcpy(ve, dve.p, sizeof(double) * N, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(dm, ddm.p, sizeof(double) * N * J, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(dv, ddv.p, sizeof(double) * N * J, hipMemcpyDeviceToHost));
+  });
+}
+
+int hmogp_bench_contraction(int32_t device, int32_t role, int64_t n, int32_t M, int32_t iters, double* avg_ms) {
+  return guarded(nullptr, [&] {
+    need_device(device);
+    if (n <= 0 || M <= 0 || iters <= 0 || !avg_ms || (role != 1 && role != 2)) throw EngineError{HMOGP_E_INVALID, "bad arguments"};
+    const long long MM = (long long)M * M;
+    DevBuf A, B, Cc, beta, slabs;
+    A.ensure(sizeof(double) * n * M), B.ensure(sizeof(double) * MM), Cc.ensure(sizeof(double) * std::max<long long>(n * M, MM));
+    beta.ensure(sizeof(double) * n), slabs.ensure(sizeof(double) * MM * 64, true);
+    std::vector<double> h((size_t)std::max<long long>(n * M, MM));
+    unsigned long long s = 88172645463325252ULL;   // xorshift: full-range random operands (DVFS-realistic, guide rule 25)
+    auto rnd = [&] { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (double)(s >> 11) / 9007199254740992.0 * 2.0 - 1.0; };
+    for (auto& v : h) v = rnd();
+    HIP_TRY(hipMemcpy(A.p, h.data(), sizeof(double) * n * M, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(B.p, h.data(), sizeof(double) * MM, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(beta.p, h.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    auto once = [&] {
+      GemmArgs g;
+      if (role == 1) {
+        g.A = A.d(), g.lda = M, g.a_kmajor = 0;
+        g.B = B.d(), g.ldb = M, g.b_kmajor = 1;
+        g.C = Cc.d(), g.ldc = M;
+        g.M = (int)n, g.N = M, g.K = M;
+        g.role = 1;
+        launch_gemm_f64(g, nullptr);
+      } else {
+        const int ksplit = gram_ksplit(n, M);
+        g.A = A.d(), g.lda = M, g.a_kmajor = 1;
+        g.B = A.d(), g.ldb = M, g.b_kmajor = 1;
+        g.kscale = beta.d();
+        g.C = slabs.d(), g.ldc = M;
+        g.M = g.N = M, g.K = (int)n;
+        g.lower_only = 1, g.ksplit = ksplit, g.sSplit = MM, g.role = 2;
+        launch_gemm_f64(g, nullptr);
+        if (!std::getenv("HMOGP_BENCH_NO_REDUCE")) launch_reduce_slabs(slabs.d(), ksplit, MM, MM, Cc.d(), true, nullptr);
+      }
+    };
+    once();
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) once();
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
   });
 }
 

@@ -11,15 +11,24 @@
 // lane l is element [k = l>>4][row = l&15], so a wave reads 4 runs of 16 consecutive doubles; 144*8 B = 288
 // dwords == 32 banks (mod 64) puts the two k-rows of each 32-lane half on disjoint banks (ds_read_b64 is
 // conflict-free).  LDS is double buffered; the next tile's global loads are issued before the MFMA block.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, LDS_LD = 144, NTHREADS = 256;
+constexpr int BM = 128, BN = 128, BK = 16, NTHREADS = 256;
+// LDS images of one 128 x 16 operand tile (2304 doubles either way):
+//   k-major  [k][144]  for operands stored [k][row]  -> fragment (lane l) = [k = l>>4][row = l&15]
+//   row-major [row][18] for operands stored [row][k] -> copied as is (no transposition), fragment = [row = l&15][k = l>>4]
+// 144*8 B = 288 dwords == 32 (mod 64) and 18*8 B = 36 dwords: in both images the 32 lanes of a ds_read_b64 half-wave hit
+// 64 distinct banks, and the 16-byte staging stores of each 8-lane group hit 32 distinct banks.
+constexpr int KM_LD = 144, RM_LD = 18, TILE_DOUBLES = BK * KM_LD;
+static_assert(BM * RM_LD == TILE_DOUBLES, "both LDS images have the same size");
 
 struct Tile {
-  double a[2][BK][LDS_LD];
-  double b[2][BK][LDS_LD];
+  double a[2][TILE_DOUBLES];
+  double b[2][TILE_DOUBLES];
 };
 
 // Load 8 consecutive doubles p[0..7] (16-byte vector loads) -- caller guarantees alignment and bounds.
@@ -43,39 +52,60 @@ __device__ __forceinline__ void load_rowmajor(const double* __restrict__ base, i
   } else {
     const bool rok = (row0 + r) < nrows;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (rok && (k0 + kh + i) < kend) ? p[i] : 0.0;
+    for (int i = 0; i < 8; ++i) {
+      v[i] = 0.0;
+      if (rok && (k0 + kh + i) < kend) v[i] = p[i];
+    }
   }
 }
-__device__ __forceinline__ void store_rowmajor(double (*s)[LDS_LD], const double (&v)[8]) {
+__device__ __forceinline__ void store_rowmajor(double* s, const double (&v)[8]) {
   const int t = threadIdx.x, r = t >> 1, kh = (t & 1) * 8;
+  f64x2* q = reinterpret_cast<f64x2*>(s + r * RM_LD + kh);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) s[kh + i][r] = v[i];
+  for (int i = 0; i < 4; ++i) q[i] = f64x2{v[2 * i], v[2 * i + 1]};
 }
 
-// Operand stored [k][col] (col contiguous): thread loads k = t>>4, 8 cols starting at (t&15)*8.
+// Operand stored [k][col] (col contiguous): thread owns row k = t>>4 and the four column pairs
+// j*32 + (t&15)*2 (j = 0..3): each 16-lane group reads / writes 256 contiguous bytes per vector instruction
+// (coalesced global segments, conflict-free ds_write_b128).
 __device__ __forceinline__ void load_kmajor(const double* __restrict__ base, int ld, int col0, int ncols, int k0,
                                             int kend, bool fast, double (&v)[8]) {
-  const int t = threadIdx.x, k = t >> 4, c8 = (t & 15) * 8;
-  const double* p = base + (long long)(k0 + k) * ld + (col0 + c8);
+  const int t = threadIdx.x, k = t >> 4, c2 = (t & 15) * 2;
+  const double* p = base + (long long)(k0 + k) * ld + (col0 + c2);
   if (fast) {
-    load8_fast(p, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f64x2 x = *reinterpret_cast<const f64x2*>(p + j * 32);
+      v[2 * j] = x.x;
+      v[2 * j + 1] = x.y;
+    }
   } else {
     const bool kok = (k0 + k) < kend;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (kok && (col0 + c8 + i) < ncols) ? p[i] : 0.0;
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        v[2 * j + e] = 0.0;
+        if (kok && (col0 + c2 + j * 32 + e) < ncols) v[2 * j + e] = p[j * 32 + e];
+      }
   }
 }
-__device__ __forceinline__ void store_kmajor(double (*s)[LDS_LD], const double (&v)[8]) {
-  const int t = threadIdx.x, k = t >> 4, c8 = (t & 15) * 8;
-  f64x2* q = reinterpret_cast<f64x2*>(&s[k][c8]);
+__device__ __forceinline__ void store_kmajor(double* s, const double (&v)[8]) {
+  const int t = threadIdx.x, k = t >> 4, c2 = (t & 15) * 2;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) q[i] = f64x2{v[2 * i], v[2 * i + 1]};
+  for (int j = 0; j < 4; ++j) *reinterpret_cast<f64x2*>(s + k * KM_LD + c2 + j * 32) = f64x2{v[2 * j], v[2 * j + 1]};
 }
 
 // ROLE only names the instantiation (0 = generic M x M algebra, 1 = forward P~ = K^ C, 2 = weighted Gram) so that
 // rocprofv3 reports the two row-pass contractions separately from the small replicated GEMMs.
 template <bool A_KMAJOR, bool B_KMAJOR, int ROLE>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int tiles_n, int ntiles) {
+#ifndef GEMM_ABL
+#define GEMM_ABL 0
+#endif
+#ifndef GEMM_WAVES_PER_SIMD
+#define GEMM_WAVES_PER_SIMD 2
+#endif
+__global__ __launch_bounds__(NTHREADS, GEMM_WAVES_PER_SIMD) void gemm_f64_kernel(GemmArgs g, int tiles_n, int ntiles) {
   __shared__ __attribute__((aligned(16))) Tile lds;
 
   // ---- which tile / batch / k-range -----------------------------------------------------------------
@@ -131,6 +161,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
 
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wm = w >> 1, wn = w & 1, lr = lane & 15, lk = lane >> 4;
+  // lower-only products: on a diagonal tile the wave that owns the strictly-upper 64 x 64 quadrant has nothing to
+  // compute (it still takes part in staging and barriers)
+  const bool idle_quadrant = g.lower_only && ti == tj && wm == 0 && wn == 1;
 
   f64x4 acc[4][4];
 #pragma unroll
@@ -138,7 +171,80 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-  double ra[8], rb[8];
+  // The loads of tile k+1 are issued before the MFMA block of tile k and must not be consumed until `stage` (after the
+  // MFMA block): the k-scale of the Gram operand is therefore applied at stage time, not at load time (a multiply at
+  // load time makes hipcc wait vmcnt(0) in front of the MFMAs and exposes the whole HBM latency every k-step).
+#ifdef GEMM_DEEP
+  // Two register sets: loads of tile k+2 are issued before the MFMA block of tile k and staged after the MFMA block
+  // of tile k+1 (two k-steps of latency budget).
+  double ra0[8], rb0[8], ra1[8], rb1[8], ks0 = 1.0, ks1 = 1.0;
+  auto load = [&](int k0, double (&ra)[8], double (&rb)[8], double& ks) {
+    const bool fk = (k0 + BK <= kend);
+    if (A_KMAJOR)
+      load_kmajor(A, g.lda, i0, M, k0, kend, fullA && fk, ra);
+    else
+      load_rowmajor(A, g.lda, i0, M, k0, kend, fullA && fk, ra);
+    if (B_KMAJOR) {
+      load_kmajor(B, g.ldb, j0, N, k0, kend, fullB && fk, rb);
+      if (S) {
+        const int k = k0 + (t >> 4);
+        ks = (k < kend) ? S[k] : 0.0;
+      }
+    } else {
+      load_rowmajor(B, g.ldb, j0, N, k0, kend, fullB && fk, rb);
+    }
+  };
+  auto stage = [&](int buf, double (&ra)[8], double (&rb)[8], double ks) {
+    if (A_KMAJOR)
+      store_kmajor(lds.a[buf], ra);
+    else
+      store_rowmajor(lds.a[buf], ra);
+    if (B_KMAJOR) {
+      if (S) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rb[i] *= ks;
+      }
+      store_kmajor(lds.b[buf], rb);
+    } else {
+      store_rowmajor(lds.b[buf], rb);
+    }
+  };
+  auto compute = [&](int cur) {
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const double* pa = A_KMAJOR ? &lds.a[cur][(kk * 4 + lk) * KM_LD + wm * 64 + lr] : &lds.a[cur][(wm * 64 + lr) * RM_LD + kk * 4 + lk];
+      const double* pb = B_KMAJOR ? &lds.b[cur][(kk * 4 + lk) * KM_LD + wn * 64 + lr] : &lds.b[cur][(wn * 64 + lr) * RM_LD + kk * 4 + lk];
+      double fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = pa[i * 16 * (A_KMAJOR ? 1 : RM_LD)];
+        fb[i] = pb[i * 16 * (B_KMAJOR ? 1 : RM_LD)];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+  };
+  if (kbeg < kend) {
+    load(kbeg, ra0, rb0, ks0);
+    stage(0, ra0, rb0, ks0);
+    if (kbeg + BK < kend) load(kbeg + BK, ra1, rb1, ks1);
+  }
+  __syncthreads();
+  for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
+    if (k0 + 2 * BK < kend) load(k0 + 2 * BK, ra0, rb0, ks0);
+    compute(0);
+    if (k0 + BK < kend) stage(1, ra1, rb1, ks1);
+    __syncthreads();
+    if (k0 + BK >= kend) break;
+    if (k0 + 3 * BK < kend) load(k0 + 3 * BK, ra1, rb1, ks1);
+    compute(1);
+    if (k0 + 2 * BK < kend) stage(0, ra0, rb0, ks0);
+    __syncthreads();
+  }
+#else
+  double ra[8], rb[8], ks = 1.0;
   auto load = [&](int k0) {
     const bool fk = (k0 + BK <= kend);
     if (A_KMAJOR)
@@ -149,17 +255,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
       load_kmajor(B, g.ldb, j0, N, k0, kend, fullB && fk, rb);
       if (S) {
         const int k = k0 + (t >> 4);
-        const double s = (k < kend) ? S[k] : 0.0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) rb[i] *= s;
+        ks = (k < kend) ? S[k] : 0.0;
       }
     } else {
       load_rowmajor(B, g.ldb, j0, N, k0, kend, fullB && fk, rb);
-      if (S) {
-        const int kh = k0 + (t & 1) * 8;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) rb[i] *= ((kh + i) < kend) ? S[kh + i] : 0.0;
-      }
     }
   };
   auto stage = [&](int buf) {
@@ -167,10 +266,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
       store_kmajor(lds.a[buf], ra);
     else
       store_rowmajor(lds.a[buf], ra);
-    if (B_KMAJOR)
+    if (B_KMAJOR) {
+      if (S) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rb[i] *= ks;
+      }
       store_kmajor(lds.b[buf], rb);
-    else
+    } else {
       store_rowmajor(lds.b[buf], rb);
+    }
   };
 
   int cur = 0;
@@ -181,29 +285,39 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
   __syncthreads();
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     const bool more = (k0 + BK) < kend;
+#if !(GEMM_ABL & 1)
     if (more) load(k0 + BK);
+#endif
+    if (!idle_quadrant)
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
-      const double* pa = &lds.a[cur][kk * 4 + lk][wm * 64 + lr];
-      const double* pb = &lds.b[cur][kk * 4 + lk][wn * 64 + lr];
+      const double* pa = A_KMAJOR ? &lds.a[cur][(kk * 4 + lk) * KM_LD + wm * 64 + lr] : &lds.a[cur][(wm * 64 + lr) * RM_LD + kk * 4 + lk];
+      const double* pb = B_KMAJOR ? &lds.b[cur][(kk * 4 + lk) * KM_LD + wn * 64 + lr] : &lds.b[cur][(wn * 64 + lr) * RM_LD + kk * 4 + lk];
       double fa[4], fb[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        fa[i] = pa[i * 16];
-        fb[i] = pb[i * 16];
+        fa[i] = pa[i * 16 * (A_KMAJOR ? 1 : RM_LD)];
+        fb[i] = pb[i * 16 * (B_KMAJOR ? 1 : RM_LD)];
       }
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
     }
+#if !(GEMM_ABL & 1)
     if (more) stage(cur ^ 1);
+#endif
+#if !(GEMM_ABL & 2)
     __syncthreads();
+#endif
     cur ^= 1;
   }
 
+#endif
+
   // ---- epilogue: D fragment of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg -----------
   const double alpha = g.alpha, beta = (g.ksplit > 1) ? 0.0 : g.beta;
+  if (idle_quadrant) return;  // the strictly-upper quadrant is never read (mirrored from the lower one)
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
 #pragma unroll
@@ -228,20 +342,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
 
 void launch_gemm_f64(const GemmArgs& g, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0 || g.nbatch <= 0 || g.nouter <= 0) return;
+  if (g.kscale && !g.b_kmajor) throw HipError{hipErrorInvalidValue, "k-scale needs a k-major B operand", __FILE__, __LINE__};
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   const int ntiles = g.lower_only ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
   const int gx = (g.ksplit > 1) ? ntiles * ((g.ksplit + 7) / 8) * 8 : ntiles;
   dim3 grid(gx, g.nouter, g.nbatch), block(NTHREADS);
+  static const int dyn = std::getenv("HMOGP_GEMM_DYNLDS") ? std::atoi(std::getenv("HMOGP_GEMM_DYNLDS")) : 0;  // occupancy experiments
   if (g.role == 1 && !g.a_kmajor && g.b_kmajor)
-    hipLaunchKernelGGL((gemm_f64_kernel<false, true, 1>), grid, block, 0, stream, g, tiles_n, ntiles);
+    hipLaunchKernelGGL((gemm_f64_kernel<false, true, 1>), grid, block, dyn, stream, g, tiles_n, ntiles);
   else if (g.role == 2 && g.a_kmajor && g.b_kmajor)
-    hipLaunchKernelGGL((gemm_f64_kernel<true, true, 2>), grid, block, 0, stream, g, tiles_n, ntiles);
+    hipLaunchKernelGGL((gemm_f64_kernel<true, true, 2>), grid, block, dyn, stream, g, tiles_n, ntiles);
   else if (g.a_kmajor && g.b_kmajor)
-    hipLaunchKernelGGL((gemm_f64_kernel<true, true, 0>), grid, block, 0, stream, g, tiles_n, ntiles);
+    hipLaunchKernelGGL((gemm_f64_kernel<true, true, 0>), grid, block, dyn, stream, g, tiles_n, ntiles);
   else if (g.a_kmajor && !g.b_kmajor)
-    hipLaunchKernelGGL((gemm_f64_kernel<true, false, 0>), grid, block, 0, stream, g, tiles_n, ntiles);
+    hipLaunchKernelGGL((gemm_f64_kernel<true, false, 0>), grid, block, dyn, stream, g, tiles_n, ntiles);
   else if (!g.a_kmajor && g.b_kmajor)
-    hipLaunchKernelGGL((gemm_f64_kernel<false, true, 0>), grid, block, 0, stream, g, tiles_n, ntiles);
+    hipLaunchKernelGGL((gemm_f64_kernel<false, true, 0>), grid, block, dyn, stream, g, tiles_n, ntiles);
   else
-    hipLaunchKernelGGL((gemm_f64_kernel<false, false, 0>), grid, block, 0, stream, g, tiles_n, ntiles);
+    hipLaunchKernelGGL((gemm_f64_kernel<false, false, 0>), grid, block, dyn, stream, g, tiles_n, ntiles);
 }

@@ -82,7 +82,7 @@ typedef struct {
   const int32_t* f_index;   /* [Df] task owning function d      (Y_metadata['function_index'])        */
   const int32_t* d_index;   /* [Df] column of d inside its task (Y_metadata['d_index'])               */
   int32_t device;           /* HIP device ordinal                                                    */
-  int64_t chunk_rows;       /* rows of one task processed per pass (0 = default 131072); bounds the
+  int64_t chunk_rows;       /* rows of one task processed per pass (0 = default 262144); bounds the
                                N x M workspaces: 2 * Q * chunk_rows * M * 8 bytes                    */
 } hmogp_config;
 
@@ -177,6 +177,11 @@ int hmogp_gemm_f64(int32_t device, int32_t transA, int32_t transB, int32_t M, in
 /* Variational expectations of one likelihood: y [N], m,v [N, dim_f] -> ve [N], dm, dv [N, dim_f].         */
 int hmogp_var_exp(int32_t device, int32_t lik_id, double lik_param, int64_t N, const double* y,
                   const double* m, const double* v, double* ve, double* dm, double* dv);
+
+/* Micro-benchmark of the two row-pass contractions on synthetic operands resident in HBM (tools/bench_gemm.py):
+ * role 1: forward  P~[n,M] = K^[n,M] C[M,M];  role 2: weighted Gram  H[M,M] (lower tiles) = K^T diag(beta) K^ incl. the
+ * slab reduction.  Returns the average milliseconds per launch over `iters` launches (HIP events).            */
+int hmogp_bench_contraction(int32_t device, int32_t role, int64_t n, int32_t M, int32_t iters, double* avg_ms);
 
 #ifdef __cplusplus
 }
