@@ -57,6 +57,7 @@ EXPORTS = {
     "hmogp_stats_read": (C.c_int, [C.c_void_p, c_double_p]),
     "hmogp_stats_write": (C.c_int, [C.c_void_p, c_double_p]),
     "hmogp_posterior_u": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "hmogp_natgrad_step": (C.c_int, [C.c_void_p, C.c_double, c_double_p, c_double_p]),
     "hmogp_predict_f": (C.c_int, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p]),
     "hmogp_last_timings": (C.c_int, [C.c_void_p, c_double_p, c_int64_p]),
     "hmogp_rbf_cross_cov": (C.c_int, [C.c_int32, c_double_p, C.c_int64, c_double_p, C.c_int32, C.c_int32, C.c_double,
@@ -66,6 +67,10 @@ EXPORTS = {
     "hmogp_potri": (C.c_int, [C.c_int32, c_double_p, C.c_int32, C.c_int32, c_double_p]),
     "hmogp_gemm_f64": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, c_double_p,
                                  C.c_int32, c_double_p, C.c_int32, C.c_double, c_double_p, C.c_int32]),
+    "hmogp_predictive": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int64, c_double_p, c_double_p, c_double_p,
+                                   c_double_p]),
+    "hmogp_log_predictive": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_int64, C.c_int32, C.c_uint64, c_double_p,
+                                       c_double_p, c_double_p, c_double_p]),
     "hmogp_bench_contraction": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, c_double_p]),
     "hmogp_var_exp": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_int64, c_double_p, c_double_p, c_double_p,
                                 c_double_p, c_double_p, c_double_p]),

@@ -592,6 +592,7 @@ struct hmogp_engine {
                 zz ? (dZs[m * P + p] / (ell * ell) + hrow[((size_t)q * M + m) * (2 + P) + 2 + p] / (ell * ell)) : 0.0;
     }
     evaluated = true;
+    have_qu_grads = want_qu;
     began = false;
     if (ninf > 0.0) throw EngineError{HMOGP_E_SQI_UNSTABLE, "Sqi: Cholesky representation unstable"};
   }
@@ -607,6 +608,44 @@ struct hmogp_engine {
       HIP_TRY(hipMemcpyAsync(winv, tmpA.p, sizeof(double) * MM * Q, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
+  }
+
+  // Natural-gradient update of q(u_q) = N(m_q, S_q) from the gradients of the last evaluation (the
+  // north-star names it, the reference has none):  S^-1 <- S^-1 - 2 gamma dL/dS ;  S^-1 m <- S^-1 m + gamma (dL/dm -
+  // 2 dL/dS m) ;  then m and L = chol(S) are recovered.  Requires the q(u) group in the last evaluation's mask.
+  bool have_qu_grads = false;
+  void natgrad_step(double gamma, double* m_out, double* L_flat_out) {
+    if (!evaluated || !have_qu_grads) throw EngineError{HMOGP_E_STATE, "natural-gradient step needs a finished evaluation with the q(u) group"};
+    if (!m_out || !L_flat_out || !(gamma > 0.0)) throw EngineError{HMOGP_E_INVALID, "bad natural-gradient arguments"};
+    HIP_TRY(hipSetDevice(device));
+    const long long Mtri = (long long)M * (M + 1) / 2;
+    DevBuf t1, t2, th, mnew, mq, lflat;
+    for (DevBuf* b : {&t1, &t2, &th, &mnew}) b->ensure(sizeof(double) * Q * M);
+    mq.ensure(sizeof(double) * M * Q), lflat.ensure(sizeof(double) * Mtri * Q);
+    std::vector<int> info(Q);
+    launch_natgrad_prec(Sqi.d(), dLdS.d(), gamma, HK.d(), Q, M, st);                 // Lambda = new precision
+    launch_gemv_batched(Sqi.d(), dmu.d(), t1.d(), Q, M, 1, Q, st);                   // S^-1 m
+    launch_gemv_batched(dLdS.d(), dmu.d(), t2.d(), Q, M, 1, Q, st);                  // dL/dS m
+    launch_natgrad_theta1(t1.d(), t2.d(), gmu.d(), gamma, th.d(), Q, M, st);
+    HIP_TRY(hipMemcpyAsync(G.p, HK.p, sizeof(double) * (long long)M * M * Q, hipMemcpyDeviceToDevice, st));
+    launch_potrf_batched(G.d(), Q, M, dinfo.as<int>(), dscr.d(), st);                // Lambda = R R^T
+    HIP_TRY(hipMemcpyAsync(info.data(), dinfo.p, sizeof(int) * Q, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int q = 0; q < Q; ++q)
+      if (info[q] != 0) throw EngineError{HMOGP_E_NOT_PD, "natural-gradient step leaves the positive-definite cone (reduce gamma)"};
+    launch_trtri_batched(G.d(), tmpA.d(), tmpB.d(), Q, M, st);
+    launch_ltl_batched(tmpA.d(), GSK.d(), Q, M, st);                                 // S_new = Lambda^-1
+    launch_gemv_batched(GSK.d(), th.d(), mnew.d(), Q, M, M, 1, st);                  // m_new = S_new theta1
+    launch_potrf_batched(GSK.d(), Q, M, dinfo.as<int>(), dscr.d(), st);              // L_new = chol(S_new)
+    HIP_TRY(hipMemcpyAsync(info.data(), dinfo.p, sizeof(int) * Q, hipMemcpyDeviceToHost, st));
+    launch_pack_tril(GSK.d(), lflat.d(), Q, M, 1.0, st);
+    launch_scatter_mq(mnew.d(), mq.d(), Q, M, st);
+    HIP_TRY(hipMemcpyAsync(m_out, mq.p, sizeof(double) * M * Q, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(L_flat_out, lflat.p, sizeof(double) * Mtri * Q, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int q = 0; q < Q; ++q)
+      if (info[q] != 0) throw EngineError{HMOGP_E_NOT_PD, "natural-gradient step: new covariance not positive definite"};
+    evaluated = false;  // HK/G/GSK scratch was reused: posterior/predict need a fresh evaluation
   }
 
   void predict_f(const double* Xnew, long long Nnew, double* m, double* v) {
@@ -752,6 +791,11 @@ int hmogp_posterior_u(hmogp_handle h, double* woodbury_vector, double* woodbury_
   return guarded(h, [&] { h->posterior_u(woodbury_vector, woodbury_inv); });
 }
 
+int hmogp_natgrad_step(hmogp_handle h, double gamma, double* m_u_new, double* L_flat_new) {
+  if (!h) return HMOGP_E_INVALID;
+  return guarded(h, [&] { h->natgrad_step(gamma, m_u_new, L_flat_new); });
+}
+
 int hmogp_predict_f(hmogp_handle h, const double* Xnew, int64_t Nnew, double* m, double* v) {
   if (!h) return HMOGP_E_INVALID;
   return guarded(h, [&] { h->predict_f(Xnew, Nnew, m, v); });
@@ -870,6 +914,49 @@ int hmogp_var_exp(int32_t device, int32_t lik_id, double lik_param, int64_t N, c
     HIP_TRY(hipMemcpy(ve, dve.p, sizeof(double) * N, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(dm, ddm.p, sizeof(double) * N * J, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(dv, ddv.p, sizeof(double) * N * J, hipMemcpyDeviceToHost));
+  });
+}
+
+int hmogp_predictive(int32_t device, int32_t lik_id, double lik_param, int32_t gh_T, int64_t N, const double* m,
+                     const double* v, double* mean, double* var) {
+  return guarded(nullptr, [&] {
+    need_device(device);
+    if (lik_id == HMOGP_LIK_GAUSSIAN && !(lik_param > 0.0)) lik_param = 0.5;
+    const int J = lik_dimf(lik_id, lik_param);
+    const int Jp = (lik_id == HMOGP_LIK_CATEGORICAL) ? J : 1;  // dim_p of the reference's get_metadata()
+    if (gh_T == 0) gh_T = (lik_id == HMOGP_LIK_CATEGORICAL) ? 10 : 20;
+    if (J < 1 || J > HMOGP_MAXJ || N <= 0 || !m || !v || !mean || !var || (gh_T != 10 && gh_T != 20))
+      throw EngineError{HMOGP_E_INVALID, "bad arguments"};
+    DevBuf dm, dv, om, ov;
+    dm.ensure(sizeof(double) * N * J), dv.ensure(sizeof(double) * N * J);
+    om.ensure(sizeof(double) * N * Jp), ov.ensure(sizeof(double) * N * Jp);
+    HIP_TRY(hipMemcpy(dm.p, m, sizeof(double) * N * J, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dv.p, v, sizeof(double) * N * J, hipMemcpyHostToDevice));
+    launch_predictive(lik_id, J, Jp, lik_param, gh_T, N, dm.d(), dv.d(), om.d(), ov.d(), nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(mean, om.p, sizeof(double) * N * Jp, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(var, ov.p, sizeof(double) * N * Jp, hipMemcpyDeviceToHost));
+  });
+}
+
+int hmogp_log_predictive(int32_t device, int32_t lik_id, double lik_param, int64_t N, int32_t num_samples, uint64_t seed,
+                         const double* y, const double* m, const double* v, double* log_pred) {
+  return guarded(nullptr, [&] {
+    need_device(device);
+    const int J = lik_dimf(lik_id, lik_param);
+    if (J < 1 || J > HMOGP_MAXJ || N <= 0 || num_samples < 1 || !y || !m || !v || !log_pred)
+      throw EngineError{HMOGP_E_INVALID, "bad arguments"};
+    if (lik_id == HMOGP_LIK_GAMMA || lik_id == HMOGP_LIK_BETA)
+      throw EngineError{HMOGP_E_INVALID, "the reference defines no log_predictive for Gamma / Beta"};
+    DevBuf dy, dm, dv, dout;
+    dy.ensure(sizeof(double) * N), dout.ensure(sizeof(double) * N);
+    dm.ensure(sizeof(double) * N * J), dv.ensure(sizeof(double) * N * J);
+    HIP_TRY(hipMemcpy(dy.p, y, sizeof(double) * N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dm.p, m, sizeof(double) * N * J, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dv.p, v, sizeof(double) * N * J, hipMemcpyHostToDevice));
+    launch_log_predictive(lik_id, J, lik_param, N, num_samples, seed, dy.d(), dm.d(), dv.d(), dout.d(), nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(log_pred, dout.p, sizeof(double) * N, hipMemcpyDeviceToHost));
   });
 }
 

@@ -249,6 +249,192 @@ __device__ __forceinline__ void lik_categorical_wave(double y, const double* m, 
   }
 }
 
+// ============================================================================ predictive moments
+// `<likelihood>.predictive(m, v)`: mean and variance of y under q(f) = N(m, diag v).  One lane per row for the closed
+// forms and 1-D rules, one wave per row for the T x T (Gamma, Beta) and 10^(K-1) (Categorical) tensor rules.
+// T = 20 on a fresh reference instance, 10 when var_exp ran first on it (GPy caches the first rule, quirk Q7).
+__device__ __forceinline__ double gh_x(int T, int i) { return T == 10 ? GH10_X[i] : GH20_X[i]; }
+__device__ __forceinline__ double gh_wn(int T, int i) { return T == 10 ? GH10_WN[i] : GH20_WN[i]; }
+
+template <int LIK>
+__device__ __forceinline__ void lik_predictive(const double* m, const double* v, double param, int T, int lane, double* etab,
+                                               double* mean, double* var) {
+  if (LIK == HMOGP_LIK_GAUSSIAN) {  // gaussian.py:64-67
+    mean[0] = m[0];
+    var[0] = param * param + v[0];
+  } else if (LIK == HMOGP_LIK_HETGAUSSIAN) {  // hetgaussian.py:75-88
+    const double s1 = sqrt(2.0 * v[0]), s2 = sqrt(2.0 * v[1]);
+    double e2 = 0.0, sq = 0.0;
+    for (int i = 0; i < T; ++i) {
+      const double w = gh_wn(T, i);
+      e2 += safe_exp(gh_x(T, i) * s2 + m[1]) * w;
+      sq += safe_square(gh_x(T, i) * s1 + m[0]) * w;
+    }
+    mean[0] = m[0];
+    var[0] = e2 + sq - m[0] * m[0];
+  } else if (LIK == HMOGP_LIK_BERNOULLI || LIK == HMOGP_LIK_POISSON || LIK == HMOGP_LIK_EXPONENTIAL) {
+    const double s = sqrt(2.0 * v[0]);  // bernoulli.py:113-128, poisson.py:97-112, exponential.py:101-116
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int i = 0; i < T; ++i) {
+      const double f = gh_x(T, i) * s + m[0], w = gh_wn(T, i);
+      double mu, vr, ms;
+      if (LIK == HMOGP_LIK_BERNOULLI) {
+        const double ef = safe_exp(f);
+        const double p = clip(ef / (1.0 + ef), 1e-9, 1.0 - 1e-9);
+        mu = p, vr = p * (1.0 - p), ms = p * p;
+      } else if (LIK == HMOGP_LIK_POISSON) {
+        const double ef = safe_exp(f);
+        mu = ef, vr = ef, ms = ef * ef;
+      } else {
+        const double b = clip(safe_exp(-f), 1e-9, 1e9);
+        mu = b, vr = safe_square(b), ms = safe_square(b);
+      }
+      a0 += mu * w;
+      a1 += vr * w;
+      a2 += ms * w;
+    }
+    mean[0] = a0;
+    var[0] = a1 + a2 - a0 * a0;
+  } else if (LIK == HMOGP_LIK_GAMMA || LIK == HMOGP_LIK_BETA) {  // gamma.py:196-238, beta.py:199-241 (quirk Q1)
+    const double s1 = sqrt(2.0 * v[0]), s2 = sqrt(2.0 * v[1]);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int n = lane; n < T * T; n += 64) {
+      const int i = n / T, j = n - T * i;
+      const double w = (gh_wn(T, i) * INV_SQRT_PI) * (gh_wn(T, j) * INV_SQRT_PI);
+      const double a = clip(safe_exp(gh_x(T, i) * s1 + m[0]), 1e-9, 1e9);
+      const double b = clip(safe_exp(gh_x(T, j) * s2 + m[1]), 1e-9, 1e9);
+      double mu, vr;
+      if (LIK == HMOGP_LIK_GAMMA) {
+        mu = a / b;
+        vr = a / (b * b);
+      } else {
+        mu = a / (a + b);
+        vr = a * b / ((a + b) * (a + b) * (a + b + 1.0));
+      }
+      a0 += w * mu;
+      a1 += w * vr;
+      a2 += w * mu * mu;
+    }
+    a0 = wave_sum(a0), a1 = wave_sum(a1), a2 = wave_sum(a2);
+    mean[0] = a0;
+    var[0] = a1 + a2 - safe_square(a0);
+  } else {  // Categorical, categorical.py:84-99,224-269: E[rho_d], rho normalised over the K-1 columns; variance zeros
+    const int D = (int)param - 1;
+    for (int e = lane; e < D * 10; e += 64) {
+      const int k = e / 10, i = e - 10 * k;
+      etab[e] = safe_exp(GH10_X[i] * sqrt(2.0 * v[k]) + m[k]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    int total = 1;
+    for (int k = 0; k < D; ++k) total *= 10;
+    double acc[HMOGP_MAXJ];
+#pragma unroll
+    for (int k = 0; k < HMOGP_MAXJ; ++k) acc[k] = 0.0;
+    for (int n = lane; n < total; n += 64) {
+      double e[HMOGP_MAXJ];
+      double w = 1.0, esum = 0.0;
+      int rem = n;
+#pragma unroll
+      for (int k = HMOGP_MAXJ - 1; k >= 0; --k) {
+        if (k < D) {
+          const int i = rem % 10;
+          rem /= 10;
+          e[k] = etab[k * 10 + i];
+          w *= GH10_WN[i];
+          esum += e[k];
+        } else {
+          e[k] = 0.0;
+        }
+      }
+      double rs = 0.0;
+#pragma unroll
+      for (int k = 0; k < HMOGP_MAXJ; ++k)
+        if (k < D) {
+          e[k] = clip(e[k] / (1.0 + esum), 1e-9, 1.0 - 1e-9);
+          rs += e[k];
+        }
+#pragma unroll
+      for (int k = 0; k < HMOGP_MAXJ; ++k)
+        if (k < D) acc[k] += w * (e[k] / rs);
+    }
+#pragma unroll
+    for (int k = 0; k < HMOGP_MAXJ; ++k)
+      if (k < D) {
+        mean[k] = wave_sum(acc[k]);
+        var[k] = 0.0;
+      }
+  }
+}
+
+// ============================================================================ Monte-Carlo log predictive
+// log p(y|f) at ONE sample f of q(f), as the reference's `log_predictive` evaluates it (gaussian.py:28-34 -- sigma is
+// ignored, quirk Q6 --, bernoulli.py:31-36, hetgaussian.py:35-39, poisson.py:31-34, exponential.py:28-32,
+// categorical.py:48-63).  Gamma and Beta have no log_predictive in the reference.
+template <int LIK>
+__device__ __forceinline__ double lik_logpdf_sample(double y, double yaux, const double* f, double param) {
+  if (LIK == HMOGP_LIK_GAUSSIAN) {
+    const double d = y - f[0];
+    return -0.5 * log(2.0 * M_PI) - 0.5 * d * d;
+  } else if (LIK == HMOGP_LIK_BERNOULLI) {
+    const double ef = safe_exp(f[0]);
+    const double p = clip(ef / (1.0 + ef), 1e-9, 1.0 - 1e-9);
+    return y * log(p) + (1.0 - y) * log(1.0 - p);
+  } else if (LIK == HMOGP_LIK_HETGAUSSIAN) {
+    const double ev = safe_exp(f[1]);
+    return -0.5 * log(2.0 * M_PI) - 0.5 * f[1] - 0.5 * (safe_square(y - f[0]) / ev);
+  } else if (LIK == HMOGP_LIK_POISSON) {
+    return -safe_exp(f[0]) + y * f[0] - yaux;
+  } else if (LIK == HMOGP_LIK_EXPONENTIAL) {
+    const double b = clip(safe_exp(-f[0]), 1e-9, 1e9);
+    return -log(b) - y / b;
+  } else if (LIK == HMOGP_LIK_CATEGORICAL) {
+    const int K = (int)param, D = K - 1, label = (int)y;
+    double esum = 0.0, e[HMOGP_MAXJ];
+#pragma unroll
+    for (int k = 0; k < HMOGP_MAXJ; ++k) {
+      e[k] = (k < D) ? safe_exp(f[k]) : 0.0;
+      esum += e[k];
+    }
+    const double den = 1.0 + esum;
+    double psum = 0.0, py = 0.0;
+#pragma unroll
+    for (int k = 0; k < HMOGP_MAXJ; ++k)
+      if (k < D) {
+        const double pk = clip(e[k] / den, 1e-9, 1.0 - 1e-9);
+        psum += pk;
+        if (label == k + 1) py = pk;
+      }
+    const double pK = clip(1.0 / den, 1e-9, 1.0 - 1e-9);
+    psum += pK;
+    if (label == K) py = pK;
+    return log(py / psum);
+  }
+  return nan("");
+}
+
+// counter-based generator: two standard normals from (seed, row, sample, pair) via splitmix64 + Box-Muller
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ULL;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ void normal_pair(unsigned long long seed, long long n, int s, int pair, double& z0, double& z1) {
+  const unsigned long long h = splitmix64(splitmix64(seed ^ (unsigned long long)n * 0xD1342543DE82EF95ULL) ^
+                                          ((unsigned long long)s << 8) ^ (unsigned long long)pair);
+  const unsigned long long h2 = splitmix64(h);
+  const double u1 = ((double)(h >> 11) + 1.0) * (1.0 / 9007199254740993.0);  // (0, 1)
+  const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);         // [0, 1)
+  const double r = sqrt(-2.0 * log(u1));
+  z0 = r * cos(2.0 * M_PI * u2);
+  z1 = r * sin(2.0 * M_PI * u2);
+}
+
+// lanes per row of a likelihood's predictive rule
+__host__ __device__ constexpr int lik_pred_lanes(int lik) {
+  return (lik == HMOGP_LIK_BETA || lik == HMOGP_LIK_GAMMA || lik == HMOGP_LIK_CATEGORICAL) ? 64 : 1;
+}
+
 // lanes per row of a likelihood
 __host__ __device__ constexpr int lik_lanes(int lik) {
   return (lik == HMOGP_LIK_BETA || lik == HMOGP_LIK_CATEGORICAL) ? 64 : 1;

@@ -19,3 +19,9 @@ void launch_kzz_rows(const double* dKmm, const double* Z, int ldz, int P, const 
                      int M, double* rowout, hipStream_t s);
 void launch_qf_combine(const double* p, const double* c, long long ldn, long long N, int Q, int Df, const double* W,
                        const double* kappa, const double* var, double* m, double* v, hipStream_t s);
+// natural-gradient step of q(u)
+void launch_natgrad_prec(const double* Sqi, const double* dLdS, double gamma, double* out, int Q, int M, hipStream_t s);
+void launch_natgrad_theta1(const double* t1, const double* t2, const double* gm, double gamma, double* out, int Q, int M,
+                           hipStream_t s);
+void launch_pack_tril(const double* T, double* out, int Q, int M, double scale, hipStream_t s);
+void launch_scatter_mq(const double* v, double* out, int Q, int M, hipStream_t s);

@@ -153,7 +153,47 @@ __global__ void qf_combine_kernel(const double* __restrict__ p, const double* __
   }
 }
 
+// natural-gradient precision update: out = sym(Sqi - 2 gamma dLdS)            
+__global__ void natgrad_prec_kernel(const double* __restrict__ Sqi, const double* __restrict__ dLdS, double gamma,
+                                    double* __restrict__ out, int M) {
+  const int q = blockIdx.z, i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= M) return;
+  const long long b = (long long)q * M * M, ij = b + (long long)i * M + j, ji = b + (long long)j * M + i;
+  out[ij] = 0.5 * ((Sqi[ij] - 2.0 * gamma * dLdS[ij]) + (Sqi[ji] - 2.0 * gamma * dLdS[ji]));
+}
+// theta1[q][i] = t1[q][i] + gamma * (g_m[i*Q+q] - 2 t2[q][i])       with t1 = Sqi m, t2 = dLdS m
+__global__ void natgrad_theta1_kernel(const double* __restrict__ t1, const double* __restrict__ t2,
+                                      const double* __restrict__ gm, double gamma, double* __restrict__ out, int Q, int M) {
+  const int q = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M) out[(long long)q * M + i] = t1[(long long)q * M + i] + gamma * (gm[(long long)i * Q + q] - 2.0 * t2[(long long)q * M + i]);
+}
+// out[(r(r+1)/2 + c) * Q + q] = scale * T[q][r][c]
+__global__ void pack_tril_kernel(const double* __restrict__ T, double* __restrict__ out, int Q, int M, double scale) {
+  const int q = blockIdx.z, r = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > r || c >= M) return;
+  out[((long long)r * (r + 1) / 2 + c) * Q + q] = scale * T[((long long)q * M + r) * M + c];
+}
+// out[i*Q + q] = v[q][i]
+__global__ void scatter_mq_kernel(const double* __restrict__ v, double* __restrict__ out, int Q, int M) {
+  const int q = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M) out[(long long)i * Q + q] = v[(long long)q * M + i];
+}
+
 }  // namespace
+
+void launch_natgrad_prec(const double* Sqi, const double* dLdS, double gamma, double* out, int Q, int M, hipStream_t s) {
+  hipLaunchKernelGGL(natgrad_prec_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, Sqi, dLdS, gamma, out, M);
+}
+void launch_natgrad_theta1(const double* t1, const double* t2, const double* gm, double gamma, double* out, int Q, int M,
+                           hipStream_t s) {
+  hipLaunchKernelGGL(natgrad_theta1_kernel, dim3((M + 255) / 256, Q), dim3(256), 0, s, t1, t2, gm, gamma, out, Q, M);
+}
+void launch_pack_tril(const double* T, double* out, int Q, int M, double scale, hipStream_t s) {
+  hipLaunchKernelGGL(pack_tril_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, T, out, Q, M, scale);
+}
+void launch_scatter_mq(const double* v, double* out, int Q, int M, hipStream_t s) {
+  hipLaunchKernelGGL(scatter_mq_kernel, dim3((M + 255) / 256, Q), dim3(256), 0, s, v, out, Q, M);
+}
 
 void launch_add_diag_copy(const double* src, double* dst, int Q, int M, const double* d_jit, hipStream_t s) {
   hipLaunchKernelGGL(add_diag_copy_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, src, dst, M, d_jit);

@@ -38,6 +38,12 @@ void launch_quad(const QuadArgs& a, hipStream_t s);
 void launch_var_exp(int lik, int J, double param, long long N, const double* y, const double* m, const double* v, double* ve,
                     double* dm, double* dv, hipStream_t s);
 // K[n][m] = var * exp(-r2/2); X rows have stride ldx, Z rows stride ldz (block q of the M x Q*P inducing array)
+// predictive mean / variance of y: m, v [N][J] -> mean, var [N][Jp]; T = Gauss-Hermite order (10 or 20)
+void launch_predictive(int lik, int J, int Jp, double param, int T, long long N, const double* m, const double* v,
+                       double* mean, double* var, hipStream_t s);
+// out[n] = -log S + logsumexp_s log p(y_n | f_s), f_s ~ N(m_n, diag v_n): Monte-Carlo log predictive density per row
+void launch_log_predictive(int lik, int J, double param, long long N, int S, unsigned long long seed, const double* y,
+                           const double* m, const double* v, double* out, hipStream_t s);
 void launch_rbf(const double* X, int ldx, long long N, int P, const double* Z, int ldz, int M, double var, double ell,
                 double* K, bool same, hipStream_t s);
 void launch_rowstats(const double* Kh, const double* Pt, const double* a, const double* X, int P, const double* Z, int ldz,

@@ -334,6 +334,75 @@ __global__ __launch_bounds__(256) void var_exp_kernel(int J, double param, long 
   }
 }
 
+// ---- predictive moments of y (hmogp_predictive) ------------------------------------------------------------------
+template <int LIK>
+__global__ __launch_bounds__(256) void predictive_kernel(int J, int Jp, double param, int T, long long N,
+                                                         const double* __restrict__ m, const double* __restrict__ v,
+                                                         double* __restrict__ mean, double* __restrict__ var) {
+  constexpr int G = lik_pred_lanes(LIK);
+  __shared__ double etab[4][HMOGP_MAXJ * 10];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const long long n = ((long long)blockIdx.x * 256 + t) / G;
+  if (n >= N) return;
+  double mu[HMOGP_MAXJ], vv[HMOGP_MAXJ], om[HMOGP_MAXJ], ov[HMOGP_MAXJ];
+#pragma unroll
+  for (int j = 0; j < HMOGP_MAXJ; ++j) {
+    mu[j] = (j < J) ? m[n * J + j] : 0.0;
+    vv[j] = (j < J) ? v[n * J + j] : 0.0;
+    om[j] = ov[j] = 0.0;
+  }
+  lik_predictive<LIK>(mu, vv, param, T, lane, etab[w], om, ov);
+  if (G == 1 || lane == 0)
+    for (int j = 0; j < Jp; ++j) {
+      mean[n * Jp + j] = om[j];
+      var[n * Jp + j] = ov[j];
+    }
+}
+
+// ---- Monte-Carlo log predictive density: one wave per test row, samples strided over the lanes ------------------------
+//   out[n] = -log(S) + logsumexp_s log p(y_n | f_s),  f_s ~ N(m_n, diag v_n)       (e.g. bernoulli.py:130-144)
+template <int LIK>
+__global__ __launch_bounds__(256) void log_predictive_kernel(int J, double param, long long N, int S, unsigned long long seed,
+                                                             const double* __restrict__ y, const double* __restrict__ m,
+                                                             const double* __restrict__ v, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  double mu[HMOGP_MAXJ], sd[HMOGP_MAXJ];
+#pragma unroll
+  for (int j = 0; j < HMOGP_MAXJ; ++j) {
+    mu[j] = (j < J) ? m[n * J + j] : 0.0;
+    sd[j] = (j < J) ? sqrt(v[n * J + j]) : 0.0;
+  }
+  const double yy = y[n], yaux = (LIK == HMOGP_LIK_POISSON) ? lgamma(yy + 1.0) : 0.0;
+  double mx = -INFINITY, se = 0.0;  // running max / sum of exp(l - max)
+  for (int s = lane; s < S; s += 64) {
+    double f[HMOGP_MAXJ];
+#pragma unroll
+    for (int j = 0; j < HMOGP_MAXJ; j += 2) {
+      double z0 = 0.0, z1 = 0.0;
+      if (j < J) normal_pair(seed, n, s, j >> 1, z0, z1);
+      f[j] = mu[j] + sd[j] * z0;
+      if (j + 1 < HMOGP_MAXJ) f[j + 1] = mu[j + 1] + sd[j + 1] * z1;
+    }
+    const double l = lik_logpdf_sample<LIK>(yy, yaux, f, param);
+    if (l > mx) {
+      se = se * exp(mx - l) + 1.0;
+      mx = l;
+    } else {
+      se += exp(l - mx);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {  // combine (max, sumexp) pairs across the wave
+    const double omx = __shfl_xor(mx, o, 64), ose = __shfl_xor(se, o, 64);
+    const double nm = fmax(mx, omx);
+    se = (mx == -INFINITY ? 0.0 : se * exp(mx - nm)) + (omx == -INFINITY ? 0.0 : ose * exp(omx - nm));
+    mx = nm;
+  }
+  if (lane == 0) out[n] = -log((double)S) + mx + log(se);
+}
+
 }  // namespace
 
 // =============================================================================================== launchers
@@ -395,6 +464,42 @@ void launch_var_exp(int lik, int J, double param, long long N, const double* y, 
     default: throw HipError{hipErrorInvalidValue, "unknown likelihood id", __FILE__, __LINE__};
   }
 #undef VK
+}
+
+void launch_predictive(int lik, int J, int Jp, double param, int T, long long N, const double* m, const double* v,
+                       double* mean, double* var, hipStream_t s) {
+  if (N <= 0) return;
+  dim3 grid((unsigned)((N * lik_pred_lanes(lik) + 255) / 256));
+#define PK(L) hipLaunchKernelGGL((predictive_kernel<L>), grid, dim3(256), 0, s, J, Jp, param, T, N, m, v, mean, var)
+  switch (lik) {
+    case HMOGP_LIK_GAUSSIAN: PK(HMOGP_LIK_GAUSSIAN); break;
+    case HMOGP_LIK_BERNOULLI: PK(HMOGP_LIK_BERNOULLI); break;
+    case HMOGP_LIK_HETGAUSSIAN: PK(HMOGP_LIK_HETGAUSSIAN); break;
+    case HMOGP_LIK_CATEGORICAL: PK(HMOGP_LIK_CATEGORICAL); break;
+    case HMOGP_LIK_POISSON: PK(HMOGP_LIK_POISSON); break;
+    case HMOGP_LIK_EXPONENTIAL: PK(HMOGP_LIK_EXPONENTIAL); break;
+    case HMOGP_LIK_GAMMA: PK(HMOGP_LIK_GAMMA); break;
+    case HMOGP_LIK_BETA: PK(HMOGP_LIK_BETA); break;
+    default: throw HipError{hipErrorInvalidValue, "unknown likelihood id", __FILE__, __LINE__};
+  }
+#undef PK
+}
+
+void launch_log_predictive(int lik, int J, double param, long long N, int S, unsigned long long seed, const double* y,
+                           const double* m, const double* v, double* out, hipStream_t s) {
+  if (N <= 0) return;
+  dim3 grid((unsigned)((N + 3) / 4));
+#define LK(L) hipLaunchKernelGGL((log_predictive_kernel<L>), grid, dim3(256), 0, s, J, param, N, S, seed, y, m, v, out)
+  switch (lik) {
+    case HMOGP_LIK_GAUSSIAN: LK(HMOGP_LIK_GAUSSIAN); break;
+    case HMOGP_LIK_BERNOULLI: LK(HMOGP_LIK_BERNOULLI); break;
+    case HMOGP_LIK_HETGAUSSIAN: LK(HMOGP_LIK_HETGAUSSIAN); break;
+    case HMOGP_LIK_CATEGORICAL: LK(HMOGP_LIK_CATEGORICAL); break;
+    case HMOGP_LIK_POISSON: LK(HMOGP_LIK_POISSON); break;
+    case HMOGP_LIK_EXPONENTIAL: LK(HMOGP_LIK_EXPONENTIAL); break;
+    default: throw HipError{hipErrorInvalidValue, "the reference defines no log_predictive for this likelihood", __FILE__, __LINE__};
+  }
+#undef LK
 }
 
 void launch_colstats(const double* Kh, const double* Pt, const double* a, const double* alpha, const double* alpha0,

@@ -184,6 +184,13 @@ class Engine(object):
         check(lib.hmogp_posterior_u(self._h, _p(wv), _p(wi)), self._h)
         return wv, wi
 
+    def natgrad_step(self, gamma=1.0):
+        """Natural-gradient update of q(u) from the last evaluation's gradients: returns (m_u_new, L_flat_new)."""
+        m = np.zeros((self.M, self.Q))
+        L = np.zeros((self.Mtri, self.Q))
+        check(lib.hmogp_natgrad_step(self._h, float(gamma), _p(m), _p(L)), self._h)
+        return m, L
+
     def predict_f(self, Xnew):
         Xnew = _f64(Xnew).reshape(-1, self.P)
         m = np.zeros((Xnew.shape[0], self.Df))
@@ -246,3 +253,26 @@ def var_exp(name, y, m, v, device=0, **kw):
     check(lib.hmogp_var_exp(device, LIK_IDS[name], lik_param(name, **kw), y.shape[0], _p(y), _p(m), _p(v), _p(ve), _p(dm),
                             _p(dv)))
     return ve, dm, dv
+
+
+def predictive(name, m, v, gh_T=0, device=0, **kw):
+    """`<likelihood>.predictive(m, v)`: predictive mean / variance of y (N, dim_p)."""
+    m, v = _f64(m), _f64(v)
+    J = lik_dim_f(name, **kw)
+    m, v = m.reshape(-1, J), v.reshape(-1, J)
+    Jp = J if name == "Categorical" else 1
+    mean, var = np.zeros((m.shape[0], Jp)), np.zeros((m.shape[0], Jp))
+    check(lib.hmogp_predictive(device, LIK_IDS[name], lik_param(name, **kw), int(gh_T), m.shape[0], _p(m), _p(v), _p(mean),
+                               _p(var)))
+    return mean, var
+
+
+def log_predictive_rows(name, y, m, v, num_samples=1000, seed=0, device=0, **kw):
+    """Per-row Monte-Carlo log predictive density: -log S + logsumexp_s log p(y_n | f_s), f_s ~ N(m_n, diag v_n)."""
+    y, m, v = _f64(y).reshape(-1), _f64(m), _f64(v)
+    J = lik_dim_f(name, **kw)
+    m, v = m.reshape(-1, J), v.reshape(-1, J)
+    out = np.zeros(y.shape[0])
+    check(lib.hmogp_log_predictive(device, LIK_IDS[name], lik_param(name, **kw), y.shape[0], int(num_samples), int(seed),
+                                   _p(y), _p(m), _p(v), _p(out)))
+    return out

@@ -29,6 +29,18 @@ class _Lik(object):
         _, dm, dv = var_exp(self.name, Y, m, v, **self.kwargs())
         return dm, dv
 
+    def log_predictive(self, Ytest, mu_F_star, v_F_star, num_samples, seed=0):
+        """The reference's Monte-Carlo log predictive, including its 1/num_samples factor on the sum over test points
+        (e.g. bernoulli.py:130-144).  Sampling happens on the device."""
+        from .engine import log_predictive_rows
+        lp = log_predictive_rows(self.name, Ytest, mu_F_star, v_F_star, num_samples, seed, **self.kwargs())
+        return (1.0 / num_samples) * lp.sum()
+
+    def predictive(self, m, v, gh_points=None, Y_metadata=None):
+        """Predictive mean / variance of y (the reference's `predictive`; Gauss-Hermite order of a fresh instance)."""
+        from .engine import predictive
+        return predictive(self.name, m, v, **self.kwargs())
+
 
 class Gaussian(_Lik):
     name = "Gaussian"
@@ -128,6 +140,18 @@ class HetLikelihood(object):
 
     def var_exp(self, Y, mu_F, v_F, Y_metadata):
         return [l.var_exp(Y[t], mu_F[t], v_F[t]) for t, l in enumerate(self.likelihoods_list)]
+
+    def predictive(self, mu_F_pred, v_F_pred, Y_metadata):
+        """het_likelihood.py:133-148."""
+        out = [l.predictive(mu_F_pred[t], v_F_pred[t]) for t, l in enumerate(self.likelihoods_list)]
+        return [o[0] for o in out], [o[1] for o in out]
+
+    def negative_log_predictive(self, Ytest, mu_F_star, v_F_star, Y_metadata, num_samples, seed=0):
+        """het_likelihood.py:150-164."""
+        logpred = 0.0
+        for t, l in enumerate(self.likelihoods_list):
+            logpred += l.log_predictive(Ytest[t], mu_F_star[t], v_F_star[t], num_samples, seed=seed + t)
+        return -logpred
 
     def var_exp_derivatives(self, Y, mu_F, v_F, Y_metadata):
         out = [l.var_exp_derivatives(Y[t], mu_F[t], v_F[t]) for t, l in enumerate(self.likelihoods_list)]

@@ -267,6 +267,39 @@ class SVMOGP(object):
         """q(f_d) at Xnew for every function d: (mean [N, Df], variance [N, Df])."""
         return self._engine.predict_f(np.asarray(Xnew, dtype=float).reshape(-1, self.Xdim))
 
+    def predictive(self, Xpred):
+        """svmogp.py:333-351: predictive mean / variance of every output at Xpred[t].  The reference routes q(f) through
+        `_raw_predict_f` (an O(N^3) regression on q(f) at ALL training inputs, svmogp.py:255-278); here q(f_d)(Xpred) comes
+        straight from q(u) (`calculate_q_f` at the new inputs, the `predictive_new` semantics) on the device."""
+        m_F, v_F = [], []
+        for t, lik in enumerate(self.likelihood.likelihoods_list):
+            m, v = self.predict_f(Xpred[t])
+            cols = [d for d in range(self.num_output_funcs) if self.Y_metadata["function_index"].flatten()[d] == t]
+            m_F.append(m[:, cols])
+            v_F.append(np.abs(v[:, cols]))
+        return self.likelihood.predictive(m_F, v_F, self.Y_metadata)
+
+    def natural_gradient_step(self, gamma=1.0):
+        """q(u) <- natural-gradient step of size gamma (not in the reference; named in the north-star).  Uses the
+        gradients of the last `parameters_changed()`; updates q_u_means / q_u_chols and re-evaluates."""
+        m, L = self._engine.natgrad_step(gamma)
+        self.q_u_means[...] = m
+        self.q_u_chols[...] = L
+        self.parameters_changed()
+        return self
+
+    def negative_log_predictive(self, Xtest, Ytest, num_samples=1000, seed=0):
+        """svmogp.py:353-370 (q(f) at the test inputs from `predict_f`, see `predictive`)."""
+        f_index = self.Y_metadata["function_index"].flatten()
+        mu, vv = [], []
+        for t in range(len(self.Ymulti_all)):
+            m, v = self.predict_f(Xtest[t])
+            cols = [d for d in range(self.num_output_funcs) if f_index[d] == t]
+            mu.append(m[:, cols])
+            vv.append(np.abs(v[:, cols]))
+        return self.likelihood.negative_log_predictive(Ytest, mu, vv, Y_metadata=self.Y_metadata, num_samples=num_samples,
+                                                       seed=seed)
+
     def timings(self):
         return self._engine.timings()
 

@@ -154,6 +154,13 @@ int hmogp_posterior_u(hmogp_handle h, double* woodbury_vector, double* woodbury_
  * before the abs; svmogp_inf.py:186-225 with X := Xnew), using the parameters of the last evaluation.   */
 int hmogp_predict_f(hmogp_handle h, const double* Xnew, int64_t Nnew, double* m, double* v);
 
+/* ---- natural-gradient update of q(u) (named in the north-star; the reference has no such step) ---------- */
+/* From the gradients of the LAST finished evaluation (its group_mask must include HMOGP_GROUP_QU):
+ *   S_q^-1 <- S_q^-1 - 2 gamma dL/dS_q ;  S_q^-1 m_q <- S_q^-1 m_q + gamma (dL/dm_q - 2 dL/dS_q m_q)
+ * returns the new m_u [M, Q] and L_flat [M(M+1)/2, Q] (Cholesky of the new S_q, GPy packing).  HMOGP_E_NOT_PD if
+ * the step leaves the positive-definite cone.  Invalidates posterior_u / predict_f until the next evaluation.   */
+int hmogp_natgrad_step(hmogp_handle h, double gamma, double* m_u_new, double* L_flat_new);
+
 /* ---- timing --------------------------------------------------------------------------------------- */
 /* Milliseconds the kernels of the last evaluation spent, measured with HIP events on the engine's stream:
  * out[0] whole evaluation, [1] K_uf construction (rbf_cross_cov), [2] forward N x M x M products,
@@ -177,6 +184,22 @@ int hmogp_gemm_f64(int32_t device, int32_t transA, int32_t transB, int32_t M, in
 /* Variational expectations of one likelihood: y [N], m,v [N, dim_f] -> ve [N], dm, dv [N, dim_f].         */
 int hmogp_var_exp(int32_t device, int32_t lik_id, double lik_param, int64_t N, const double* y,
                   const double* m, const double* v, double* ve, double* dm, double* dv);
+
+/* Predictive mean / variance of y under q(f) = N(m, diag v): the reference's `<likelihood>.predictive(m, v)`
+ * (e.g. bernoulli.py:113-128, gamma.py:196-238, categorical.py:224-269), consumed by HetLikelihood.predictive
+ * (het_likelihood.py:133-148).  m, v [N, dim_f] -> mean, var [N, dim_p] (dim_p = K-1 for Categorical, else 1).
+ * gh_T: Gauss-Hermite order, 20 (fresh reference instance), 10 (instance whose var_exp ran first: GPy caches the
+ * first rule), 0 = the reference's default for a fresh instance.                                              */
+int hmogp_predictive(int32_t device, int32_t lik_id, double lik_param, int32_t gh_T, int64_t N, const double* m,
+                     const double* v, double* mean, double* var);
+
+/* Monte-Carlo log predictive density per test row (the inner part of `<likelihood>.log_predictive`, e.g.
+ * bernoulli.py:130-144): log_pred[n] = -log(S) + logsumexp_s log p(y_n | f_s), f_s ~ N(m_n, diag v_n), S = num_samples,
+ * counter-based generator seeded by `seed` (reproducible; a different stream than NumPy's).  The reference then returns
+ * (1/S) * sum_n log_pred[n] and HetLikelihood.negative_log_predictive (het_likelihood.py:150-164) negates the sum over
+ * tasks -- done by the caller.  Defined for Gaussian, Bernoulli, HetGaussian, Poisson, Exponential, Categorical.   */
+int hmogp_log_predictive(int32_t device, int32_t lik_id, double lik_param, int64_t N, int32_t num_samples, uint64_t seed,
+                         const double* y, const double* m, const double* v, double* log_pred);
 
 /* Micro-benchmark of the two row-pass contractions on synthetic operands resident in HBM (tools/bench_gemm.py):
  * role 1: forward  P~[n,M] = K^[n,M] C[M,M];  role 2: weighted Gram  H[M,M] (lower tiles) = K^T diag(beta) K^ incl. the

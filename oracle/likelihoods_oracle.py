@@ -209,3 +209,63 @@ def var_exp_all(name, y, m, v, **kw):
         return categorical(y, m, v, kw["K"])
     return dict(Bernoulli=bernoulli, HetGaussian=hetgaussian, Poisson=poisson, Exponential=exponential, Gamma=gamma,
                 Beta=beta)[name](y, m, v)
+
+
+# ============================================================================ predictive
+def predictive(name, m, v, gh_T=None, **kw):
+    """`<likelihood>.predictive(m, v)` of the reference: predictive mean and variance of y under q(f) = N(m, diag v).
+    Returns (mean_pred (N, dim_p), var_pred (N, dim_p)).  gh_T = Gauss-Hermite order the instance would use: 20 on a
+    fresh instance, 10 for Gamma/Beta whose var_exp ran first (quirk Q7); Categorical always 10.
+    References: gaussian.py:64-67, bernoulli.py:113-128, hetgaussian.py:75-88, poisson.py:97-112, exponential.py:101-116,
+    gamma.py:196-238, beta.py:199-241 (both 1/pi-scaled, quirk Q1), categorical.py:224-269 (variance 'NOT IMPLEMENTED')."""
+    N = m.shape[0]
+    if name == "Gaussian":
+        s = kw.get("sigma", 0.5)
+        s = 0.5 if s is None else s
+        return m.reshape(N, 1).copy(), s * s + v.reshape(N, 1)
+    if name == "HetGaussian":
+        x, w = gh_rule(gh_T or 20)
+        f1 = x[None, :] * np.sqrt(2.0 * v[:, 0, None]) + m[:, 0, None]
+        f2 = x[None, :] * np.sqrt(2.0 * v[:, 1, None]) + m[:, 1, None]
+        return m[:, :1].copy(), (safe_exp(f2) @ w + safe_square(f1) @ w - np.square(m[:, 0]))[:, None]
+    if name in ("Bernoulli", "Poisson", "Exponential"):
+        x, w = gh_rule(gh_T or 20)
+        f = x[None, :] * np.sqrt(2.0 * v.reshape(-1)[:, None]) + m.reshape(-1)[:, None]
+        if name == "Bernoulli":
+            ef = safe_exp(f)
+            p = np.clip(ef / (1 + ef), 1e-9, 1 - 1e-9)
+            mean, var, msq = p, p * (1 - p), np.square(p)
+        elif name == "Poisson":
+            ef = safe_exp(f)
+            mean, var, msq = ef, ef, np.square(ef)
+        else:
+            b = np.clip(safe_exp(-f), 1e-9, 1e9)
+            mean, var, msq = b, safe_square(b), safe_square(b)
+        mp = mean @ w
+        return mp[:, None], (var @ w + msq @ w - np.square(mp))[:, None]
+    if name in ("Gamma", "Beta"):
+        f1, f2, w = _grid2(m, v, gh_T or 20)
+        a = np.clip(safe_exp(f1), 1e-9, 1e9) + 0 * f2
+        b = np.clip(safe_exp(f2), 1e-9, 1e9) + 0 * f1
+        if name == "Gamma":
+            mean, var = a / b, a / b ** 2
+        else:
+            mean, var = a / (a + b), a * b / ((a + b) ** 2 * (a + b + 1))
+        c2 = lambda g: (g @ w) @ w / np.square(_SQRT_PI)
+        mp = c2(mean)
+        return mp[:, None], (c2(var) + c2(np.square(mean)) - safe_square(mp))[:, None]
+    if name == "Categorical":
+        K = kw["K"]
+        D = K - 1
+        x, w = gh_rule(10)
+        Wt = w
+        for _ in range(D - 1):
+            Wt = np.multiply.outer(Wt, w)
+        Wf = Wt.reshape(-1)
+        grids = np.stack(np.meshgrid(*[x] * D, indexing="ij"), -1).reshape(-1, D)
+        F = grids[None, :, :] * np.sqrt(2.0 * v[:, None, :]) + m[:, None, :]
+        eF = safe_exp(F)
+        rho = np.clip(eF / (1.0 + eF.sum(-1, keepdims=True)), 1e-9, 1 - 1e-9)
+        rho = rho / rho.sum(-1, keepdims=True)                      # normalised over the K-1 columns (categorical.py:89-91)
+        return np.einsum("ngd,g->nd", rho, Wf), np.zeros((N, D))
+    raise ValueError(name)

@@ -10,6 +10,7 @@ Fixture families:
   lik_<name>.npz    G1  per-likelihood var_exp / var_exp_derivatives          (likelihoods/*.py)
   cov_<case>.npz    G2  Kuu, Luu (jitchol), Kuui, ladder rung                  (util.py:181-200)
   inf_<case>.npz    G3/G4/G5  q(f_d), KL, ELBO and the raw gradient dict        (svmogp_inf.py:23-250)
+  pred_<name>.npz   f2  per-likelihood predictive mean / variance                 (likelihoods/*.py `predictive`)
   model_<case>.npz  G6  assembled parameter gradients from the reference's own
                         SVMOGP.parameters_changed (svmogp.py:85-166) run over the stand-in's
                         RESTATED GPy RBF gradient formulas ("GPy-unpinned").
@@ -103,6 +104,36 @@ def gen_likelihoods(liks):
                             var_exp=np.asarray(ve).reshape(n, 1), var_exp_dm=np.asarray(dm).reshape(n, df),
                             var_exp_dv=np.asarray(dv).reshape(n, df))
         print("lik", tag, float(np.sum(ve)))
+
+
+def gen_predictive(liks):
+    """f2: `<likelihood>.predictive(m, v)` (predictive mean / variance of y).  `gh_T` records the Gauss-Hermite order
+    the instance used: 20 on a fresh instance, 10 when `var_exp` ran first on it (GPy caches the first rule, quirk Q7)."""
+    cases = [("Gaussian", {"sigma": 0.5}, False), ("Bernoulli", {}, False), ("HetGaussian", {}, False), ("Poisson", {}, False),
+             ("Exponential", {}, False), ("Gamma", {}, False), ("Gamma", {}, True), ("Beta", {}, False), ("Beta", {}, True),
+             ("Categorical", {"K": 3}, False), ("Categorical", {"K": 4}, False)]
+    for k, (name, kw, cached) in enumerate(cases):
+        rng = np.random.RandomState(500 + k)
+        n = 48
+        spec = (name, kw)
+        df = dim_f(spec)
+        m = rng.uniform(-2, 2, size=(n, df))
+        v = np.exp(rng.uniform(np.log(1e-3), np.log(2.0), size=(n, df)))
+        m[0, :], v[0, :] = 6.0, 4.0
+        m[1, :], v[1, :] = -6.0, 1e-6
+        lik = make_lik(liks, spec)
+        gh_T = 10 if name == "Categorical" else 20
+        if cached:
+            lik.var_exp(sample_y(rng, spec, n), m, v)
+            gh_T = 10
+        if name == "Gaussian":
+            mp, vp = lik.predictive(m, v, None)
+        else:
+            mp, vp = lik.predictive(m, v)
+        tag = name.lower() + ("_K%d" % kw["K"] if "K" in kw else "") + ("_cached10" if cached else "")
+        np.savez_compressed(os.path.join(OUT, "pred_%s.npz" % tag), spec=json.dumps(spec), m=m, v=v, gh_T=gh_T,
+                            mean_pred=np.asarray(mp).reshape(n, -1), var_pred=np.asarray(vp).reshape(n, -1))
+        print("pred", tag, float(np.sum(mp)), float(np.sum(vp)))
 
 
 # --------------------------------------------------------------------------- G2
@@ -303,6 +334,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     stand, inf, util, hl, svmogp, liks = _import_reference()
     gen_likelihoods(liks)
+    gen_predictive(liks)
     gen_cov(stand, util)
     gen_inference(stand, inf, util, hl, liks)
     gen_model(stand, util, hl, svmogp, liks)

@@ -1,0 +1,99 @@
+"""GPU: the device-side plumbing of the one exchange step -- the engine's statistic bundle aliased as a torch tensor
+(no copy) and reduced by RCCL -- on the single GPU that is available (world_size 1), plus a 2-process gloo run on the
+same GPU that drives the real engine through the host-staged reducer."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _case():
+    from hetmogp_amd.synthetic import make_case
+    specs = [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {}), ("Poisson", {}), ("Gamma", {})]
+    prm, X, Y = make_case(specs, [3000, 2000, 2500, 1500], M=64, Q=3, P=1, seed=3)
+    return specs, prm, X, Y
+
+
+def test_bundle_aliases_as_torch_tensor_and_rccl_allreduce():
+    import torch
+    import torch.distributed as dist
+    from hetmogp_amd.engine import Engine
+    from hetmogp_amd import dist as hd
+    specs, prm, X, Y = _case()
+    e = Engine(specs, 3, 64, 1)
+    e.set_data(X, Y)
+    full = e.elbo_grad(**prm)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        red = hd.StatsReducer(e, device=0)
+        assert red.mode == "device" and red.tensor.is_cuda and red.tensor.dtype == torch.float64
+        e.step_begin(**prm)
+        host = e.stats_read()
+        assert np.array_equal(red.tensor.cpu().numpy(), host)            # same memory, no copy
+        dist.all_reduce(red.tensor)                                      # RCCL on engine-owned HBM (sum over 1 rank)
+        torch.cuda.synchronize()
+        assert np.array_equal(e.stats_read(), host)
+        out = hd.sharded_elbo_grad(e, red, 0, 1, **prm)
+        for k in ("elbo", "g_m_u", "g_L_u", "g_Z", "g_W"):
+            assert np.array_equal(np.asarray(out[k]), np.asarray(full[k])), k   # deterministic reductions: bit-identical
+    finally:
+        dist.destroy_process_group()
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from hetmogp_amd.engine import Engine
+    from hetmogp_amd import dist as hd
+    from test_dist_gpu import _case
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    specs, prm, X, Y = _case()
+    e = Engine(specs, 3, 64, 1, device=0)                 # both ranks share the one GPU of the box
+    e.set_data(X, Y)
+    red = hd.StatsReducer(e, device=0)
+    assert red.mode == "host"
+    out = hd.sharded_elbo_grad(e, red, rank, world, **prm)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, out["elbo"], out["g_Z"], out["g_L_u"]))
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_row_sharded_match_single_rank():
+    import torch.multiprocessing as mp
+    from hetmogp_amd.engine import Engine
+    specs, prm, X, Y = _case()
+    e = Engine(specs, 3, 64, 1)
+    e.set_data(X, Y)
+    full = e.elbo_grad(**prm)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, elbo, gZ, gL in res:
+        assert abs(elbo - full["elbo"]) < 1e-10 * abs(full["elbo"])
+        assert np.max(np.abs(gZ - full["g_Z"])) < 1e-9 * np.max(np.abs(full["g_Z"]))
+        assert np.max(np.abs(gL - full["g_L_u"])) < 1e-9 * np.max(np.abs(full["g_L_u"]))
+    assert res[0][1] == res[1][1]                          # replicated finish: identical on every rank

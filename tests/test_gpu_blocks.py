@@ -117,3 +117,60 @@ def test_var_exp_large_random_vs_oracle(E):
         want = lo.var_exp_all(name, y[:, None], m, v, **kw)
         for a, b in zip(got, want):
             np.testing.assert_allclose(a, b.reshape(a.shape), rtol=1e-9, atol=1e-11 * np.max(np.abs(b)))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "pred_*.npz"))), ids=os.path.basename)
+def test_predictive_golden(E, path):
+    """f2: predictive mean / variance of y against the reference's own `<likelihood>.predictive` outputs."""
+    g = np.load(path)
+    name, kw = json.loads(str(g["spec"]))
+    mp, vp = E.predictive(name, g["m"], g["v"], gh_T=int(g["gh_T"]), **kw)
+    np.testing.assert_allclose(mp, g["mean_pred"], rtol=1e-10, atol=1e-13 * np.max(np.abs(g["mean_pred"])))
+    np.testing.assert_allclose(vp, g["var_pred"], rtol=1e-8, atol=1e-12 * max(1.0, np.max(np.abs(g["var_pred"]))))
+
+
+def test_log_predictive_monte_carlo_vs_quadrature(E):
+    """f4: the Monte-Carlo log predictive is stochastic (own counter-based generator), so it is checked statistically:
+    for 1-D likelihoods log E_q[p(y|f)] is also a Gauss-Hermite integral (T = 20, the oracle), and the MC estimate with
+    S = 16384 samples must agree per row within 0.05 nats and within 0.01 on average; HetGaussian / Categorical are
+    checked against NumPy Monte-Carlo with the same number of samples."""
+    from oracle import likelihoods_oracle as lo
+    rng = np.random.RandomState(9)
+    n = 64
+    x, w = lo.gh_rule(20)
+    for name, y in (("Gaussian", rng.randn(n)), ("Bernoulli", (rng.rand(n) < 0.5).astype(float)),
+                    ("Poisson", rng.poisson(3.0, n).astype(float)), ("Exponential", rng.gamma(2.0, 1.0, n))):
+        m, v = rng.uniform(-1, 1, (n, 1)), np.exp(rng.uniform(-3, 0, (n, 1)))
+        f = x[None, :] * np.sqrt(2 * v) + m
+        if name == "Gaussian":
+            lp = -0.5 * np.log(2 * np.pi) - 0.5 * (y[:, None] - f) ** 2          # sigma ignored (quirk Q6)
+        elif name == "Bernoulli":
+            p = np.clip(1 / (1 + np.exp(-f)), 1e-9, 1 - 1e-9)
+            lp = y[:, None] * np.log(p) + (1 - y[:, None]) * np.log(1 - p)
+        elif name == "Poisson":
+            from scipy.special import gammaln
+            lp = -np.exp(f) + y[:, None] * f - gammaln(y[:, None] + 1)
+        else:
+            b = np.clip(np.exp(-f), 1e-9, 1e9)
+            lp = -np.log(b) - y[:, None] / b
+        want = np.log(np.exp(lp) @ w)
+        got = E.log_predictive_rows(name, y, m, v, num_samples=16384, seed=123)
+        assert np.max(np.abs(got - want)) < 0.05 and abs(np.mean(got - want)) < 0.01, name
+        assert np.array_equal(got, E.log_predictive_rows(name, y, m, v, num_samples=16384, seed=123))   # reproducible
+    # multi-function likelihoods: NumPy Monte-Carlo
+    S = 16384
+    for name, kw, J in (("HetGaussian", {}, 2), ("Categorical", {"K": 4}, 3)):
+        m, v = rng.uniform(-1, 1, (n, J)), np.exp(rng.uniform(-3, 0, (n, J)))
+        y = rng.randn(n) if name == "HetGaussian" else rng.randint(1, 5, n).astype(float)
+        F = m[:, :, None] + np.sqrt(v)[:, :, None] * rng.randn(n, J, S)
+        if name == "HetGaussian":
+            lp = -0.5 * np.log(2 * np.pi) - 0.5 * F[:, 1] - 0.5 * (y[:, None] - F[:, 0]) ** 2 / np.exp(F[:, 1])
+        else:
+            e = np.exp(F)
+            den = 1 + e.sum(1, keepdims=True)
+            p = np.clip(np.concatenate([e / den, 1 / den], 1), 1e-9, 1 - 1e-9)
+            p = p / p.sum(1, keepdims=True)
+            lp = np.log(p[np.arange(n), (y - 1).astype(int)])
+        want = np.log(np.mean(np.exp(lp), 1))
+        got = E.log_predictive_rows(name, y, m, v, num_samples=S, seed=7, **kw)
+        assert np.max(np.abs(got - want)) < 0.1 and abs(np.mean(got - want)) < 0.02, name

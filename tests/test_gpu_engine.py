@@ -250,3 +250,48 @@ def test_headline_size_properties():
     both = e.step_finish()
     for k in KEYS:
         assert rel(both[k], full[k]) < 1e-9, k
+
+
+def test_natural_gradient_step():
+    """f3 (no reference oracle: property tests).  With Gaussian likelihoods and ONE latent GP the model is conjugate: one
+    natural-gradient step of size 1 lands on the optimum of q(u) (gradients vanish) -- with Q > 1 the factors q(u_q) are
+    coupled through the mixing and a simultaneous step is only a Jacobi sweep.  The device update equals the same formulas
+    in NumPy from the exported dL/dm, dL/dS; small steps increase the ELBO for non-conjugate likelihoods."""
+    from oracle import svmogp_oracle as so
+    specs = [("Gaussian", {"sigma": 0.5}), ("Gaussian", {"sigma": 1.0})]
+    prm, prob, X, Y = synth(21, specs, [400, 300], 24, 1, 1, (1.0,))
+    e = make_engine(prob, X, Y)
+    args = dict(Z=prm["Z"], m_u=prm["m_u"], L_flat=prm["L_flat"], variance=prm["variance"], lengthscale=prm["lengthscale"],
+                W=prm["W"], kappa=prm["kappa"])
+    out0 = e.elbo_grad(want_dL_dS=True, **args)
+    m1, L1 = e.natgrad_step(1.0)
+    # NumPy restatement of the update from the exported gradients
+    M, Q = 24, 1
+    for q in range(Q):
+        L = so.flat_to_tril(prm["L_flat"][:, q], M)
+        Si = np.linalg.inv(L @ L.T)
+        dS = 0.5 * (out0["dL_dS"][q] + out0["dL_dS"][q].T)
+        Lam = Si - 2.0 * dS
+        th1 = Si @ prm["m_u"][:, q] + (out0["g_m_u"][:, q] - 2.0 * dS @ prm["m_u"][:, q])
+        Snew = np.linalg.inv(Lam)
+        assert rel(m1[:, q], Snew @ th1) < 1e-8
+        Ln = so.flat_to_tril(L1[:, q], M)
+        assert rel(Ln @ Ln.T, Snew) < 1e-8
+    a1 = dict(args, m_u=m1, L_flat=L1)
+    out1 = e.elbo_grad(**a1)
+    assert out1["elbo"] > out0["elbo"]
+    scale = max(np.max(np.abs(out0["g_m_u"])), np.max(np.abs(out0["g_L_u"])))
+    assert np.max(np.abs(out1["g_m_u"])) < 1e-7 * scale and np.max(np.abs(out1["g_L_u"])) < 1e-7 * scale
+    # non-conjugate likelihood, small step: monotone
+    specs2 = [("Bernoulli", {}), ("Poisson", {})]
+    prm2, prob2, X2, Y2 = synth(22, specs2, [400, 300], 24, 2, 1, (1.0, 1.3))
+    e2 = make_engine(prob2, X2, Y2)
+    a2 = dict(Z=prm2["Z"], m_u=prm2["m_u"], L_flat=prm2["L_flat"], variance=prm2["variance"],
+              lengthscale=prm2["lengthscale"], W=prm2["W"], kappa=prm2["kappa"])
+    prev = e2.elbo_grad(**a2)["elbo"]
+    for _ in range(3):
+        m_new, L_new = e2.natgrad_step(0.1)
+        a2 = dict(a2, m_u=m_new, L_flat=L_new)
+        cur = e2.elbo_grad(**a2)["elbo"]
+        assert cur > prev
+        prev = cur
