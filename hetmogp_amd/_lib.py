@@ -17,6 +17,7 @@ LIK_IDS_BY_NAME = dict(Gaussian=0, Bernoulli=1, HetGaussian=2, Categorical=3, Po
 E_INVALID, E_NO_DEVICE, E_NOT_PD, E_SQI_UNSTABLE, E_STATE = -1, -2, -3, -4, -5
 FLAG_V_NEGATIVE = 1
 GROUP_QU, GROUP_HYPER, GROUP_Z, GROUP_ALL = 1, 2, 4, 7
+CFG_EXACT_ZERO_WINDOWS = 1
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -27,7 +28,7 @@ c_uint32_p = C.POINTER(C.c_uint32)
 class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("T", C.c_int32), ("Q", C.c_int32), ("M", C.c_int32), ("P", C.c_int32),
                 ("Df", C.c_int32), ("lik_id", c_int32_p), ("lik_param", c_double_p), ("f_index", c_int32_p),
-                ("d_index", c_int32_p), ("device", C.c_int32), ("chunk_rows", C.c_int64)]
+                ("d_index", c_int32_p), ("device", C.c_int32), ("chunk_rows", C.c_int64), ("flags", C.c_uint32)]
 
 
 class Params(C.Structure):

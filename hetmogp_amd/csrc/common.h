@@ -69,7 +69,28 @@ struct GemmArgs {
   int a_kmajor = 0, b_kmajor = 1;
   int lower_only = 0;
   int role = 0;  // 0 generic, 1 forward contraction, 2 weighted Gram (names the kernel instantiation for profiles)
+  // role 1 only -- row statistics fused into the epilogue while the P~ tile is still in registers (replaces a separate
+  // pass over K^ and P~):  for every row n of the tile and this block's 128 columns j
+  //   p += K^_nj a_j,  c += P~_nj K^_nj,  pt += K^_nj a_j r2_nj,  ct += P~_nj K^_nj r2_nj      (r2 = |x_n - z_j|^2 / l^2)
+  // written as per-column-tile partials fs_part[stat][tile_col][n]; launch_combine_parts sums the column tiles.
+  double* fs_part = nullptr;
+  const double* fs_a = nullptr;  // [N]      a = Kuu^-1 m
+  const double* fs_x = nullptr;  // [M][P]   inputs of the rows
+  const double* fs_z = nullptr;  // inducing inputs of this latent, row stride fs_ldz
+  int fs_ldz = 0, fs_P = 1, fs_hyper = 0;
+  double fs_ell = 1.0;
+  int store_c = 1;               // 0: do not write P~ at all (no consumer when the Z gradient is not requested)
+  // Exact-zero windows (rowpass.hip: launch_windows): K^ = s2 exp(-r2/2) underflows to exactly 0.0 beyond r ~ 38.6
+  // lengthscales, so for spatially sorted rows it is banded.  role 1: win[2*ti], win[2*ti+1] = [lo, hi) column range
+  // (multiples of 16) outside which every entry of row tile ti is exactly zero -> column tiles outside it are skipped
+  // and the K loop runs over the range only.  role 2: win[2*b], win[2*b+1] = [lo, hi) row range outside which column
+  // block b is exactly zero -> the K loop of tile (i,j) runs over the intersection.  Skipped terms are products with
+  // exact zeros, so results are unchanged.  nullptr = dense.
+  const int* win = nullptr;
 };
+// p[n] = sum_t part[0][t][n], c <- part[1], pt <- part[2], ct <- part[3]   (pt/ct may be nullptr)
+void launch_combine_parts(const double* part, int tiles, long long n, double* p, double* c, double* pt, double* ct,
+                          hipStream_t s);
 void launch_gemm_f64(const GemmArgs& g, hipStream_t stream);
 
 // ---- linear algebra on Q x M x M batches (linalg.hip) ---------------------------------------------------

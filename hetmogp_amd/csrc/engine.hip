@@ -141,6 +141,7 @@ void jitchol_batched(const double* Kuu, double* Luu, int Q, int M, const double*
 struct hmogp_engine {
   int T = 0, Q = 0, M = 0, P = 0, Df = 0, device = 0;
   long long chunk = 262144;
+  bool use_windows = false;
   std::vector<int> f_index, d_index;
   std::vector<Task> tasks;
   hipStream_t st = nullptr;
@@ -161,7 +162,7 @@ struct hmogp_engine {
   // N x M workspaces and row vectors
   long long ws_rows = 0;
   DevBuf Kh, Pt, vp, vc, vpt, vct, valpha, vbeta, valpha0, vbeta0;
-  DevBuf stats, slabs, colpart, quadpart;
+  DevBuf stats, slabs, colpart, quadpart, fwdpart, winrow, wincol, winhit;
   bool began = false, evaluated = false;
 
   // timing
@@ -224,6 +225,8 @@ struct hmogp_engine {
     if (P < 1 || P > 4) throw EngineError{HMOGP_E_INVALID, "input dimension P must be 1..4"};
     if (Q > HMOGP_MAXQ) throw EngineError{HMOGP_E_INVALID, "Q exceeds HMOGP_MAXQ (8)"};
     if (c->chunk_rows > 0) chunk = c->chunk_rows;
+    use_windows = (c->flags & HMOGP_CFG_EXACT_ZERO_WINDOWS) != 0;
+    if (use_windows && M > 8192) throw EngineError{HMOGP_E_INVALID, "exact-zero windows support M <= 8192"};
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
       throw EngineError{HMOGP_E_NO_DEVICE, "no HIP device visible (this library has no CPU path)"};
@@ -311,6 +314,11 @@ struct hmogp_engine {
     for (DevBuf* b : {&vp, &vc, &vpt, &vct, &valpha, &vbeta, &valpha0, &vbeta0}) b->ensure(nv, true);
     colpart.ensure(sizeof(double) * ((rows + 255) / 256) * M * (1 + P));
     quadpart.ensure(sizeof(double) * (rows * 64 / 256 + 1) * HMOGP_MAXSCAL);
+    fwdpart.ensure(sizeof(double) * 4 * ((M + 127) / 128) * rows);
+    if (use_windows) {
+      const size_t tiles = (rows + 127) / 128, ncb = (M + 127) / 128;
+      winrow.ensure(sizeof(int) * 2 * tiles * Q), wincol.ensure(sizeof(int) * 2 * ncb * Q), winhit.ensure(tiles * ncb);
+    }
     ws_rows = rows;
   }
 
@@ -395,6 +403,8 @@ struct hmogp_engine {
     const long long ldn = ws_rows;
     HIP_TRY(hipMemsetAsync(stats.p, 0, sizeof(double) * nstats, st));
     const int tiles = (M + 127) / 128, ntl = tiles * (tiles + 1) / 2;
+    const long long wtiles = (ws_rows + 127) / 128;
+    (void)ntl;
     for (int t = 0; t < T; ++t) {
       Task& k = tasks[t];
       for (long long r0 = rb[t]; r0 < re[t]; r0 += chunk) {
@@ -403,24 +413,30 @@ struct hmogp_engine {
         for (int q = 0; q < Q; ++q) {
           double* kh = Kh.d() + (long long)q * ldn * M;
           double* pt = Pt.d() + (long long)q * ldn * M;
+          int* rw = use_windows ? winrow.as<int>() + 2 * wtiles * q : nullptr;
+          int* cw = use_windows ? wincol.as<int>() + 2 * ((M + 127) / 128) * q : nullptr;
           {
-            Scope sc(this, CAT_RBF, 1);
-            launch_rbf(X, P, n, P, dZ.d() + q * P, ldz, M, h_var[q], h_ell[q], kh, false, st);
+            Scope sc(this, CAT_RBF, use_windows ? 4 : 1);
+            if (use_windows) launch_windows(X, n, P, dZ.d() + q * P, ldz, M, h_ell[q], rw, cw, winhit.as<unsigned char>(), st);
+            launch_rbf(X, P, n, P, dZ.d() + q * P, ldz, M, h_var[q], h_ell[q], kh, false, st, rw);
           }
           {
-            Scope sc(this, CAT_FWD, 1);
+            // forward contraction with the row statistics fused into its epilogue; P~ itself is only stored when the
+            // Z gradient (its one remaining consumer, colstats) is requested
+            Scope sc(this, CAT_FWD, 2);
             GemmArgs g;
             g.A = kh, g.lda = M, g.a_kmajor = 0;
             g.B = C.d() + q * MM, g.ldb = M, g.b_kmajor = 1;
             g.C = pt, g.ldc = M;
             g.M = (int)n, g.N = M, g.K = M;
             g.role = 1;
+            g.fs_part = fwdpart.d(), g.fs_a = a.d() + (long long)q * M, g.fs_x = X, g.fs_z = dZ.d() + q * P;
+            g.fs_ldz = ldz, g.fs_P = P, g.fs_hyper = want_hyper ? 1 : 0, g.fs_ell = h_ell[q];
+            g.store_c = want_z ? 1 : 0;
+            g.win = rw;
             launch_gemm_f64(g, st);
-          }
-          {
-            Scope sc(this, CAT_ROWSTATS, 1);
-            launch_rowstats(kh, pt, a.d() + (long long)q * M, X, P, dZ.d() + q * P, ldz, h_ell[q], n, M, vp.d() + q * ldn,
-                            vc.d() + q * ldn, vpt.d() + q * ldn, vct.d() + q * ldn, want_hyper, st);
+            launch_combine_parts(fwdpart.d(), (M + 127) / 128, n, vp.d() + q * ldn, vc.d() + q * ldn,
+                                 want_hyper ? vpt.d() + q * ldn : nullptr, want_hyper ? vct.d() + q * ldn : nullptr, st);
           }
         }
         {
@@ -451,9 +467,10 @@ struct hmogp_engine {
         for (int q = 0; q < Q; ++q) {
           const double* kh = Kh.d() + (long long)q * ldn * M;
           const double* pt = Pt.d() + (long long)q * ldn * M;
+          const int* cw = use_windows ? wincol.as<int>() + 2 * ((M + 127) / 128) * q : nullptr;
           {
             Scope sc(this, CAT_GRAM, 2);  // H_q += K^T diag(beta) K^   (svmogp_inf.py:145-147 summed over d)
-            const int ksplit = gram_ksplit(n, M);
+            const int ksplit = use_windows ? std::min(8, gram_ksplit(n, M)) : gram_ksplit(n, M);
             slabs.ensure(sizeof(double) * MM * 64, true);
             GemmArgs g;
             g.A = kh, g.lda = M, g.a_kmajor = 1;
@@ -464,6 +481,7 @@ struct hmogp_engine {
             g.lower_only = 1;
             g.ksplit = ksplit, g.sSplit = MM;
             g.role = 2;
+            g.win = cw;
             launch_gemm_f64(g, st);
             launch_reduce_slabs(slabs.d(), ksplit, MM, MM, Hq(q), true, st);
           }
@@ -471,7 +489,7 @@ struct hmogp_engine {
             Scope sc(this, CAT_COLSTATS, 2);
             const long long len = (long long)M * (1 + P);
             launch_colstats(kh, pt, a.d() + (long long)q * M, valpha.d() + q * ldn, valpha0.d() + q * ldn,
-                            vbeta0.d() + q * ldn, X, P, dZ.d() + q * P, ldz, n, M, 256, want_z, colpart.d(), st);
+                            vbeta0.d() + q * ldn, X, P, dZ.d() + q * P, ldz, n, M, 256, want_z, colpart.d(), st, cw);
             launch_reduce_slabs(colpart.d(), (int)((n + 255) / 256), len, len, Hq(q) + oR, true, st);
           }
         }
@@ -670,9 +688,12 @@ struct hmogp_engine {
         g.B = C.d() + q * MM, g.ldb = M, g.b_kmajor = 1;
         g.C = pt, g.ldc = M;
         g.M = (int)n, g.N = M, g.K = M;
+        g.role = 1;
+        g.fs_part = fwdpart.d(), g.fs_a = a.d() + (long long)q * M, g.fs_x = dX.d(), g.fs_z = dZ.d() + q * P;
+        g.fs_ldz = ldz, g.fs_P = P, g.fs_hyper = 0, g.fs_ell = h_ell[q];
+        g.store_c = 0;
         launch_gemm_f64(g, st);
-        launch_rowstats(kh, pt, a.d() + (long long)q * M, dX.d(), P, dZ.d() + q * P, ldz, h_ell[q], n, M, vp.d() + q * ldn,
-                        vc.d() + q * ldn, nullptr, nullptr, false, st);
+        launch_combine_parts(fwdpart.d(), (M + 127) / 128, n, vp.d() + q * ldn, vc.d() + q * ldn, nullptr, nullptr, st);
       }
       launch_qf_combine(vp.d(), vc.d(), ldn, n, Q, Df, dW.d(), dkap.d(), dvar.d(), dm.d(), dv.d(), st);
       HIP_TRY(hipMemcpyAsync(m + r0 * Df, dm.p, sizeof(double) * n * Df, hipMemcpyDeviceToHost, st));

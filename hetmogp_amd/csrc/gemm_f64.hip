@@ -99,13 +99,7 @@ __device__ __forceinline__ void store_kmajor(double* s, const double (&v)[8]) {
 // ROLE only names the instantiation (0 = generic M x M algebra, 1 = forward P~ = K^ C, 2 = weighted Gram) so that
 // rocprofv3 reports the two row-pass contractions separately from the small replicated GEMMs.
 template <bool A_KMAJOR, bool B_KMAJOR, int ROLE>
-#ifndef GEMM_ABL
-#define GEMM_ABL 0
-#endif
-#ifndef GEMM_WAVES_PER_SIMD
-#define GEMM_WAVES_PER_SIMD 2
-#endif
-__global__ __launch_bounds__(NTHREADS, GEMM_WAVES_PER_SIMD) void gemm_f64_kernel(GemmArgs g, int tiles_n, int ntiles) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int tiles_n, int ntiles) {
   __shared__ __attribute__((aligned(16))) Tile lds;
 
   // ---- which tile / batch / k-range -----------------------------------------------------------------
@@ -142,10 +136,24 @@ __global__ __launch_bounds__(NTHREADS, GEMM_WAVES_PER_SIMD) void gemm_f64_kernel
   }
   const int i0 = ti * BM, j0 = tj * BN;
   if (i0 >= M || j0 >= N) return;
-  const int ksteps = (K + BK - 1) / BK;
+  int wlo = 0, whi = K;
+  if (ROLE == 1 && g.win) {  // exact-zero window of this row tile (see GemmArgs::win)
+    wlo = g.win[2 * ti], whi = min(K, g.win[2 * ti + 1]);
+    if (j0 >= whi || j0 + BN <= wlo) {  // no consumer ever reads this P~ tile: its statistics are exact zeros
+      if (g.fs_part && threadIdx.x < 128 && i0 + (int)threadIdx.x < M)
+        for (int st = 0; st < (g.fs_hyper ? 4 : 2); ++st)
+          g.fs_part[((long long)st * tiles_n + tj) * M + (i0 + threadIdx.x)] = 0.0;
+      return;
+    }
+  }
+  if (ROLE == 2 && g.win) {
+    wlo = max(g.win[2 * ti], g.win[2 * tj]);
+    whi = max(wlo, min(K, min(g.win[2 * ti + 1], g.win[2 * tj + 1])));
+  }
+  const int ksteps = (whi - wlo + BK - 1) / BK;
   const int per = (ksteps + g.ksplit - 1) / g.ksplit;
-  const int kbeg = split * per * BK;
-  const int kend = min(K, kbeg + per * BK);
+  const int kbeg = wlo + split * per * BK;
+  const int kend = min(whi, kbeg + per * BK);
 
   const long long ob = blockIdx.y;
   const double* __restrict__ A = g.A + (long long)batch * g.sA + ob * g.oA;
@@ -174,76 +182,6 @@ __global__ __launch_bounds__(NTHREADS, GEMM_WAVES_PER_SIMD) void gemm_f64_kernel
   // The loads of tile k+1 are issued before the MFMA block of tile k and must not be consumed until `stage` (after the
   // MFMA block): the k-scale of the Gram operand is therefore applied at stage time, not at load time (a multiply at
   // load time makes hipcc wait vmcnt(0) in front of the MFMAs and exposes the whole HBM latency every k-step).
-#ifdef GEMM_DEEP
-  // Two register sets: loads of tile k+2 are issued before the MFMA block of tile k and staged after the MFMA block
-  // of tile k+1 (two k-steps of latency budget).
-  double ra0[8], rb0[8], ra1[8], rb1[8], ks0 = 1.0, ks1 = 1.0;
-  auto load = [&](int k0, double (&ra)[8], double (&rb)[8], double& ks) {
-    const bool fk = (k0 + BK <= kend);
-    if (A_KMAJOR)
-      load_kmajor(A, g.lda, i0, M, k0, kend, fullA && fk, ra);
-    else
-      load_rowmajor(A, g.lda, i0, M, k0, kend, fullA && fk, ra);
-    if (B_KMAJOR) {
-      load_kmajor(B, g.ldb, j0, N, k0, kend, fullB && fk, rb);
-      if (S) {
-        const int k = k0 + (t >> 4);
-        ks = (k < kend) ? S[k] : 0.0;
-      }
-    } else {
-      load_rowmajor(B, g.ldb, j0, N, k0, kend, fullB && fk, rb);
-    }
-  };
-  auto stage = [&](int buf, double (&ra)[8], double (&rb)[8], double ks) {
-    if (A_KMAJOR)
-      store_kmajor(lds.a[buf], ra);
-    else
-      store_rowmajor(lds.a[buf], ra);
-    if (B_KMAJOR) {
-      if (S) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) rb[i] *= ks;
-      }
-      store_kmajor(lds.b[buf], rb);
-    } else {
-      store_rowmajor(lds.b[buf], rb);
-    }
-  };
-  auto compute = [&](int cur) {
-#pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      const double* pa = A_KMAJOR ? &lds.a[cur][(kk * 4 + lk) * KM_LD + wm * 64 + lr] : &lds.a[cur][(wm * 64 + lr) * RM_LD + kk * 4 + lk];
-      const double* pb = B_KMAJOR ? &lds.b[cur][(kk * 4 + lk) * KM_LD + wn * 64 + lr] : &lds.b[cur][(wn * 64 + lr) * RM_LD + kk * 4 + lk];
-      double fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = pa[i * 16 * (A_KMAJOR ? 1 : RM_LD)];
-        fb[i] = pb[i * 16 * (B_KMAJOR ? 1 : RM_LD)];
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
-    }
-  };
-  if (kbeg < kend) {
-    load(kbeg, ra0, rb0, ks0);
-    stage(0, ra0, rb0, ks0);
-    if (kbeg + BK < kend) load(kbeg + BK, ra1, rb1, ks1);
-  }
-  __syncthreads();
-  for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
-    if (k0 + 2 * BK < kend) load(k0 + 2 * BK, ra0, rb0, ks0);
-    compute(0);
-    if (k0 + BK < kend) stage(1, ra1, rb1, ks1);
-    __syncthreads();
-    if (k0 + BK >= kend) break;
-    if (k0 + 3 * BK < kend) load(k0 + 3 * BK, ra1, rb1, ks1);
-    compute(1);
-    if (k0 + 2 * BK < kend) stage(0, ra0, rb0, ks0);
-    __syncthreads();
-  }
-#else
   double ra[8], rb[8], ks = 1.0;
   auto load = [&](int k0) {
     const bool fk = (k0 + BK <= kend);
@@ -285,9 +223,7 @@ __global__ __launch_bounds__(NTHREADS, GEMM_WAVES_PER_SIMD) void gemm_f64_kernel
   __syncthreads();
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     const bool more = (k0 + BK) < kend;
-#if !(GEMM_ABL & 1)
     if (more) load(k0 + BK);
-#endif
     if (!idle_quadrant)
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
@@ -304,19 +240,117 @@ __global__ __launch_bounds__(NTHREADS, GEMM_WAVES_PER_SIMD) void gemm_f64_kernel
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
     }
-#if !(GEMM_ABL & 1)
     if (more) stage(cur ^ 1);
-#endif
-#if !(GEMM_ABL & 2)
     __syncthreads();
-#endif
     cur ^= 1;
   }
 
-#endif
 
   // ---- epilogue: D fragment of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg -----------
   const double alpha = g.alpha, beta = (g.ksplit > 1) ? 0.0 : g.beta;
+  if (ROLE == 1 && g.fs_part) {
+    // fused row statistics (see GemmArgs): the block's P~ tile is in registers, its K^ tile is re-read (L2/MALL-warm)
+    const int P = g.fs_P;
+    double av[4], zv[4][4], zsq[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = j0 + wn * 64 + b * 16 + lr;
+      const bool ok = col < N;
+      av[b] = ok ? g.fs_a[col] : 0.0;
+      zsq[b] = 0.0;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        zv[b][p] = (ok && p < P) ? g.fs_z[(long long)col * g.fs_ldz + p] : 0.0;
+        zsq[b] += zv[b][p] * zv[b][p];
+      }
+    }
+    // LDS after the k-loop (which ended with a barrier): kbuf[32][130] (33 KB, over lds.a) holds one 32-row slice of the
+    // block's K^ tile, fetched with fully coalesced 16-byte loads; red[2][128][4] (8 KB, over lds.b) the row partials.
+    constexpr int KB_LD = 130;
+    double* kbuf = &lds.a[0][0];
+    double* red = &lds.b[0][0];
+    double* xs = red + 2 * 128 * 4;  // [128][4] inputs of the block's rows (staged once: no global latency in the row loop)
+    static_assert(32 * KB_LD <= 2 * TILE_DOUBLES && 2 * 128 * 4 + 128 * 4 <= 2 * TILE_DOUBLES, "epilogue scratch fits the tile buffers");
+    for (int e = t; e < 128 * 4; e += NTHREADS) {
+      const int rr = e >> 2, p = e & 3;
+      xs[e] = (i0 + rr < M && p < P) ? g.fs_x[(long long)(i0 + rr) * P + p] : 0.0;
+    }
+    const double inv_l2 = 1.0 / (g.fs_ell * g.fs_ell);
+    const bool vecK = ((g.lda & 1) == 0) && ((((uintptr_t)A) & 15) == 0) && (j0 + BN <= N);
+#pragma unroll 1
+    for (int a = 0; a < 4; ++a) {
+      // slice a = rows {wm*64 + a*16 + (0..15)} for wm = 0, 1: thread t stages row (t>>3), 16 columns from (t&7)*16
+      {
+        const int lrow = t >> 3, c16 = (t & 7) * 16;
+        const int grow = i0 + (lrow >> 4) * 64 + a * 16 + (lrow & 15);
+        const double* src = A + (long long)grow * g.lda + j0 + c16;
+        double* dst = kbuf + lrow * KB_LD + c16;
+        if (vecK && grow < M) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) *reinterpret_cast<f64x2*>(dst + 2 * e) = *reinterpret_cast<const f64x2*>(src + 2 * e);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) dst[e] = (grow < M && (j0 + c16 + e) < N) ? src[e] : 0.0;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = wm * 64 + a * 16 + 4 * r + lk, row = i0 + rl;
+        const bool rok = row < M;
+        double xv[4], xsq = 0.0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          xv[p] = xs[rl * 4 + p];
+          xsq += xv[p] * xv[p];
+        }
+        (void)rok;
+        const double* krow = kbuf + (wm * 16 + 4 * r + lk) * KB_LD + wn * 64 + lr;
+        double sp = 0.0, sc = 0.0, spt = 0.0, sct = 0.0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const double kv = krow[b * 16];  // K^[row][j0 + wn*64 + b*16 + lr]
+          double pv;
+          switch (a) {  // acc[a] with a runtime slice index: select, never index (register arrays)
+            case 0: pv = acc[0][b][r]; break;
+            case 1: pv = acc[1][b][r]; break;
+            case 2: pv = acc[2][b][r]; break;
+            default: pv = acc[3][b][r]; break;
+          }
+          sp += kv * av[b];
+          sc += pv * kv;
+          if (g.fs_hyper) {
+            double dot = 0.0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) dot += xv[p] * zv[b][p];
+            const double r2 = fmax(-2.0 * dot + (xsq + zsq[b]), 0.0) * inv_l2;
+            spt += kv * av[b] * r2;
+            sct += pv * kv * r2;
+          }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {  // sum over the 16 lanes that share this row
+          sp += __shfl_xor(sp, o, 64);
+          sc += __shfl_xor(sc, o, 64);
+          if (g.fs_hyper) {
+            spt += __shfl_xor(spt, o, 64);
+            sct += __shfl_xor(sct, o, 64);
+          }
+        }
+        if (lr == 0) {
+          double* o4 = red + ((wn * 128) + rl) * 4;
+          o4[0] = sp, o4[1] = sc, o4[2] = spt, o4[3] = sct;
+        }
+      }
+      __syncthreads();  // kbuf is overwritten by the next slice
+    }
+    if (t < 128 && i0 + t < M) {
+      const int nst = g.fs_hyper ? 4 : 2;
+      for (int st = 0; st < nst; ++st)
+        g.fs_part[((long long)st * tiles_n + tj) * M + (i0 + t)] = red[t * 4 + st] + red[(128 + t) * 4 + st];
+    }
+    if (!g.store_c) return;
+  }
   if (idle_quadrant) return;  // the strictly-upper quadrant is never read (mirrored from the lower one)
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
@@ -339,6 +373,28 @@ __global__ __launch_bounds__(NTHREADS, GEMM_WAVES_PER_SIMD) void gemm_f64_kernel
 }
 
 }  // namespace
+
+namespace {
+__global__ void combine_parts_kernel(const double* __restrict__ part, int tiles, long long n, double* __restrict__ p,
+                                     double* __restrict__ c, double* __restrict__ pt, double* __restrict__ ct) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double* outs[4] = {p, c, pt, ct};
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    if (!outs[st]) continue;
+    double s = 0.0;
+    for (int t = 0; t < tiles; ++t) s += part[((long long)st * tiles + t) * n + i];
+    outs[st][i] = s;
+  }
+}
+}  // namespace
+
+void launch_combine_parts(const double* part, int tiles, long long n, double* p, double* c, double* pt, double* ct,
+                          hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(combine_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, tiles, n, p, c, pt, ct);
+}
 
 void launch_gemm_f64(const GemmArgs& g, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0 || g.nbatch <= 0 || g.nouter <= 0) return;

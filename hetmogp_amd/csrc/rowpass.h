@@ -45,12 +45,14 @@ void launch_predictive(int lik, int J, int Jp, double param, int T, long long N,
 void launch_log_predictive(int lik, int J, double param, long long N, int S, unsigned long long seed, const double* y,
                            const double* m, const double* v, double* out, hipStream_t s);
 void launch_rbf(const double* X, int ldx, long long N, int P, const double* Z, int ldz, int M, double var, double ell,
-                double* K, bool same, hipStream_t s);
-void launch_rowstats(const double* Kh, const double* Pt, const double* a, const double* X, int P, const double* Z, int ldz,
-                     double ell, long long N, int M, double* p, double* c, double* pt, double* ct, bool hyper, hipStream_t s);
+                double* K, bool same, hipStream_t s, const int* rowwin = nullptr);
+// exact-zero windows of K^ = k(X, Z) for one (row chunk, latent): rowwin [tiles][2] column range per 128-row tile,
+// colwin [ncb][2] row range per 128-column block, hit [tiles][ncb] scratch (see rowpass.hip)
+void launch_windows(const double* X, long long N, int P, const double* Z, int ldz, int M, double ell, int* rowwin, int* colwin,
+                    unsigned char* hit, hipStream_t s);
 void launch_colstats(const double* Kh, const double* Pt, const double* a, const double* alpha, const double* alpha0,
                      const double* beta0, const double* X, int P, const double* Z, int ldz, long long N, int M, int rows,
-                     bool want_z, double* partials, hipStream_t s);
+                     bool want_z, double* partials, hipStream_t s, const int* colwin = nullptr);
 void launch_reduce_rows(const double* partials, long long nrows, int len, const long long* off, double* dst, bool accumulate,
                         hipStream_t s);
 void launch_reduce_slabs(const double* slabs, int nslabs, long long stride, long long len, double* dst, bool accumulate,

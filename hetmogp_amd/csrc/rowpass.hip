@@ -2,7 +2,7 @@
 // except the two FP64-MFMA contractions (gemm_f64.hip).
 //
 //   rbf_cross_cov   K^[n,m] = s2 exp(-r2/2)          HBM-bound writer (N*M*8 B), util.py:145-164 / GPy RBF.K
-//   rowstats        p = K^ a, c = rowsum(P~ .* K^), and their r2-weighted twins           (reads K^, P~ once)
+//   (row statistics p = K^ a, c = rowsum(P~ .* K^) ... are fused into the forward contraction's epilogue, gemm_f64.hip)
 //   quad            q(f) mean/variance (svmogp_inf.py:212-218) -> variational expectations (het_likelihood.py:
 //                   101-131) -> row weights alpha/beta for the backward pass + scalar statistics
 //   colstats        r = K^T alpha, dZ numerators = colsum(E^ .* (x - z))                     (reads K^, P~ once)
@@ -18,7 +18,7 @@ constexpr int RBF_ROWS = 32;  // rows per block; 256 threads x 2 columns = 512 c
 template <int P>
 __global__ __launch_bounds__(256) void rbf_kernel(const double* __restrict__ X, int ldx, long long N,
                                                   const double* __restrict__ Z, int ldz, int M, double var, double ell,
-                                                  double* __restrict__ K, int same) {
+                                                  double* __restrict__ K, int same, const int* __restrict__ rowwin) {
   __shared__ double xs[RBF_ROWS][P + 1];
   const int t = threadIdx.x;
   const long long n0 = (long long)blockIdx.x * RBF_ROWS;
@@ -36,6 +36,10 @@ __global__ __launch_bounds__(256) void rbf_kernel(const double* __restrict__ X, 
   }
   __syncthreads();
   if (c >= M) return;
+  if (rowwin) {  // exact-zero windows: a wave owns one 128-column block; skip it if no consumer will read it
+    const int T = (int)(n0 >> 7), cb0 = (c >> 7) << 7;
+    if (cb0 >= rowwin[2 * T + 1] || cb0 + 128 <= rowwin[2 * T]) return;
+  }
   const bool two = (c + 1) < M;
   double z0[P], z1[P];
 #pragma unroll
@@ -67,49 +71,106 @@ __global__ __launch_bounds__(256) void rbf_kernel(const double* __restrict__ X, 
   }
 }
 
-// ---- rowstats: one wave per row ---------------------------------------------------------------------------
-template <int P, bool HYPER>
-__global__ __launch_bounds__(256) void rowstats_kernel(const double* __restrict__ Kh, const double* __restrict__ Pt,
-                                                       const double* __restrict__ a, const double* __restrict__ X,
-                                                       const double* __restrict__ Z, int ldz, double ell, long long N,
-                                                       int M, double* __restrict__ p, double* __restrict__ c,
-                                                       double* __restrict__ pt, double* __restrict__ ct) {
-  const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (n >= N) return;
-  const double* k = Kh + n * M;
-  const double* q = Pt + n * M;
-  double xv[P];
+// ---- exact-zero windows ----------------------------------------------------------------------------------------
+// K^[n][m] = s2 exp(-r2/2) is EXACTLY 0.0 in float64 once r2 > ~1490.3 (exp underflows below the smallest subnormal).
+// For spatially sorted inputs K^ is therefore banded, and every product the row pass forms with an entry outside the
+// band is a product with an exact zero.  window_kernel finds, per 128-row tile, the column range [lo, hi) that holds all
+// possibly-nonzero entries (r2 <= 1491: a superset), and per 128-column block the hull of the row tiles that touch it;
+// window_fix_kernel falls back to full ranges when the data is not banded (a row tile inside a block's hull that does not
+// touch the block), so arbitrary inputs stay correct.  No host synchronisation is involved.
+constexpr double WINDOW_R2_MAX = 1491.0;
+
+__global__ void window_init_kernel(int* __restrict__ colwin, int ncb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ncb) {
+    colwin[2 * i] = 0x7fffffff;
+    colwin[2 * i + 1] = 0;
+  }
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void window_kernel(const double* __restrict__ X, long long N, const double* __restrict__ Z,
+                                                     int ldz, int M, double ell, int* __restrict__ rowwin,
+                                                     int* __restrict__ colwin, unsigned char* __restrict__ hit, int ncb) {
+  __shared__ double xs[128][P + 1];
+  __shared__ int s_lo, s_hi;
+  __shared__ int s_hit[64];
+  const int t = threadIdx.x, T = blockIdx.x;
+  const long long r0 = (long long)T * 128;
+  const int nr = (int)min(128LL, N - r0);
+  if (t == 0) s_lo = 0x7fffffff, s_hi = 0;
+  if (t < 64) s_hit[t] = 0;
+  for (int e = t; e < 128 * P; e += 256) {
+    const int r = e / P, p = e % P;
+    xs[r][p] = (r < nr) ? X[(r0 + r) * P + p] : 0.0;
+  }
+  __syncthreads();
+  if (t < 128) {
+    double xv[P];
 #pragma unroll
-  for (int i = 0; i < P; ++i) xv[i] = X[n * P + i];
-  const double xsq = sumsq<P>(xv);
-  double sp = 0.0, sc = 0.0, spt = 0.0, sct = 0.0;
-  for (int m = lane; m < M; m += 64) {
-    const double kv = k[m], pv = q[m], av = a[m];
-    sp += kv * av;
-    sc += pv * kv;
-    if (HYPER) {
-      double zv[P];
+    for (int p = 0; p < P; ++p) xv[p] = xs[t][p];
+    xs[t][P] = sumsq<P>(xv);
+  }
+  __syncthreads();
+  for (int m = t; m < M; m += 256) {
+    double zv[P];
 #pragma unroll
-      for (int i = 0; i < P; ++i) zv[i] = Z[(long long)m * ldz + i];
-      const double r2 = rbf_r2<P>(xv, xsq, zv, sumsq<P>(zv), ell);
-      spt += kv * av * r2;
-      sct += pv * kv * r2;
+    for (int p = 0; p < P; ++p) zv[p] = Z[(long long)m * ldz + p];
+    const double zsq = sumsq<P>(zv);
+    bool any = false;
+    for (int r = 0; r < nr && !any; ++r) {
+      double xv[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) xv[p] = xs[r][p];
+      any = !(rbf_r2<P>(xv, xs[r][P], zv, zsq, ell) > WINDOW_R2_MAX);  // NaN counts as "possibly nonzero"
+    }
+    if (any) {
+      atomicMin(&s_lo, m);
+      atomicMax(&s_hi, m + 1);
+      s_hit[m >> 7] = 1;
     }
   }
-  sp = wave_sum(sp);
-  sc = wave_sum(sc);
-  if (HYPER) {
-    spt = wave_sum(spt);
-    sct = wave_sum(sct);
+  __syncthreads();
+  if (t == 0) {
+    const bool none = s_hi == 0;
+    rowwin[2 * T] = none ? 0 : (s_lo & ~15);
+    rowwin[2 * T + 1] = none ? 0 : min((s_hi + 15) & ~15, (M + 15) & ~15);
   }
-  if (lane == 0) {
-    p[n] = sp;
-    c[n] = sc;
-    if (HYPER) {
-      pt[n] = spt;
-      ct[n] = sct;
+  if (t < ncb) {
+    hit[(long long)T * ncb + t] = (unsigned char)s_hit[t];
+    if (s_hit[t]) {
+      atomicMin(&colwin[2 * t], (int)r0);
+      atomicMax(&colwin[2 * t + 1], (int)(r0 + nr));
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void window_fix_kernel(int* __restrict__ rowwin, int* __restrict__ colwin,
+                                                         const unsigned char* __restrict__ hit, int tiles, int ncb, int M,
+                                                         long long N) {
+  __shared__ int viol;
+  const int t = threadIdx.x;
+  if (t == 0) viol = 0;
+  __syncthreads();
+  for (int cb = 0; cb < ncb; ++cb) {
+    const int lo = colwin[2 * cb], hi = colwin[2 * cb + 1];
+    if (lo == 0x7fffffff) continue;
+    for (int T = (lo >> 7) + t; T < (hi + 127) >> 7; T += 256)
+      if (!hit[(long long)T * ncb + cb]) viol = 1;
+  }
+  __syncthreads();
+  if (viol) {  // not banded: dense ranges everywhere
+    for (int T = t; T < tiles; T += 256) {
+      rowwin[2 * T] = 0;
+      rowwin[2 * T + 1] = (M + 15) & ~15;
+    }
+    for (int cb = t; cb < ncb; cb += 256) {
+      colwin[2 * cb] = 0;
+      colwin[2 * cb + 1] = (int)N;
+    }
+  } else {
+    for (int cb = t; cb < ncb; cb += 256)
+      if (colwin[2 * cb] == 0x7fffffff) colwin[2 * cb] = 0, colwin[2 * cb + 1] = 0;
   }
 }
 
@@ -214,12 +275,16 @@ __global__ __launch_bounds__(256) void colstats_kernel(const double* __restrict_
                                                        const double* __restrict__ alpha0, const double* __restrict__ beta0,
                                                        const double* __restrict__ X, const double* __restrict__ Z, int ldz,
                                                        long long N, int M, int rows, int want_z,
-                                                       double* __restrict__ partials) {
+                                                       double* __restrict__ partials, const int* __restrict__ colwin) {
   const int t = threadIdx.x, c = blockIdx.x * 512 + 2 * t;
   if (c >= M) return;
   const bool two = (c + 1) < M;
   const bool vec = two && ((M & 1) == 0);
-  const long long n0 = (long long)blockIdx.y * rows, n1 = min(N, n0 + rows);
+  long long n0 = (long long)blockIdx.y * rows, n1 = min(N, n0 + rows);
+  if (colwin) {  // rows outside the exact-zero window of this 128-column block contribute exact zeros
+    n0 = max(n0, (long long)colwin[2 * (c >> 7)]);
+    n1 = min(n1, (long long)colwin[2 * (c >> 7) + 1]);
+  }
   double z0[P], z1[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) {
@@ -231,16 +296,21 @@ __global__ __launch_bounds__(256) void colstats_kernel(const double* __restrict_
 #pragma unroll
   for (int p = 0; p < P; ++p) d0[p] = d1[p] = 0.0;
   for (long long n = n0; n < n1; ++n) {
-    double k0, k1, q0, q1;
+    double k0, k1, q0 = 0.0, q1 = 0.0;
     if (vec) {
       const f64x2 kv = *reinterpret_cast<const f64x2*>(Kh + n * M + c);
-      const f64x2 qv = *reinterpret_cast<const f64x2*>(Pt + n * M + c);
-      k0 = kv.x, k1 = kv.y, q0 = qv.x, q1 = qv.y;
+      k0 = kv.x, k1 = kv.y;
+      if (want_z) {
+        const f64x2 qv = *reinterpret_cast<const f64x2*>(Pt + n * M + c);
+        q0 = qv.x, q1 = qv.y;
+      }
     } else {
       k0 = Kh[n * M + c];
-      q0 = Pt[n * M + c];
       k1 = two ? Kh[n * M + c + 1] : 0.0;
-      q1 = two ? Pt[n * M + c + 1] : 0.0;
+      if (want_z) {
+        q0 = Pt[n * M + c];
+        q1 = two ? Pt[n * M + c + 1] : 0.0;
+      }
     }
     const double al = alpha[n];
     r0 += k0 * al;
@@ -406,25 +476,22 @@ __global__ __launch_bounds__(256) void log_predictive_kernel(int J, double param
 }  // namespace
 
 // =============================================================================================== launchers
-void launch_rbf(const double* X, int ldx, long long N, int P, const double* Z, int ldz, int M, double var, double ell,
-                double* K, bool same, hipStream_t s) {
-  if (N <= 0 || M <= 0) return;
-  dim3 grid((unsigned)((N + RBF_ROWS - 1) / RBF_ROWS), (M + 511) / 512);
-  DISPATCH_P(P, hipLaunchKernelGGL((rbf_kernel<PP>), grid, dim3(256), 0, s, X, ldx, N, Z, ldz, M, var, ell, K, same ? 1 : 0));
+void launch_windows(const double* X, long long N, int P, const double* Z, int ldz, int M, double ell, int* rowwin, int* colwin,
+                    unsigned char* hit, hipStream_t s) {
+  if (N <= 0) return;
+  const int tiles = (int)((N + 127) / 128), ncb = (M + 127) / 128;
+  if (ncb > 64) throw HipError{hipErrorInvalidValue, "exact-zero windows support M <= 8192", __FILE__, __LINE__};
+  hipLaunchKernelGGL(window_init_kernel, dim3(1), dim3(64), 0, s, colwin, ncb);
+  DISPATCH_P(P, hipLaunchKernelGGL((window_kernel<PP>), dim3(tiles), dim3(256), 0, s, X, N, Z, ldz, M, ell, rowwin, colwin, hit,
+                                   ncb));
+  hipLaunchKernelGGL(window_fix_kernel, dim3(1), dim3(256), 0, s, rowwin, colwin, hit, tiles, ncb, M, N);
 }
 
-void launch_rowstats(const double* Kh, const double* Pt, const double* a, const double* X, int P, const double* Z, int ldz,
-                     double ell, long long N, int M, double* p, double* c, double* pt, double* ct, bool hyper,
-                     hipStream_t s) {
-  if (N <= 0) return;
-  dim3 grid((unsigned)((N + 3) / 4));
-  if (hyper) {
-    DISPATCH_P(P, hipLaunchKernelGGL((rowstats_kernel<PP, true>), grid, dim3(256), 0, s, Kh, Pt, a, X, Z, ldz, ell, N, M, p,
-                                     c, pt, ct));
-  } else {
-    DISPATCH_P(P, hipLaunchKernelGGL((rowstats_kernel<PP, false>), grid, dim3(256), 0, s, Kh, Pt, a, X, Z, ldz, ell, N, M,
-                                     p, c, pt, ct));
-  }
+void launch_rbf(const double* X, int ldx, long long N, int P, const double* Z, int ldz, int M, double var, double ell,
+                double* K, bool same, hipStream_t s, const int* rowwin) {
+  if (N <= 0 || M <= 0) return;
+  dim3 grid((unsigned)((N + RBF_ROWS - 1) / RBF_ROWS), (M + 511) / 512);
+  DISPATCH_P(P, hipLaunchKernelGGL((rbf_kernel<PP>), grid, dim3(256), 0, s, X, ldx, N, Z, ldz, M, var, ell, K, same ? 1 : 0, rowwin));
 }
 
 long long quad_blocks(int lik, long long N) { return (N * lik_lanes(lik) + 255) / 256; }
@@ -504,11 +571,11 @@ void launch_log_predictive(int lik, int J, double param, long long N, int S, uns
 
 void launch_colstats(const double* Kh, const double* Pt, const double* a, const double* alpha, const double* alpha0,
                      const double* beta0, const double* X, int P, const double* Z, int ldz, long long N, int M, int rows,
-                     bool want_z, double* partials, hipStream_t s) {
+                     bool want_z, double* partials, hipStream_t s, const int* colwin) {
   if (N <= 0) return;
   dim3 grid((M + 511) / 512, (unsigned)((N + rows - 1) / rows));
   DISPATCH_P(P, hipLaunchKernelGGL((colstats_kernel<PP>), grid, dim3(256), 0, s, Kh, Pt, a, alpha, alpha0, beta0, X, Z, ldz,
-                                   N, M, rows, want_z ? 1 : 0, partials));
+                                   N, M, rows, want_z ? 1 : 0, partials, colwin));
 }
 
 void launch_reduce_rows(const double* partials, long long nrows, int len, const long long* off, double* dst, bool accumulate,

@@ -23,7 +23,7 @@ class Posterior(object):
 
 class SVMOGP(object):
     def __init__(self, X, Y, Z, kern_list, likelihood, Y_metadata, name="SVMOGP", batch_size=None, W_list=None,
-                 device=0, chunk_rows=0):
+                 device=0, chunk_rows=0, exact_zero_windows=False):
         self.name = name
         self.batch_size = batch_size
         self.kern_list = kern_list
@@ -43,7 +43,7 @@ class SVMOGP(object):
         T = len(self.Ymulti_all)
         self.Xdim = Z.shape[1]
         self._engine = Engine(likelihood.specs(), self.num_latent_funcs, self.num_inducing, self.Xdim, device=device,
-                              chunk_rows=chunk_rows)
+                              chunk_rows=chunk_rows, exact_zero_windows=exact_zero_windows)
         self._engine.set_data(self.Xmulti_all, self.Ymulti_all)
         self._rows = [(0, x.shape[0]) for x in self.Xmulti_all]
         self._last_batch = None

@@ -84,7 +84,15 @@ typedef struct {
   int32_t device;           /* HIP device ordinal                                                    */
   int64_t chunk_rows;       /* rows of one task processed per pass (0 = default 262144); bounds the
                                N x M workspaces: 2 * Q * chunk_rows * M * 8 bytes                    */
+  uint32_t flags;           /* HMOGP_CFG_*                                                           */
 } hmogp_config;
+
+/* hmogp_config.flags */
+#define HMOGP_CFG_EXACT_ZERO_WINDOWS 1u /* opt-in: skip the parts of K_uf = k(X,Z) that are EXACTLY 0.0 in float64
+   (exp underflow beyond ~38.6 lengthscales).  For spatially sorted inputs K_uf is banded and the row pass only touches
+   the band; every skipped term is a product with an exact zero, so ELBO and gradients are unchanged (tested equal to
+   the dense path); unsorted inputs fall back to dense ranges on the device.  Default off: the dense path is what
+   bench.py reports as `value`.                                                                                  */
 
 /* All model parameters of one evaluation: the arrays paramz hands to parameters_changed().             */
 typedef struct {

@@ -295,3 +295,49 @@ def test_natural_gradient_step():
         cur = e2.elbo_grad(**a2)["elbo"]
         assert cur > prev
         prev = cur
+
+
+def test_exact_zero_windows_equal_dense():
+    """Opt-in exact-zero windows (HMOGP_CFG_EXACT_ZERO_WINDOWS): sorted 1-D inputs make K_uf banded and most tiles are
+    skipped; every skipped term is a product with an exact 0.0, so the result must equal the dense path (to summation
+    order of the row-range split) and the oracle.  Shuffled rows are not banded: the device falls back to dense ranges."""
+    from oracle import svmogp_oracle as so
+    specs = [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {}), ("Poisson", {}), ("Gamma", {})]
+    Ns = [3000, 2500, 1111, 700]
+    prm, prob, X, Y = synth(31, specs, Ns, 300, 3, 1, (0.8, 1.0, 1.3))
+    bs = [1.0, 2.0, 1.5, 3.0]
+    dense = run(make_engine(prob, X, Y), prm, bs)
+    win = run(make_engine(prob, X, Y, exact_zero_windows=True), prm, bs)
+    want = so.elbo_grad_fused(prm, prob, X, Y, bs)
+    for k in KEYS:
+        assert rel(win[k], dense[k]) < 1e-11, k
+        assert rel(win[k], want[k]) < TOL, k
+    # chunked + windows
+    winc = run(make_engine(prob, X, Y, exact_zero_windows=True, chunk_rows=512), prm, bs)
+    for k in KEYS:
+        assert rel(winc[k], dense[k]) < 1e-9, k
+    # not banded (rows shuffled): dense fallback
+    rng = np.random.RandomState(0)
+    perm = [rng.permutation(n) for n in Ns]
+    Xs, Ys = [x[p] for x, p in zip(X, perm)], [y[p] for y, p in zip(Y, perm)]
+    ws = run(make_engine(prob, Xs, Ys, exact_zero_windows=True), prm, bs)
+    for k in KEYS:
+        assert rel(ws[k], dense[k]) < 1e-9, k
+    # E-step mask (P~ never stored) and long lengthscale (no exact zeros at all)
+    from hetmogp_amd import _lib
+    d2 = run(make_engine(prob, X, Y), prm, bs, group_mask=_lib.GROUP_QU)
+    w2 = run(make_engine(prob, X, Y, exact_zero_windows=True), prm, bs, group_mask=_lib.GROUP_QU)
+    for k in ("elbo", "g_m_u", "g_L_u"):
+        assert rel(w2[k], d2[k]) < 1e-11, k
+
+
+@pytest.mark.slow
+def test_exact_zero_windows_headline_shape():
+    specs = [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {}), ("Poisson", {}), ("Gamma", {})]
+    Ns = [50000] * 4
+    prm, prob, X, Y = synth(32, specs, Ns, 1024, 3, 1, (0.8, 1.0, 1.3))
+    dense = run(make_engine(prob, X, Y), prm)
+    e = make_engine(prob, X, Y, exact_zero_windows=True)
+    win = run(e, prm)
+    for k in KEYS:
+        assert rel(win[k], dense[k]) < 1e-10, k

@@ -53,11 +53,13 @@ def main():
               (r["kernel"][:40], r["grid_threads"], r["launches"], r["fetch_kb_raw_avg"], r["write_kb_raw_avg"],
                r["hbm_bytes_per_launch"] / 1e9))
     # the forward contraction of the headline workload's full chunk: the dominant kernel's traffic for bench.py
-    fwd = [r for r in rows if r["kernel"].startswith("gemm_f64_kernel<false, true") and r["grid_threads"] == 2097152]
+    fwd = [r for r in rows if r["kernel"].startswith("gemm_f64_kernel<false, true, 1>")]
+    fwd.sort(key=lambda r: -r["grid_threads"])
     if fwd:
         json.dump({"kernel": fwd[0]["kernel"], "grid_threads": fwd[0]["grid_threads"], "launches": fwd[0]["launches"],
                    "hbm_bytes_per_launch": fwd[0]["hbm_bytes_per_launch"],
-                   "note": "131072-row chunk; (2*FETCH_SIZE + WRITE_SIZE)*1024, round %s" % rnd},
+                   "note": "forward contraction of one (task, latent) of the headline workload (200000 rows, one chunk); "
+                           "(2*FETCH_SIZE + WRITE_SIZE)*1024 from separate --pmc passes, round %s" % rnd},
                   open(os.path.join(dst, "pmc_forward_gemm.json"), "w"))
 
 
