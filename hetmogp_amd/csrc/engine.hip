@@ -418,7 +418,7 @@ struct hmogp_engine {
           {
             Scope sc(this, CAT_RBF, use_windows ? 4 : 1);
             if (use_windows) launch_windows(X, n, P, dZ.d() + q * P, ldz, M, h_ell[q], rw, cw, winhit.as<unsigned char>(), st);
-            launch_rbf(X, P, n, P, dZ.d() + q * P, ldz, M, h_var[q], h_ell[q], kh, false, st, rw);
+            launch_rbf(X, P, n, P, dZ.d() + q * P, ldz, M, h_var[q], h_ell[q], kh, false, st, rw, false);
           }
           {
             // forward contraction with the row statistics fused into its epilogue; P~ itself is only stored when the
@@ -483,7 +483,7 @@ struct hmogp_engine {
             g.role = 2;
             g.win = cw;
             launch_gemm_f64(g, st);
-            launch_reduce_slabs(slabs.d(), ksplit, MM, MM, Hq(q), true, st);
+            launch_reduce_slabs_lower(slabs.d(), ksplit, M, Hq(q), true, st);
           }
           {
             Scope sc(this, CAT_COLSTATS, 2);
@@ -682,7 +682,7 @@ struct hmogp_engine {
       for (int q = 0; q < Q; ++q) {
         double* kh = Kh.d() + (long long)q * ldn * M;
         double* pt = Pt.d() + (long long)q * ldn * M;
-        launch_rbf(dX.d(), P, n, P, dZ.d() + q * P, ldz, M, h_var[q], h_ell[q], kh, false, st);
+        launch_rbf(dX.d(), P, n, P, dZ.d() + q * P, ldz, M, h_var[q], h_ell[q], kh, false, st, nullptr, false);
         GemmArgs g;
         g.A = kh, g.lda = M, g.a_kmajor = 0;
         g.B = C.d() + q * MM, g.ldb = M, g.b_kmajor = 1;

@@ -15,6 +15,16 @@ __device__ __forceinline__ double rbf_r2(const double* x, double xsq, const doub
   const double r = sqrt(r2) / ell;
   return r * r;
 }
+// cheaper scaled squared distance: clip(r2, 0) * (1/l^2), no sqrt / divide
+template <int P>
+__device__ __forceinline__ double rbf_r2_fast(const double* x, double xsq, const double* z, double zsq, double inv_l2) {
+#pragma clang fp contract(off)
+  double dot = x[0] * z[0];
+#pragma unroll
+  for (int p = 1; p < P; ++p) dot = dot + x[p] * z[p];
+  const double r2 = -2.0 * dot + (xsq + zsq);
+  return fmax(r2, 0.0) * inv_l2;
+}
 template <int P>
 __device__ __forceinline__ double sumsq(const double* x) {
 #pragma clang fp contract(off)

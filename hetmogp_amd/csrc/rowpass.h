@@ -45,7 +45,8 @@ void launch_predictive(int lik, int J, int Jp, double param, int T, long long N,
 void launch_log_predictive(int lik, int J, double param, long long N, int S, unsigned long long seed, const double* y,
                            const double* m, const double* v, double* out, hipStream_t s);
 void launch_rbf(const double* X, int ldx, long long N, int P, const double* Z, int ldz, int M, double var, double ell,
-                double* K, bool same, hipStream_t s, const int* rowwin = nullptr);
+                double* K, bool same, hipStream_t s, const int* rowwin = nullptr, bool exact = true);
+void launch_reduce_slabs_lower(const double* slabs, int nslabs, int M, double* dst, bool accumulate, hipStream_t s);
 // exact-zero windows of K^ = k(X, Z) for one (row chunk, latent): rowwin [tiles][2] column range per 128-row tile,
 // colwin [ncb][2] row range per 128-column block, hit [tiles][ncb] scratch (see rowpass.hip)
 void launch_windows(const double* X, long long N, int P, const double* Z, int ldz, int M, double ell, int* rowwin, int* colwin,

@@ -15,7 +15,10 @@ namespace {
 
 constexpr int RBF_ROWS = 32;  // rows per block; 256 threads x 2 columns = 512 columns per block
 
-template <int P>
+// EXACT = GPy's rounding order r = sqrt(clip(r2))/l; K = s2 exp(-0.5 r*r)   (used for K_uu, whose inverse amplifies
+// rounding);  !EXACT = s2 exp(-0.5 clip(r2) * (1/l^2)): no sqrt / divide per element -- the K_uf kernel is otherwise bound
+// by the FP64 VALU (sqrt + divide cost as much as the exp), not by HBM.  The two differ by <= 2 ulp of the exponent.
+template <int P, bool EXACT>
 __global__ __launch_bounds__(256) void rbf_kernel(const double* __restrict__ X, int ldx, long long N,
                                                   const double* __restrict__ Z, int ldz, int M, double var, double ell,
                                                   double* __restrict__ K, int same, const int* __restrict__ rowwin) {
@@ -55,7 +58,13 @@ __global__ __launch_bounds__(256) void rbf_kernel(const double* __restrict__ X, 
 #pragma unroll
     for (int p = 0; p < P; ++p) xv[p] = xs[r][p];
     const double xsq = xs[r][P];
-    double r20 = rbf_r2<P>(xv, xsq, z0, zs0, ell), r21 = rbf_r2<P>(xv, xsq, z1, zs1, ell);
+    double r20, r21;
+    if (EXACT) {
+      r20 = rbf_r2<P>(xv, xsq, z0, zs0, ell), r21 = rbf_r2<P>(xv, xsq, z1, zs1, ell);
+    } else {
+      const double il2 = 1.0 / (ell * ell);
+      r20 = rbf_r2_fast<P>(xv, xsq, z0, zs0, il2), r21 = rbf_r2_fast<P>(xv, xsq, z1, zs1, il2);
+    }
     if (same) {  // GPy's X2=None branch forces the diagonal distance to 0 (kern/stationary)
       if (n0 + r == c) r20 = 0.0;
       if (n0 + r == c + 1) r21 = 0.0;
@@ -361,6 +370,36 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const double* __restr
   for (int b = 0; b < nslabs; ++b) s += slabs[b * stride + i];
   dst[i] = accumulate ? dst[i] + s : s;
 }
+// dst[i][j] (+)= sum_s slabs[s][i][j] over the LOWER 128 x 128 tiles only (the Gram product never writes the others)
+__global__ __launch_bounds__(256) void reduce_slabs_lower_kernel(const double* __restrict__ slabs, int nslabs, int M,
+                                                                 double* __restrict__ dst, int accumulate) {
+  int v = blockIdx.x, ti = (int)((sqrt(8.0 * (double)v + 1.0) - 1.0) * 0.5);
+  while ((ti + 1) * (ti + 2) / 2 <= v) ++ti;
+  while (ti * (ti + 1) / 2 > v) --ti;
+  const int tj = v - ti * (ti + 1) / 2;
+  const long long MM = (long long)M * M;
+  const int c2 = (threadIdx.x & 63) * 2, r4 = threadIdx.x >> 6;  // 64 lanes x 2 columns; block = 4 rows (blockIdx.y)
+  const int col = tj * 128 + c2;
+  if (col >= M) return;
+  const bool two = col + 1 < M, vec = two && ((M & 1) == 0);
+  {
+    const int row = ti * 128 + blockIdx.y * 4 + r4;
+    if (row >= M) return;
+    const long long off = (long long)row * M + col;
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = 0; b < nslabs; ++b) {
+      if (vec) {
+        const f64x2 x = *reinterpret_cast<const f64x2*>(slabs + b * MM + off);
+        s0 += x.x, s1 += x.y;
+      } else {
+        s0 += slabs[b * MM + off];
+        if (two) s1 += slabs[b * MM + off + 1];
+      }
+    }
+    dst[off] = accumulate ? dst[off] + s0 : s0;
+    if (two) dst[off + 1] = accumulate ? dst[off + 1] + s1 : s1;
+  }
+}
 // lower tiles of H were computed: mirror to the upper triangle
 __global__ void mirror_lower_kernel(double* __restrict__ A, int M, long long stride) {
   double* a = A + (long long)blockIdx.z * stride;
@@ -488,10 +527,16 @@ void launch_windows(const double* X, long long N, int P, const double* Z, int ld
 }
 
 void launch_rbf(const double* X, int ldx, long long N, int P, const double* Z, int ldz, int M, double var, double ell,
-                double* K, bool same, hipStream_t s, const int* rowwin) {
+                double* K, bool same, hipStream_t s, const int* rowwin, bool exact) {
   if (N <= 0 || M <= 0) return;
   dim3 grid((unsigned)((N + RBF_ROWS - 1) / RBF_ROWS), (M + 511) / 512);
-  DISPATCH_P(P, hipLaunchKernelGGL((rbf_kernel<PP>), grid, dim3(256), 0, s, X, ldx, N, Z, ldz, M, var, ell, K, same ? 1 : 0, rowwin));
+  if (exact) {
+    DISPATCH_P(P, hipLaunchKernelGGL((rbf_kernel<PP, true>), grid, dim3(256), 0, s, X, ldx, N, Z, ldz, M, var, ell, K,
+                                     same ? 1 : 0, rowwin));
+  } else {
+    DISPATCH_P(P, hipLaunchKernelGGL((rbf_kernel<PP, false>), grid, dim3(256), 0, s, X, ldx, N, Z, ldz, M, var, ell, K,
+                                     same ? 1 : 0, rowwin));
+  }
 }
 
 long long quad_blocks(int lik, long long N) { return (N * lik_lanes(lik) + 255) / 256; }
@@ -589,6 +634,12 @@ void launch_reduce_slabs(const double* slabs, int nslabs, long long stride, long
   if (len <= 0) return;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, slabs, nslabs, stride, len,
                      dst, accumulate ? 1 : 0);
+}
+
+void launch_reduce_slabs_lower(const double* slabs, int nslabs, int M, double* dst, bool accumulate, hipStream_t s) {
+  const int tiles = (M + 127) / 128;
+  hipLaunchKernelGGL(reduce_slabs_lower_kernel, dim3(tiles * (tiles + 1) / 2, 32), dim3(256), 0, s, slabs, nslabs, M, dst,
+                     accumulate ? 1 : 0);
 }
 
 void launch_mirror_lower(double* A, int Q, int M, long long stride, hipStream_t s) {

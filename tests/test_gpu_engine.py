@@ -341,3 +341,58 @@ def test_exact_zero_windows_headline_shape():
     win = run(e, prm)
     for k in KEYS:
         assert rel(win[k], dense[k]) < 1e-10, k
+
+
+@pytest.mark.slow
+def test_config5_like_2d_M2048_vs_oracle():
+    """BASELINE config 5 shape: P = 2, M = 2048 (16 x 16 GEMM tiles), Q = 2, [Categorical(4), Gaussian], plus prediction
+    on a grid (predict_f = predictive_new) and the per-likelihood predictive moments."""
+    from oracle import svmogp_oracle as so
+    from oracle import likelihoods_oracle as lo
+    from hetmogp_amd import engine as E
+    specs = [("Categorical", {"K": 4}), ("Gaussian", {"sigma": 0.5})]
+    prm, prob, X, Y = synth(41, specs, [1500, 2000], 2048, 2, 2, (0.9, 1.1))
+    want = so.elbo_grad_fused(prm, prob, X, Y)
+    assert want["rungs"] == [-1, -1]
+    e = make_engine(prob, X, Y)
+    out = run(e, prm)
+    for k in KEYS:
+        assert rel(out[k], want[k]) < 1e-7, k
+    g = np.stack(np.meshgrid(np.linspace(0, 1, 24), np.linspace(0, 1, 24), indexing="ij"), -1).reshape(-1, 2)
+    m, v = e.predict_f(g)
+    u = so.u_algebra(prm, prob)
+    for d in range(prob["Df"]):
+        md, vd = np.zeros(len(g)), np.zeros(len(g))
+        for q in range(2):
+            K = so.rbf_K(g, prm["Z"][:, 2 * q:2 * q + 2], prm["variance"][q], prm["lengthscale"][q])
+            w = prm["W"][q, d]
+            md += w * (K @ u["a"][q])
+            vd += (w * w + prm["kappa"][q, d]) * prm["variance"][q] + w * w * np.sum((K @ u["C"][q]) * K, 1)
+        assert rel(m[:, d], md) < 1e-7 and rel(v[:, d], vd) < 1e-7
+    mp, vp = E.predictive("Categorical", m[:, :3], np.abs(v[:, :3]), K=4)
+    wm, wv = lo.predictive("Categorical", m[:, :3], np.abs(v[:, :3]), K=4)
+    assert rel(mp, wm) < 1e-9 and np.allclose(mp.sum(1), 1.0)
+
+
+@pytest.mark.slow
+def test_config4_like_eight_likelihoods_Q4_vs_oracle():
+    """BASELINE config 4 mix: T = 8 [HetGaussian, Categorical(5), Beta, Exponential, Gaussian, Bernoulli, Poisson, Gamma],
+    Df = 14, Q = 4, two row shards combined through the statistic bundle."""
+    from oracle import svmogp_oracle as so
+    specs = [("HetGaussian", {}), ("Categorical", {"K": 5}), ("Beta", {}), ("Exponential", {}), ("Gaussian", {"sigma": 0.5}),
+             ("Bernoulli", {}), ("Poisson", {}), ("Gamma", {})]
+    Ns = [400, 150, 300, 250, 500, 350, 300, 200]
+    prm, prob, X, Y = synth(42, specs, Ns, 160, 4, 1, (0.8, 1.0, 1.3, 1.1))
+    assert prob["Df"] == 14
+    want = so.elbo_grad_fused(prm, prob, X, Y)
+    e = make_engine(prob, X, Y)
+    args = dict(Z=prm["Z"], m_u=prm["m_u"], L_flat=prm["L_flat"], variance=prm["variance"], lengthscale=prm["lengthscale"],
+                W=prm["W"], kappa=prm["kappa"])
+    cut = [n // 2 for n in Ns]
+    e.step_begin(row_begin=[0] * 8, row_end=cut, **args)
+    s1 = e.stats_read()
+    e.step_begin(row_begin=cut, row_end=Ns, **args)
+    e.stats_write(s1 + e.stats_read())
+    out = e.step_finish()
+    for k in KEYS:
+        assert rel(out[k], want[k]) < TOL, k
