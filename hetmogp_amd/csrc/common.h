@@ -73,12 +73,14 @@ struct GemmArgs {
   // pass over K^ and P~):  for every row n of the tile and this block's 128 columns j
   //   p += K^_nj a_j,  c += P~_nj K^_nj,  pt += K^_nj a_j r2_nj,  ct += P~_nj K^_nj r2_nj      (r2 = |x_n - z_j|^2 / l^2)
   // written as per-column-tile partials fs_part[stat][tile_col][n]; launch_combine_parts sums the column tiles.
+  // Batched over the latents (nbatch): fs_part / fs_a / fs_z / fs_ell / win advance by their strides per batch.
   double* fs_part = nullptr;
-  const double* fs_a = nullptr;  // [N]      a = Kuu^-1 m
-  const double* fs_x = nullptr;  // [M][P]   inputs of the rows
-  const double* fs_z = nullptr;  // inducing inputs of this latent, row stride fs_ldz
+  const double* fs_a = nullptr;    // [N]      a = Kuu^-1 m                         (+ batch * fs_sA)
+  const double* fs_x = nullptr;    // [M][P]   inputs of the rows (shared by the batch)
+  const double* fs_z = nullptr;    // inducing inputs of the latent, row stride fs_ldz (+ batch * fs_sZ)
+  const double* fs_ell = nullptr;  // [nbatch] lengthscales (device)
   int fs_ldz = 0, fs_P = 1, fs_hyper = 0;
-  double fs_ell = 1.0;
+  long long fs_sPart = 0, fs_sA = 0, fs_sZ = 0;
   int store_c = 1;               // 0: do not write P~ at all (no consumer when the Z gradient is not requested)
   // Exact-zero windows (rowpass.hip: launch_windows): K^ = s2 exp(-r2/2) underflows to exactly 0.0 beyond r ~ 38.6
   // lengthscales, so for spatially sorted rows it is banded.  role 1: win[2*ti], win[2*ti+1] = [lo, hi) column range
@@ -87,10 +89,12 @@ struct GemmArgs {
   // block b is exactly zero -> the K loop of tile (i,j) runs over the intersection.  Skipped terms are products with
   // exact zeros, so results are unchanged.  nullptr = dense.
   const int* win = nullptr;
+  long long win_stride = 0;  // ints per batch
 };
 // p[n] = sum_t part[0][t][n], c <- part[1], pt <- part[2], ct <- part[3]   (pt/ct may be nullptr)
+// batched over nb latents: part + b*sPart, outputs + b*ldn
 void launch_combine_parts(const double* part, int tiles, long long n, double* p, double* c, double* pt, double* ct,
-                          hipStream_t s);
+                          hipStream_t s, int nb = 1, long long sPart = 0, long long ldn = 0);
 void launch_gemm_f64(const GemmArgs& g, hipStream_t stream);
 
 // ---- linear algebra on Q x M x M batches (linalg.hip) ---------------------------------------------------

@@ -50,7 +50,10 @@ struct DevBuf {
     release();
     HIP_TRY(hipMalloc(&p, b));
     bytes = b;
-    if (zero) HIP_TRY(hipMemset(p, 0, b));
+    if (zero) {  // the engine's stream is non-blocking: make the null-stream memset visible before any kernel uses p
+      HIP_TRY(hipMemset(p, 0, b));
+      HIP_TRY(hipDeviceSynchronize());
+    }
   }
   double* d() const { return static_cast<double*>(p); }
   template <class T>
@@ -312,9 +315,9 @@ struct hmogp_engine {
     const size_t nm = sizeof(double) * rows * M * Q, nv = sizeof(double) * rows * Q;
     Kh.ensure(nm), Pt.ensure(nm);
     for (DevBuf* b : {&vp, &vc, &vpt, &vct, &valpha, &vbeta, &valpha0, &vbeta0}) b->ensure(nv, true);
-    colpart.ensure(sizeof(double) * ((rows + 255) / 256) * M * (1 + P));
+    colpart.ensure(sizeof(double) * ((rows + 255) / 256) * M * (1 + P) * Q);
     quadpart.ensure(sizeof(double) * (rows * 64 / 256 + 1) * HMOGP_MAXSCAL);
-    fwdpart.ensure(sizeof(double) * 4 * ((M + 127) / 128) * rows);
+    fwdpart.ensure(sizeof(double) * 4 * ((M + 127) / 128) * rows * Q);
     if (use_windows) {
       const size_t tiles = (rows + 127) / 128, ncb = (M + 127) / 128;
       winrow.ensure(sizeof(int) * 2 * tiles * Q), wincol.ensure(sizeof(int) * 2 * ncb * Q), winhit.ensure(tiles * ncb);
@@ -410,34 +413,40 @@ struct hmogp_engine {
       for (long long r0 = rb[t]; r0 < re[t]; r0 += chunk) {
         const long long n = std::min(chunk, re[t] - r0);
         const double* X = k.X.d() + r0 * P;
-        for (int q = 0; q < Q; ++q) {
-          double* kh = Kh.d() + (long long)q * ldn * M;
-          double* pt = Pt.d() + (long long)q * ldn * M;
-          int* rw = use_windows ? winrow.as<int>() + 2 * wtiles * q : nullptr;
-          int* cw = use_windows ? wincol.as<int>() + 2 * ((M + 127) / 128) * q : nullptr;
-          {
-            Scope sc(this, CAT_RBF, use_windows ? 4 : 1);
-            if (use_windows) launch_windows(X, n, P, dZ.d() + q * P, ldz, M, h_ell[q], rw, cw, winhit.as<unsigned char>(), st);
-            launch_rbf(X, P, n, P, dZ.d() + q * P, ldz, M, h_var[q], h_ell[q], kh, false, st, rw, false);
-          }
-          {
-            // forward contraction with the row statistics fused into its epilogue; P~ itself is only stored when the
-            // Z gradient (its one remaining consumer, colstats) is requested
-            Scope sc(this, CAT_FWD, 2);
-            GemmArgs g;
-            g.A = kh, g.lda = M, g.a_kmajor = 0;
-            g.B = C.d() + q * MM, g.ldb = M, g.b_kmajor = 1;
-            g.C = pt, g.ldc = M;
-            g.M = (int)n, g.N = M, g.K = M;
-            g.role = 1;
-            g.fs_part = fwdpart.d(), g.fs_a = a.d() + (long long)q * M, g.fs_x = X, g.fs_z = dZ.d() + q * P;
-            g.fs_ldz = ldz, g.fs_P = P, g.fs_hyper = want_hyper ? 1 : 0, g.fs_ell = h_ell[q];
-            g.store_c = want_z ? 1 : 0;
-            g.win = rw;
-            launch_gemm_f64(g, st);
-            launch_combine_parts(fwdpart.d(), (M + 127) / 128, n, vp.d() + q * ldn, vc.d() + q * ldn,
-                                 want_hyper ? vpt.d() + q * ldn : nullptr, want_hyper ? vct.d() + q * ldn : nullptr, st);
-          }
+        const long long sK = ldn * M;                       // per-latent stride of the K^ / P~ workspaces
+        const int ncb = (M + 127) / 128;
+        int* rw = use_windows ? winrow.as<int>() : nullptr;  // [Q][wtiles][2]
+        int* cw = use_windows ? wincol.as<int>() : nullptr;  // [Q][ncb][2]
+        {
+          // K_uf for all latents in one launch (grid.z = latent)
+          Scope sc(this, CAT_RBF, use_windows ? 1 + 3 * Q : 1);
+          if (use_windows)
+            for (int q = 0; q < Q; ++q)
+              launch_windows(X, n, P, dZ.d() + q * P, ldz, M, h_ell[q], rw + 2 * wtiles * q, cw + 2 * ncb * q,
+                             winhit.as<unsigned char>(), st);
+          RbfBatch rbt;
+          rbt.nq = Q, rbt.var = dvar.d(), rbt.ell = dell.d(), rbt.sZ = P, rbt.sK = sK, rbt.sWin = 2 * wtiles;
+          launch_rbf(X, P, n, P, dZ.d(), ldz, M, 0.0, 1.0, Kh.d(), false, st, rw, false, &rbt);
+        }
+        {
+          // forward contraction for all latents (batched), row statistics fused into its epilogue; P~ itself is only
+          // stored when the Z gradient (its one remaining consumer, colstats) is requested
+          Scope sc(this, CAT_FWD, 2);
+          const long long sPart = 4LL * tiles * ldn;
+          GemmArgs g;
+          g.A = Kh.d(), g.lda = M, g.a_kmajor = 0, g.sA = sK;
+          g.B = C.d(), g.ldb = M, g.b_kmajor = 1, g.sB = MM;
+          g.C = Pt.d(), g.ldc = M, g.sC = sK;
+          g.M = (int)n, g.N = M, g.K = M;
+          g.nbatch = Q;
+          g.role = 1;
+          g.fs_part = fwdpart.d(), g.fs_sPart = sPart, g.fs_a = a.d(), g.fs_sA = M, g.fs_x = X;
+          g.fs_z = dZ.d(), g.fs_sZ = P, g.fs_ldz = ldz, g.fs_P = P, g.fs_hyper = want_hyper ? 1 : 0, g.fs_ell = dell.d();
+          g.store_c = want_z ? 1 : 0;
+          g.win = rw, g.win_stride = 2 * wtiles;
+          launch_gemm_f64(g, st);
+          launch_combine_parts(fwdpart.d(), tiles, n, vp.d(), vc.d(), want_hyper ? vpt.d() : nullptr,
+                               want_hyper ? vct.d() : nullptr, st, Q, sPart, ldn);
         }
         {
           Scope sc(this, CAT_QUAD, 2);
@@ -464,34 +473,32 @@ struct hmogp_engine {
           launch_quad(qa, st);
           launch_reduce_rows(quadpart.d(), quad_blocks(k.lik, n), k.nscal, k.offsets.as<long long>(), stats.d(), true, st);
         }
-        for (int q = 0; q < Q; ++q) {
-          const double* kh = Kh.d() + (long long)q * ldn * M;
-          const double* pt = Pt.d() + (long long)q * ldn * M;
-          const int* cw = use_windows ? wincol.as<int>() + 2 * ((M + 127) / 128) * q : nullptr;
-          {
-            Scope sc(this, CAT_GRAM, 2);  // H_q += K^T diag(beta) K^   (svmogp_inf.py:145-147 summed over d)
-            const int ksplit = use_windows ? std::min(8, gram_ksplit(n, M)) : gram_ksplit(n, M);
-            slabs.ensure(sizeof(double) * MM * 64, true);
-            GemmArgs g;
-            g.A = kh, g.lda = M, g.a_kmajor = 1;
-            g.B = kh, g.ldb = M, g.b_kmajor = 1;
-            g.kscale = vbeta.d() + q * ldn;
-            g.C = slabs.d(), g.ldc = M;
-            g.M = g.N = M, g.K = (int)n;
-            g.lower_only = 1;
-            g.ksplit = ksplit, g.sSplit = MM;
-            g.role = 2;
-            g.win = cw;
-            launch_gemm_f64(g, st);
-            launch_reduce_slabs_lower(slabs.d(), ksplit, M, Hq(q), true, st);
-          }
-          {
-            Scope sc(this, CAT_COLSTATS, 2);
-            const long long len = (long long)M * (1 + P);
-            launch_colstats(kh, pt, a.d() + (long long)q * M, valpha.d() + q * ldn, valpha0.d() + q * ldn,
-                            vbeta0.d() + q * ldn, X, P, dZ.d() + q * P, ldz, n, M, 256, want_z, colpart.d(), st, cw);
-            launch_reduce_slabs(colpart.d(), (int)((n + 255) / 256), len, len, Hq(q) + oR, true, st);
-          }
+        {
+          Scope sc(this, CAT_GRAM, 2);  // H_q += K^T diag(beta) K^ for all latents (svmogp_inf.py:145-147 summed over d)
+          const int ksplit = use_windows ? std::min(8, gram_ksplit(n, M)) : gram_ksplit(n, M);
+          slabs.ensure(sizeof(double) * MM * 64 * Q, true);
+          GemmArgs g;
+          g.A = Kh.d(), g.lda = M, g.a_kmajor = 1, g.sA = sK;
+          g.B = Kh.d(), g.ldb = M, g.b_kmajor = 1, g.sB = sK;
+          g.kscale = vbeta.d(), g.sS = ldn;
+          g.C = slabs.d(), g.ldc = M, g.sC = MM * 64;
+          g.M = g.N = M, g.K = (int)n;
+          g.nbatch = Q;
+          g.lower_only = 1;
+          g.ksplit = ksplit, g.sSplit = MM;
+          g.role = 2;
+          g.win = cw, g.win_stride = 2 * ncb;
+          launch_gemm_f64(g, st);
+          launch_reduce_slabs_lower(slabs.d(), ksplit, M, Hq(0), true, st, Q, MM * 64, per_q);
+        }
+        {
+          Scope sc(this, CAT_COLSTATS, 2);
+          const long long len = (long long)M * (1 + P), nsp = (n + 255) / 256;
+          ColBatch cb;
+          cb.nq = Q, cb.sK = sK, cb.sA = M, cb.sV = ldn, cb.sZ = P, cb.sPart = nsp * len, cb.sWin = 2 * ncb;
+          launch_colstats(Kh.d(), Pt.d(), a.d(), valpha.d(), valpha0.d(), vbeta0.d(), X, P, dZ.d(), ldz, n, M, 256, want_z,
+                          colpart.d(), st, cw, &cb);
+          launch_reduce_slabs(colpart.d(), (int)nsp, len, len, Hq(0) + oR, true, st, Q, nsp * len, per_q);
         }
       }
     }
@@ -690,7 +697,7 @@ struct hmogp_engine {
         g.M = (int)n, g.N = M, g.K = M;
         g.role = 1;
         g.fs_part = fwdpart.d(), g.fs_a = a.d() + (long long)q * M, g.fs_x = dX.d(), g.fs_z = dZ.d() + q * P;
-        g.fs_ldz = ldz, g.fs_P = P, g.fs_hyper = 0, g.fs_ell = h_ell[q];
+        g.fs_ldz = ldz, g.fs_P = P, g.fs_hyper = 0, g.fs_ell = dell.d() + q;
         g.store_c = 0;
         launch_gemm_f64(g, st);
         launch_combine_parts(fwdpart.d(), (M + 127) / 128, n, vp.d() + q * ldn, vc.d() + q * ldn, nullptr, nullptr, st);

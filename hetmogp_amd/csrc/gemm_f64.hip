@@ -137,18 +137,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
   const int i0 = ti * BM, j0 = tj * BN;
   if (i0 >= M || j0 >= N) return;
   int wlo = 0, whi = K;
-  if (ROLE == 1 && g.win) {  // exact-zero window of this row tile (see GemmArgs::win)
-    wlo = g.win[2 * ti], whi = min(K, g.win[2 * ti + 1]);
+  const int* win = g.win ? g.win + (long long)batch * g.win_stride : nullptr;
+  double* fs_part = g.fs_part ? g.fs_part + (long long)batch * g.fs_sPart : nullptr;
+  if (ROLE == 1 && win) {  // exact-zero window of this row tile (see GemmArgs::win)
+    wlo = win[2 * ti], whi = min(K, win[2 * ti + 1]);
     if (j0 >= whi || j0 + BN <= wlo) {  // no consumer ever reads this P~ tile: its statistics are exact zeros
-      if (g.fs_part && threadIdx.x < 128 && i0 + (int)threadIdx.x < M)
+      if (fs_part && threadIdx.x < 128 && i0 + (int)threadIdx.x < M)
         for (int st = 0; st < (g.fs_hyper ? 4 : 2); ++st)
-          g.fs_part[((long long)st * tiles_n + tj) * M + (i0 + threadIdx.x)] = 0.0;
+          fs_part[((long long)st * tiles_n + tj) * M + (i0 + threadIdx.x)] = 0.0;
       return;
     }
   }
-  if (ROLE == 2 && g.win) {
-    wlo = max(g.win[2 * ti], g.win[2 * tj]);
-    whi = max(wlo, min(K, min(g.win[2 * ti + 1], g.win[2 * tj + 1])));
+  if (ROLE == 2 && win) {
+    wlo = max(win[2 * ti], win[2 * tj]);
+    whi = max(wlo, min(K, min(win[2 * ti + 1], win[2 * tj + 1])));
   }
   const int ksteps = (whi - wlo + BK - 1) / BK;
   const int per = (ksteps + g.ksplit - 1) / g.ksplit;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
 
   // ---- epilogue: D fragment of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg -----------
   const double alpha = g.alpha, beta = (g.ksplit > 1) ? 0.0 : g.beta;
-  if (ROLE == 1 && g.fs_part) {
+  if (ROLE == 1 && fs_part) {
     // fused row statistics (see GemmArgs): the block's P~ tile is in registers, its K^ tile is re-read (L2/MALL-warm)
     const int P = g.fs_P;
     double av[4], zv[4][4], zsq[4];
@@ -256,11 +258,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
     for (int b = 0; b < 4; ++b) {
       const int col = j0 + wn * 64 + b * 16 + lr;
       const bool ok = col < N;
-      av[b] = ok ? g.fs_a[col] : 0.0;
+      av[b] = ok ? g.fs_a[(long long)batch * g.fs_sA + col] : 0.0;
       zsq[b] = 0.0;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        zv[b][p] = (ok && p < P) ? g.fs_z[(long long)col * g.fs_ldz + p] : 0.0;
+        zv[b][p] = (ok && p < P) ? g.fs_z[(long long)batch * g.fs_sZ + (long long)col * g.fs_ldz + p] : 0.0;
         zsq[b] += zv[b][p] * zv[b][p];
       }
     }
@@ -275,7 +277,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
       const int rr = e >> 2, p = e & 3;
       xs[e] = (i0 + rr < M && p < P) ? g.fs_x[(long long)(i0 + rr) * P + p] : 0.0;
     }
-    const double inv_l2 = 1.0 / (g.fs_ell * g.fs_ell);
+    const double ell_b = g.fs_ell[batch];
+    const double inv_l2 = 1.0 / (ell_b * ell_b);
     const bool vecK = ((g.lda & 1) == 0) && ((((uintptr_t)A) & 15) == 0) && (j0 + BN <= N);
 #pragma unroll 1
     for (int a = 0; a < 4; ++a) {
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
     if (t < 128 && i0 + t < M) {
       const int nst = g.fs_hyper ? 4 : 2;
       for (int st = 0; st < nst; ++st)
-        g.fs_part[((long long)st * tiles_n + tj) * M + (i0 + t)] = red[t * 4 + st] + red[(128 + t) * 4 + st];
+        fs_part[((long long)st * tiles_n + tj) * M + (i0 + t)] = red[t * 4 + st] + red[(128 + t) * 4 + st];
     }
     if (!g.store_c) return;
   }
@@ -376,10 +379,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
 
 namespace {
 __global__ void combine_parts_kernel(const double* __restrict__ part, int tiles, long long n, double* __restrict__ p,
-                                     double* __restrict__ c, double* __restrict__ pt, double* __restrict__ ct) {
+                                     double* __restrict__ c, double* __restrict__ pt, double* __restrict__ ct,
+                                     long long sPart, long long ldn) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  double* outs[4] = {p, c, pt, ct};
+  part += (long long)blockIdx.y * sPart;
+  const long long ob = (long long)blockIdx.y * ldn;
+  double* outs[4] = {p ? p + ob : nullptr, c ? c + ob : nullptr, pt ? pt + ob : nullptr, ct ? ct + ob : nullptr};
 #pragma unroll
   for (int st = 0; st < 4; ++st) {
     if (!outs[st]) continue;
@@ -391,9 +397,10 @@ __global__ void combine_parts_kernel(const double* __restrict__ part, int tiles,
 }  // namespace
 
 void launch_combine_parts(const double* part, int tiles, long long n, double* p, double* c, double* pt, double* ct,
-                          hipStream_t s) {
+                          hipStream_t s, int nb, long long sPart, long long ldn) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(combine_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, tiles, n, p, c, pt, ct);
+  hipLaunchKernelGGL(combine_parts_kernel, dim3((unsigned)((n + 255) / 256), nb), dim3(256), 0, s, part, tiles, n, p, c, pt,
+                     ct, sPart, ldn);
 }
 
 void launch_gemm_f64(const GemmArgs& g, hipStream_t stream) {

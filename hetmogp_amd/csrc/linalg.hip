@@ -32,24 +32,34 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
     D[r][c] = (r < jb && c <= r) ? A[(long long)(j + r) * M + (j + c)] : 0.0;
   }
   __syncthreads();
-  for (int c = 0; c < jb; ++c) {
-    if (t == 0) {
-      const double d = D[c][c];
-      if (!(d > 0.0)) fail = c + 1;  // LAPACK: ajj <= 0 or NaN
-      else D[c][c] = sqrt(d);
+  // The diagonal block is factorised by the first wave entirely in registers: lane r owns row r (32 doubles); column c
+  // needs the pivot from lane c and, for the rank-1 update, the scaled column entries L[c2][c] from lanes c2 -- both by
+  // wavefront shuffles (about 530 of them for the whole block), no LDS round trips or barriers inside the recurrence.
+  if (t < 64) {
+    const int r = t & 31;  // lanes 32..63 mirror lanes 0..31 (shuffles stay within the wave)
+    double a[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) a[c] = D[r][c];
+    int bad = 0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      const double d = __shfl(a[c], c, 64);
+      if (c < jb && !bad && !(d > 0.0)) bad = c + 1;  // LAPACK: ajj <= 0 or NaN (uniform across lanes)
+      const double piv = sqrt(d);
+      const double l = (r == c) ? piv : ((r > c) ? a[c] / piv : a[c]);
+      a[c] = l;
+#pragma unroll
+      for (int c2 = c + 1; c2 < NB; ++c2) {
+        const double lc2 = __shfl(l, c2, 64);
+        if (r >= c2) a[c2] -= l * lc2;
+      }
     }
-    __syncthreads();
-    if (fail) break;
-    const double piv = D[c][c];
-    if (t > c && t < jb) D[t][c] /= piv;
-    __syncthreads();
-    // trailing update of the lower triangle: (r, c2) with c < c2 <= r < jb
-    for (int e = t; e < jb * jb; e += blockDim.x) {
-      const int r = e / jb, c2 = e % jb;
-      if (c2 > c && c2 <= r) D[r][c2] -= D[r][c] * D[c2][c];
-    }
-    __syncthreads();
+    if (t < jb)
+#pragma unroll
+      for (int c = 0; c < NB; ++c) D[r][c] = a[c];
+    if (t == 0) fail = bad;
   }
+  __syncthreads();
   if (fail) {
     if (blockIdx.x == 0 && t == 0) info[q] = j + fail;
     return;

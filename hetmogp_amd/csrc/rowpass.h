@@ -33,6 +33,18 @@ struct QuadArgs {
   double* out_v = nullptr;
 };
 
+// per-latent strides of the batched (grid.z = latent) row kernels
+struct RbfBatch {
+  int nq = 1;
+  const double* var = nullptr;  // [nq] device
+  const double* ell = nullptr;  // [nq] device
+  long long sZ = 0, sK = 0, sWin = 0;
+};
+struct ColBatch {
+  int nq = 1;
+  long long sK = 0, sA = 0, sV = 0, sZ = 0, sPart = 0, sWin = 0;
+};
+
 long long quad_blocks(int lik, long long N);
 void launch_quad(const QuadArgs& a, hipStream_t s);
 void launch_var_exp(int lik, int J, double param, long long N, const double* y, const double* m, const double* v, double* ve,
@@ -45,18 +57,20 @@ void launch_predictive(int lik, int J, int Jp, double param, int T, long long N,
 void launch_log_predictive(int lik, int J, double param, long long N, int S, unsigned long long seed, const double* y,
                            const double* m, const double* v, double* out, hipStream_t s);
 void launch_rbf(const double* X, int ldx, long long N, int P, const double* Z, int ldz, int M, double var, double ell,
-                double* K, bool same, hipStream_t s, const int* rowwin = nullptr, bool exact = true);
-void launch_reduce_slabs_lower(const double* slabs, int nslabs, int M, double* dst, bool accumulate, hipStream_t s);
+                double* K, bool same, hipStream_t s, const int* rowwin = nullptr, bool exact = true,
+                const RbfBatch* batch = nullptr);
+void launch_reduce_slabs_lower(const double* slabs, int nslabs, int M, double* dst, bool accumulate, hipStream_t s, int nb = 1,
+                               long long sSlabs = 0, long long sDst = 0);
 // exact-zero windows of K^ = k(X, Z) for one (row chunk, latent): rowwin [tiles][2] column range per 128-row tile,
 // colwin [ncb][2] row range per 128-column block, hit [tiles][ncb] scratch (see rowpass.hip)
 void launch_windows(const double* X, long long N, int P, const double* Z, int ldz, int M, double ell, int* rowwin, int* colwin,
                     unsigned char* hit, hipStream_t s);
 void launch_colstats(const double* Kh, const double* Pt, const double* a, const double* alpha, const double* alpha0,
                      const double* beta0, const double* X, int P, const double* Z, int ldz, long long N, int M, int rows,
-                     bool want_z, double* partials, hipStream_t s, const int* colwin = nullptr);
+                     bool want_z, double* partials, hipStream_t s, const int* colwin = nullptr, const ColBatch* batch = nullptr);
 void launch_reduce_rows(const double* partials, long long nrows, int len, const long long* off, double* dst, bool accumulate,
                         hipStream_t s);
 void launch_reduce_slabs(const double* slabs, int nslabs, long long stride, long long len, double* dst, bool accumulate,
-                         hipStream_t s);
+                         hipStream_t s, int nb = 1, long long sSlabs = 0, long long sDst = 0);
 void launch_mirror_lower(double* A, int Q, int M, long long stride, hipStream_t s);
 void launch_gammaln1p(const double* y, double* out, long long N, hipStream_t s);

@@ -21,7 +21,15 @@ constexpr int RBF_ROWS = 32;  // rows per block; 256 threads x 2 columns = 512 c
 template <int P, bool EXACT>
 __global__ __launch_bounds__(256) void rbf_kernel(const double* __restrict__ X, int ldx, long long N,
                                                   const double* __restrict__ Z, int ldz, int M, double var, double ell,
-                                                  double* __restrict__ K, int same, const int* __restrict__ rowwin) {
+                                                  double* __restrict__ K, int same, const int* __restrict__ rowwin,
+                                                  RbfBatch bt) {
+  if (bt.var) {  // batched over the latents (grid.z): per-latent inducing block, hyper-parameters, output and windows
+    const int q = blockIdx.z;
+    Z += (long long)q * bt.sZ;
+    K += (long long)q * bt.sK;
+    var = bt.var[q], ell = bt.ell[q];
+    if (rowwin) rowwin += (long long)q * bt.sWin;
+  }
   __shared__ double xs[RBF_ROWS][P + 1];
   const int t = threadIdx.x;
   const long long n0 = (long long)blockIdx.x * RBF_ROWS;
@@ -284,7 +292,14 @@ __global__ __launch_bounds__(256) void colstats_kernel(const double* __restrict_
                                                        const double* __restrict__ alpha0, const double* __restrict__ beta0,
                                                        const double* __restrict__ X, const double* __restrict__ Z, int ldz,
                                                        long long N, int M, int rows, int want_z,
-                                                       double* __restrict__ partials, const int* __restrict__ colwin) {
+                                                       double* __restrict__ partials, const int* __restrict__ colwin,
+                                                       ColBatch bt) {
+  {  // batched over the latents (grid.z)
+    const long long q = blockIdx.z;
+    Kh += q * bt.sK, Pt += q * bt.sK, a += q * bt.sA, alpha += q * bt.sV, alpha0 += q * bt.sV, beta0 += q * bt.sV;
+    Z += q * bt.sZ, partials += q * bt.sPart;
+    if (colwin) colwin += q * bt.sWin;
+  }
   const int t = threadIdx.x, c = blockIdx.x * 512 + 2 * t;
   if (c >= M) return;
   const bool two = (c + 1) < M;
@@ -363,16 +378,22 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const double* __restri
 }
 // dst[i] (+)= sum_s slabs[s*stride + i], i < len ; coalesced over i
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const double* __restrict__ slabs, int nslabs, long long stride,
-                                                           long long len, double* __restrict__ dst, int accumulate) {
+                                                           long long len, double* __restrict__ dst, int accumulate,
+                                                           long long sSlabs, long long sDst) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= len) return;
+  slabs += (long long)blockIdx.y * sSlabs;
+  dst += (long long)blockIdx.y * sDst;
   double s = 0.0;
   for (int b = 0; b < nslabs; ++b) s += slabs[b * stride + i];
   dst[i] = accumulate ? dst[i] + s : s;
 }
 // dst[i][j] (+)= sum_s slabs[s][i][j] over the LOWER 128 x 128 tiles only (the Gram product never writes the others)
 __global__ __launch_bounds__(256) void reduce_slabs_lower_kernel(const double* __restrict__ slabs, int nslabs, int M,
-                                                                 double* __restrict__ dst, int accumulate) {
+                                                                 double* __restrict__ dst, int accumulate, long long sSlabs,
+                                                                 long long sDst) {
+  slabs += (long long)blockIdx.z * sSlabs;
+  dst += (long long)blockIdx.z * sDst;
   int v = blockIdx.x, ti = (int)((sqrt(8.0 * (double)v + 1.0) - 1.0) * 0.5);
   while ((ti + 1) * (ti + 2) / 2 <= v) ++ti;
   while (ti * (ti + 1) / 2 > v) --ti;
@@ -527,15 +548,16 @@ void launch_windows(const double* X, long long N, int P, const double* Z, int ld
 }
 
 void launch_rbf(const double* X, int ldx, long long N, int P, const double* Z, int ldz, int M, double var, double ell,
-                double* K, bool same, hipStream_t s, const int* rowwin, bool exact) {
+                double* K, bool same, hipStream_t s, const int* rowwin, bool exact, const RbfBatch* batch) {
   if (N <= 0 || M <= 0) return;
-  dim3 grid((unsigned)((N + RBF_ROWS - 1) / RBF_ROWS), (M + 511) / 512);
+  RbfBatch bt = batch ? *batch : RbfBatch{};
+  dim3 grid((unsigned)((N + RBF_ROWS - 1) / RBF_ROWS), (M + 511) / 512, batch ? batch->nq : 1);
   if (exact) {
     DISPATCH_P(P, hipLaunchKernelGGL((rbf_kernel<PP, true>), grid, dim3(256), 0, s, X, ldx, N, Z, ldz, M, var, ell, K,
-                                     same ? 1 : 0, rowwin));
+                                     same ? 1 : 0, rowwin, bt));
   } else {
     DISPATCH_P(P, hipLaunchKernelGGL((rbf_kernel<PP, false>), grid, dim3(256), 0, s, X, ldx, N, Z, ldz, M, var, ell, K,
-                                     same ? 1 : 0, rowwin));
+                                     same ? 1 : 0, rowwin, bt));
   }
 }
 
@@ -616,11 +638,12 @@ void launch_log_predictive(int lik, int J, double param, long long N, int S, uns
 
 void launch_colstats(const double* Kh, const double* Pt, const double* a, const double* alpha, const double* alpha0,
                      const double* beta0, const double* X, int P, const double* Z, int ldz, long long N, int M, int rows,
-                     bool want_z, double* partials, hipStream_t s, const int* colwin) {
+                     bool want_z, double* partials, hipStream_t s, const int* colwin, const ColBatch* batch) {
   if (N <= 0) return;
-  dim3 grid((M + 511) / 512, (unsigned)((N + rows - 1) / rows));
+  ColBatch bt = batch ? *batch : ColBatch{};
+  dim3 grid((M + 511) / 512, (unsigned)((N + rows - 1) / rows), batch ? batch->nq : 1);
   DISPATCH_P(P, hipLaunchKernelGGL((colstats_kernel<PP>), grid, dim3(256), 0, s, Kh, Pt, a, alpha, alpha0, beta0, X, Z, ldz,
-                                   N, M, rows, want_z ? 1 : 0, partials, colwin));
+                                   N, M, rows, want_z ? 1 : 0, partials, colwin, bt));
 }
 
 void launch_reduce_rows(const double* partials, long long nrows, int len, const long long* off, double* dst, bool accumulate,
@@ -630,16 +653,17 @@ void launch_reduce_rows(const double* partials, long long nrows, int len, const 
 }
 
 void launch_reduce_slabs(const double* slabs, int nslabs, long long stride, long long len, double* dst, bool accumulate,
-                         hipStream_t s) {
+                         hipStream_t s, int nb, long long sSlabs, long long sDst) {
   if (len <= 0) return;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, slabs, nslabs, stride, len,
-                     dst, accumulate ? 1 : 0);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((len + 255) / 256), nb), dim3(256), 0, s, slabs, nslabs, stride, len,
+                     dst, accumulate ? 1 : 0, sSlabs, sDst);
 }
 
-void launch_reduce_slabs_lower(const double* slabs, int nslabs, int M, double* dst, bool accumulate, hipStream_t s) {
+void launch_reduce_slabs_lower(const double* slabs, int nslabs, int M, double* dst, bool accumulate, hipStream_t s, int nb,
+                               long long sSlabs, long long sDst) {
   const int tiles = (M + 127) / 128;
-  hipLaunchKernelGGL(reduce_slabs_lower_kernel, dim3(tiles * (tiles + 1) / 2, 32), dim3(256), 0, s, slabs, nslabs, M, dst,
-                     accumulate ? 1 : 0);
+  hipLaunchKernelGGL(reduce_slabs_lower_kernel, dim3(tiles * (tiles + 1) / 2, 32, nb), dim3(256), 0, s, slabs, nslabs, M, dst,
+                     accumulate ? 1 : 0, sSlabs, sDst);
 }
 
 void launch_mirror_lower(double* A, int Q, int M, long long stride, hipStream_t s) {
