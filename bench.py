@@ -105,7 +105,8 @@ def main():
     if rank == 0:
         rows_rank = sum(e - b for b, e in zip(rb, re))          # rows this rank streamed per step (all tasks)
         pairs_rows = rows_rank * Q                               # (row, latent) pairs per step
-        # dominant kernel: forward contraction, 2*n*M*M algorithmic flops per launch
+        # dominant kernel: forward contraction; one launch = all Q latents of one task chunk = 2*n*M*M*Q algorithmic
+        # flops; the category holds exactly that kernel, so cat_ms / launches = its average duration
         fwd_flops = 2.0 * pairs_rows * M * M * args.steps
         fwd_s = cat_ms["forward_gemm"] / 1e3
         achieved = fwd_flops / fwd_s / 1e12 if fwd_s > 0 else 0.0
@@ -133,11 +134,11 @@ def main():
             "config": {"workload": "H: T=4 [Gaussian,Bernoulli,Poisson,Gamma] Df=5, N_t=%d rows/task, M=%d, Q=%d, P=1, "
                                    "full-batch ELBO+gradients" % (N, M, Q),
                        "rows_per_task": N, "M": M, "Q": Q, "T": T, "sharding": "rows/%d" % world},
-            "roofline": {"kernel": "gemm_f64_kernel<false,true> (forward P~ = K^ C_q)", "bound": "mfma",
+            "roofline": {"kernel": "gemm_f64_kernel<false, true, 1> (forward P~ = K^ C_q + fused row statistics)", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
                          "launches": cat_n["forward_gemm"], "avg_launch_ms": cat_ms["forward_gemm"] / max(cat_n["forward_gemm"], 1)},
-            "roofline_kuf": {"kernel": "rbf_kernel<1> (K_uf construction)", "bound": "hbm", "achieved": kuf_gbs,
+            "roofline_kuf": {"kernel": "rbf_kernel<1, false> (K_uf construction)", "bound": "hbm", "achieved": kuf_gbs,
                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": kuf_gbs / PEAK_HBM_GBS, "traffic": None,
                              "launches": cat_n["rbf_cross_cov"],
                              "avg_launch_ms": cat_ms["rbf_cross_cov"] / max(cat_n["rbf_cross_cov"], 1)},

@@ -431,8 +431,9 @@ struct hmogp_engine {
         {
           // forward contraction for all latents (batched), row statistics fused into its epilogue; P~ itself is only
           // stored when the Z gradient (its one remaining consumer, colstats) is requested
-          Scope sc(this, CAT_FWD, 2);
           const long long sPart = 4LL * tiles * ldn;
+          {
+          Scope sc(this, CAT_FWD, 1);
           GemmArgs g;
           g.A = Kh.d(), g.lda = M, g.a_kmajor = 0, g.sA = sK;
           g.B = C.d(), g.ldb = M, g.b_kmajor = 1, g.sB = MM;
@@ -445,6 +446,8 @@ struct hmogp_engine {
           g.store_c = want_z ? 1 : 0;
           g.win = rw, g.win_stride = 2 * wtiles;
           launch_gemm_f64(g, st);
+          }
+          Scope sc2(this, CAT_ROWSTATS, 1);  // sum of the per-column-tile partials of the fused row statistics
           launch_combine_parts(fwdpart.d(), tiles, n, vp.d(), vc.d(), want_hyper ? vpt.d() : nullptr,
                                want_hyper ? vct.d() : nullptr, st, Q, sPart, ldn);
         }
@@ -474,7 +477,7 @@ struct hmogp_engine {
           launch_reduce_rows(quadpart.d(), quad_blocks(k.lik, n), k.nscal, k.offsets.as<long long>(), stats.d(), true, st);
         }
         {
-          Scope sc(this, CAT_GRAM, 2);  // H_q += K^T diag(beta) K^ for all latents (svmogp_inf.py:145-147 summed over d)
+          // H_q += K^T diag(beta) K^ for all latents (svmogp_inf.py:145-147 summed over d)
           const int ksplit = use_windows ? std::min(8, gram_ksplit(n, M)) : gram_ksplit(n, M);
           slabs.ensure(sizeof(double) * MM * 64 * Q, true);
           GemmArgs g;
@@ -488,7 +491,11 @@ struct hmogp_engine {
           g.ksplit = ksplit, g.sSplit = MM;
           g.role = 2;
           g.win = cw, g.win_stride = 2 * ncb;
-          launch_gemm_f64(g, st);
+          {
+            Scope sc(this, CAT_GRAM, 1);
+            launch_gemm_f64(g, st);
+          }
+          Scope sc2(this, CAT_COLSTATS, 1);  // row-range slabs -> bundle (accounted with the column statistics)
           launch_reduce_slabs_lower(slabs.d(), ksplit, M, Hq(0), true, st, Q, MM * 64, per_q);
         }
         {

@@ -202,7 +202,8 @@ class Engine(object):
         ms = np.zeros(8)
         n = np.zeros(8, dtype=np.int64)
         check(lib.hmogp_last_timings(self._h, _p(ms), n.ctypes.data_as(_lib.c_int64_p)), self._h)
-        names = ["total", "rbf_cross_cov", "forward_gemm", "rowstats", "quadrature", "gram_gemm", "colstats", "mxm_algebra"]
+        names = ["total", "rbf_cross_cov", "forward_gemm", "rowstats_combine", "quadrature", "gram_gemm", "colstats_reduce",
+                 "mxm_algebra"]
         return dict(zip(names, ms.tolist())), dict(zip(names, n.tolist()))
 
 

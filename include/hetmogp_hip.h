@@ -171,9 +171,10 @@ int hmogp_natgrad_step(hmogp_handle h, double gamma, double* m_u_new, double* L_
 
 /* ---- timing --------------------------------------------------------------------------------------- */
 /* Milliseconds the kernels of the last evaluation spent, measured with HIP events on the engine's stream:
- * out[0] whole evaluation, [1] K_uf construction (rbf_cross_cov), [2] forward N x M x M products,
- * [3] row statistics, [4] quadrature, [5] weighted Gram (backward), [6] column statistics,
- * [7] replicated M x M algebra.  launches[i] = number of kernel launches behind out[i] (i = 1..7).       */
+ * out[0] whole evaluation, [1] K_uf construction (rbf_cross_cov; + window kernels in the opt-in mode), [2] forward
+ * N x M x M contraction incl. its fused row-statistics epilogue (ONE kernel per launch, all latents of a task chunk),
+ * [3] combine of the row-statistic partials, [4] quadrature, [5] weighted Gram contraction (ONE kernel per launch),
+ * [6] column statistics + slab reductions, [7] replicated M x M algebra.  launches[i] = kernel launches behind out[i].  */
 int hmogp_last_timings(hmogp_handle h, double* out_ms8, int64_t* launches8);
 
 /* ---- building blocks, exposed for parity tests ("inner protocol" at small sizes) ---------------------- */
