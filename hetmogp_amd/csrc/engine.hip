@@ -88,7 +88,6 @@ int lik_dimf(int lik, double param) {
 // Row ranges per weighted-Gram launch: a multiple of 8 (one range per XCD at a time), each >= 32 k-steps of 16 rows,
 // enough blocks (lower tiles x ranges) for >= 8 rounds over the 256 CUs, at most 64 slabs.
 int gram_ksplit(long long n, int M) {
-  if (const char* e = std::getenv("HMOGP_GRAM_KSPLIT")) return std::max(1, std::atoi(e));  // tuning experiments only
   const int tiles = (M + 127) / 128, ntl = tiles * (tiles + 1) / 2;
   const long long ksteps = (n + 15) / 16;
   long long want = (8 * 256 + ntl - 1) / ntl;
@@ -1031,7 +1030,7 @@ int hmogp_bench_contraction(int32_t device, int32_t role, int64_t n, int32_t M, 
         g.M = g.N = M, g.K = (int)n;
         g.lower_only = 1, g.ksplit = ksplit, g.sSplit = MM, g.role = 2;
         launch_gemm_f64(g, nullptr);
-        if (!std::getenv("HMOGP_BENCH_NO_REDUCE")) launch_reduce_slabs(slabs.d(), ksplit, MM, MM, Cc.d(), true, nullptr);
+        launch_reduce_slabs_lower(slabs.d(), ksplit, M, Cc.d(), true, nullptr);
       }
     };
     once();

@@ -11,8 +11,6 @@
 // lane l is element [k = l>>4][row = l&15], so a wave reads 4 runs of 16 consecutive doubles; 144*8 B = 288
 // dwords == 32 banks (mod 64) puts the two k-rows of each 32-lane half on disjoint banks (ds_read_b64 is
 // conflict-free).  LDS is double buffered; the next tile's global loads are issued before the MFMA block.
-#include <cstdlib>
-
 #include "common.h"
 
 namespace {
@@ -410,17 +408,16 @@ void launch_gemm_f64(const GemmArgs& g, hipStream_t stream) {
   const int ntiles = g.lower_only ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
   const int gx = (g.ksplit > 1) ? ntiles * ((g.ksplit + 7) / 8) * 8 : ntiles;
   dim3 grid(gx, g.nouter, g.nbatch), block(NTHREADS);
-  static const int dyn = std::getenv("HMOGP_GEMM_DYNLDS") ? std::atoi(std::getenv("HMOGP_GEMM_DYNLDS")) : 0;  // occupancy experiments
   if (g.role == 1 && !g.a_kmajor && g.b_kmajor)
-    hipLaunchKernelGGL((gemm_f64_kernel<false, true, 1>), grid, block, dyn, stream, g, tiles_n, ntiles);
+    hipLaunchKernelGGL((gemm_f64_kernel<false, true, 1>), grid, block, 0, stream, g, tiles_n, ntiles);
   else if (g.role == 2 && g.a_kmajor && g.b_kmajor)
-    hipLaunchKernelGGL((gemm_f64_kernel<true, true, 2>), grid, block, dyn, stream, g, tiles_n, ntiles);
+    hipLaunchKernelGGL((gemm_f64_kernel<true, true, 2>), grid, block, 0, stream, g, tiles_n, ntiles);
   else if (g.a_kmajor && g.b_kmajor)
-    hipLaunchKernelGGL((gemm_f64_kernel<true, true, 0>), grid, block, dyn, stream, g, tiles_n, ntiles);
+    hipLaunchKernelGGL((gemm_f64_kernel<true, true, 0>), grid, block, 0, stream, g, tiles_n, ntiles);
   else if (g.a_kmajor && !g.b_kmajor)
-    hipLaunchKernelGGL((gemm_f64_kernel<true, false, 0>), grid, block, dyn, stream, g, tiles_n, ntiles);
+    hipLaunchKernelGGL((gemm_f64_kernel<true, false, 0>), grid, block, 0, stream, g, tiles_n, ntiles);
   else if (!g.a_kmajor && g.b_kmajor)
-    hipLaunchKernelGGL((gemm_f64_kernel<false, true, 0>), grid, block, dyn, stream, g, tiles_n, ntiles);
+    hipLaunchKernelGGL((gemm_f64_kernel<false, true, 0>), grid, block, 0, stream, g, tiles_n, ntiles);
   else
-    hipLaunchKernelGGL((gemm_f64_kernel<false, false, 0>), grid, block, dyn, stream, g, tiles_n, ntiles);
+    hipLaunchKernelGGL((gemm_f64_kernel<false, false, 0>), grid, block, 0, stream, g, tiles_n, ntiles);
 }

@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void rbf_kernel(const double* __restrict__ X, 
 // K^[n][m] = s2 exp(-r2/2) is EXACTLY 0.0 in float64 once r2 > ~1490.3 (exp underflows below the smallest subnormal).
 // For spatially sorted inputs K^ is therefore banded, and every product the row pass forms with an entry outside the
 // band is a product with an exact zero.  window_kernel finds, per 128-row tile, the column range [lo, hi) that holds all
-// possibly-nonzero entries (r2 <= 1491: a superset), and per 128-column block the hull of the row tiles that touch it;
+// possibly-nonzero entries (distance to the tile's bounding box <= sqrt(1491) lengthscales: a superset), and per
+// 128-column block the hull of the row tiles that touch it;
 // window_fix_kernel falls back to full ranges when the data is not banded (a row tile inside a block's hull that does not
 // touch the block), so arbitrary inputs stay correct.  No host synchronisation is involved.
 constexpr double WINDOW_R2_MAX = 1491.0;
@@ -109,39 +110,60 @@ template <int P>
 __global__ __launch_bounds__(256) void window_kernel(const double* __restrict__ X, long long N, const double* __restrict__ Z,
                                                      int ldz, int M, double ell, int* __restrict__ rowwin,
                                                      int* __restrict__ colwin, unsigned char* __restrict__ hit, int ncb) {
-  __shared__ double xs[128][P + 1];
+  // A column m can hold a non-zero for some row of this 128-row tile only if z_m is within sqrt(1491) lengthscales of the
+  // tile's bounding box (per-dimension [min, max] of its inputs): a conservative test costing O(M) per tile.  Sorted
+  // 1-D inputs give tight boxes (narrow windows); unsorted inputs give boxes spanning the domain (full windows).
+  __shared__ double bmin[P], bmax[P];
+  __shared__ double red[2][4][P];
   __shared__ int s_lo, s_hi;
   __shared__ int s_hit[64];
-  const int t = threadIdx.x, T = blockIdx.x;
+  const int t = threadIdx.x, T = blockIdx.x, lane = t & 63, w = t >> 6;
   const long long r0 = (long long)T * 128;
   const int nr = (int)min(128LL, N - r0);
   if (t == 0) s_lo = 0x7fffffff, s_hi = 0;
   if (t < 64) s_hit[t] = 0;
-  for (int e = t; e < 128 * P; e += 256) {
-    const int r = e / P, p = e % P;
-    xs[r][p] = (r < nr) ? X[(r0 + r) * P + p] : 0.0;
-  }
-  __syncthreads();
-  if (t < 128) {
-    double xv[P];
+  double lo[P], hi[P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) xv[p] = xs[t][p];
-    xs[t][P] = sumsq<P>(xv);
-  }
-  __syncthreads();
-  for (int m = t; m < M; m += 256) {
-    double zv[P];
+  for (int p = 0; p < P; ++p) lo[p] = INFINITY, hi[p] = -INFINITY;
+  bool nan_in = false;
+  if (t < nr) {
 #pragma unroll
-    for (int p = 0; p < P; ++p) zv[p] = Z[(long long)m * ldz + p];
-    const double zsq = sumsq<P>(zv);
-    bool any = false;
-    for (int r = 0; r < nr && !any; ++r) {
-      double xv[P];
-#pragma unroll
-      for (int p = 0; p < P; ++p) xv[p] = xs[r][p];
-      any = !(rbf_r2<P>(xv, xs[r][P], zv, zsq, ell) > WINDOW_R2_MAX);  // NaN counts as "possibly nonzero"
+    for (int p = 0; p < P; ++p) {
+      const double x = X[(r0 + t) * P + p];
+      lo[p] = hi[p] = x;
+      nan_in |= (x != x);
     }
-    if (any) {
+  }
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[p] = fmin(lo[p], __shfl_xor(lo[p], o, 64));
+      hi[p] = fmax(hi[p], __shfl_xor(hi[p], o, 64));
+    }
+    if (lane == 0) red[0][w][p] = lo[p], red[1][w][p] = hi[p];
+  }
+  const bool any_nan = __syncthreads_or(nan_in ? 1 : 0) != 0;
+  if (t == 0) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      bmin[p] = fmin(fmin(red[0][0][p], red[0][1][p]), fmin(red[0][2][p], red[0][3][p]));
+      bmax[p] = fmax(fmax(red[1][0][p], red[1][1][p]), fmax(red[1][2][p], red[1][3][p]));
+    }
+  }
+  __syncthreads();
+  const double thr = WINDOW_R2_MAX * ell * ell * (1.0 + 1e-9);
+  for (int m = t; m < M; m += 256) {
+    double d2 = 0.0;
+    bool zn = false;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const double z = Z[(long long)m * ldz + p];
+      zn |= (z != z);
+      const double d = fmax(fmax(bmin[p] - z, z - bmax[p]), 0.0);  // distance from z to the box along dimension p
+      d2 += d * d;
+    }
+    if (any_nan || zn || !(d2 > thr)) {  // NaNs count as "possibly non-zero"
       atomicMin(&s_lo, m);
       atomicMax(&s_hi, m + 1);
       s_hit[m >> 7] = 1;
