@@ -23,7 +23,7 @@ class Posterior(object):
 
 class SVMOGP(object):
     def __init__(self, X, Y, Z, kern_list, likelihood, Y_metadata, name="SVMOGP", batch_size=None, W_list=None,
-                 device=0, chunk_rows=0, exact_zero_windows=False):
+                 device=0, chunk_rows=0, exact_zero_windows=False, distributed=False):
         self.name = name
         self.batch_size = batch_size
         self.kern_list = kern_list
@@ -45,6 +45,16 @@ class SVMOGP(object):
         self._engine = Engine(likelihood.specs(), self.num_latent_funcs, self.num_inducing, self.Xdim, device=device,
                               chunk_rows=chunk_rows, exact_zero_windows=exact_zero_windows)
         self._engine.set_data(self.Xmulti_all, self.Ymulti_all)
+        # distributed=True (inside an initialised torch.distributed group, one process per GPU): the rows of every
+        # evaluation are sharded over the ranks and the statistic bundle is all-reduced once (hetmogp_amd/dist.py); every
+        # rank holds identical parameters and receives identical gradients.
+        self._dist = None
+        if distributed:
+            import torch.distributed as tdist
+            from . import dist as hdist
+            if not tdist.is_initialized():
+                raise RuntimeError("distributed=True needs an initialised torch.distributed process group")
+            self._dist = (hdist, hdist.StatsReducer(self._engine, device=device), tdist.get_rank(), tdist.get_world_size())
         self._rows = [(0, x.shape[0]) for x in self.Xmulti_all]
         self._last_batch = None
         if batch_size is None:
@@ -98,7 +108,11 @@ class SVMOGP(object):
         if self.Z.is_fixed:
             mask &= ~_lib.GROUP_Z
         W0, k0 = self._construction_W()
-        out = self._engine.elbo_grad(
+        evaluate = self._engine.elbo_grad
+        if self._dist is not None:
+            hdist, reducer, rank, world = self._dist
+            evaluate = lambda **kw: hdist.sharded_elbo_grad(self._engine, reducer, rank, world, **kw)  # noqa: E731
+        out = evaluate(
             Z=self.Z.values, m_u=self.q_u_means.values, L_flat=self.q_u_chols.values,
             variance=[float(k.variance[0]) for k in self.kern_list],
             lengthscale=[float(k.lengthscale[0]) for k in self.kern_list],

@@ -97,3 +97,48 @@ def test_two_ranks_row_sharded_match_single_rank():
         assert np.max(np.abs(gZ - full["g_Z"])) < 1e-9 * np.max(np.abs(full["g_Z"]))
         assert np.max(np.abs(gL - full["g_L_u"])) < 1e-9 * np.max(np.abs(full["g_L_u"]))
     assert res[0][1] == res[1][1]                          # replicated finish: identical on every rank
+
+
+def _facade_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import torch.distributed as dist
+    from test_facade_gpu import build_model
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "model_config2_full.npz"))
+    import hetmogp_amd.svmogp as sv
+    orig = sv.SVMOGP.__init__
+
+    def patched(self, *a, **kw):                      # same fixture builder, sharded evaluation
+        kw["distributed"] = True
+        return orig(self, *a, **kw)
+    sv.SVMOGP.__init__ = patched
+    model = build_model(g)
+    model.parameters_changed()
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, float(model.log_likelihood()[0, 0]), np.asarray(model.Z.gradient), np.asarray(model.q_u_chols.gradient)))
+
+
+@pytest.mark.timeout(600)
+def test_facade_distributed_rows_match_reference_fixture():
+    """SVMOGP(distributed=True) on two ranks (gloo, both on the one GPU): every rank reproduces the reference's
+    parameters_changed() outputs of the fixture."""
+    import torch.multiprocessing as mp
+    g = np.load(os.path.join(ROOT, "tests", "golden", "model_config2_full.npz"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_facade_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, elbo, gZ, gL in res:
+        assert abs(elbo - float(g["elbo"])) < 1e-8 * abs(float(g["elbo"]))
+        assert np.max(np.abs(gZ - g["g_Z"])) < 1e-8 * np.max(np.abs(g["g_Z"]))
+        assert np.max(np.abs(gL - g["g_L_u"])) < 1e-8 * np.max(np.abs(g["g_L_u"]))
