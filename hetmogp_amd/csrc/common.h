@@ -5,6 +5,9 @@
 #include <string>
 
 #define HMOGP_WAVE 64
+#ifndef HMOGP_POTRF_NB
+#define HMOGP_POTRF_NB 32  // Cholesky / triangular-inverse panel width (32 or 64); dscr scratch is Q*M*HMOGP_POTRF_NB doubles
+#endif
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -99,7 +102,7 @@ void launch_gemm_f64(const GemmArgs& g, hipStream_t stream);
 
 // ---- linear algebra on Q x M x M batches (linalg.hip) ---------------------------------------------------
 // In-place lower Cholesky of A[q]; info[q] = 0 or the 1-based index of the first non-positive pivot (LAPACK
-// dpotrf convention; the matrix content is then undefined). Upper triangle is zeroed. dscr: Q*M*32 doubles.
+// dpotrf convention; the matrix content is then undefined). Upper triangle is zeroed. dscr: Q*M*HMOGP_POTRF_NB doubles.
 void launch_potrf_batched(double* A, int Q, int M, int* d_info, double* dscr, hipStream_t stream);
 // Linv[q] = L[q]^-1 (lower triangular, upper zero). `L` is preserved; tmp: Q*M*M doubles.
 void launch_trtri_batched(const double* L, double* Linv, double* tmp, int Q, int M, hipStream_t stream);

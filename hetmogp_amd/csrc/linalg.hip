@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int NB = 32;       // panel width
+constexpr int NB = HMOGP_POTRF_NB;  // panel width (common.h)
 constexpr int NBP = NB + 1;  // padded LDS leading dimension
 
 // ---------------------------------------------------------------------------------------------- potrf
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
   // needs the pivot from lane c and, for the rank-1 update, the scaled column entries L[c2][c] from lanes c2 -- both by
   // wavefront shuffles (about 530 of them for the whole block), no LDS round trips or barriers inside the recurrence.
   if (t < 64) {
-    const int r = t & 31;  // lanes 32..63 mirror lanes 0..31 (shuffles stay within the wave)
+    const int r = t & (NB - 1);  // NB = 32: lanes 32..63 mirror lanes 0..31 (shuffles stay within the wave)
     double a[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) a[c] = D[r][c];
