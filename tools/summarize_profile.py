@@ -52,6 +52,35 @@ def main():
         print("%-40s grid=%-9d n=%-3d fetch_raw=%10.0f KB write=%10.0f KB  hbm/launch=%.3f GB" %
               (r["kernel"][:40], r["grid_threads"], r["launches"], r["fetch_kb_raw_avg"], r["write_kb_raw_avg"],
                r["hbm_bytes_per_launch"] / 1e9))
+    # MFMA utilisation per kernel (third PMC pass): busy cycles of the matrix pipes / (active cycles per XCD x 1024 SIMDs).
+    # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs here (9.85e6 x 8 for a 4.27 ms kernel at 2.3 GHz).
+    mpath = os.path.join(src, "pmc_mfma", "pmc_counter_collection.csv")
+    if os.path.exists(mpath):
+        m = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(mpath)):
+            m[(short(r["Kernel_Name"]), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        mrows = []
+        for (name, grid), c in m.items():
+            if "SQ_VALU_MFMA_BUSY_CYCLES" not in c or "GRBM_GUI_ACTIVE" not in c:
+                continue
+            avg = {k: sum(v) / len(v) for k, v in c.items()}
+            if avg["SQ_VALU_MFMA_BUSY_CYCLES"] <= 0:
+                continue
+            act = avg["GRBM_GUI_ACTIVE"] / 8.0
+            mrows.append(dict(kernel=name, grid_threads=grid, launches=len(c["GRBM_GUI_ACTIVE"]),
+                              mfma_busy_cycles=int(avg["SQ_VALU_MFMA_BUSY_CYCLES"]), active_cycles_per_xcd=int(act),
+                              mfma_util=round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (act * 1024.0), 4),
+                              wait_any_frac=round(avg.get("SQ_WAIT_ANY", 0.0) / max(avg.get("SQ_WAVE_CYCLES", 1.0), 1.0), 4),
+                              lds_conflict_frac=round(avg.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(avg.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0), 4)))
+        mrows.sort(key=lambda r: -r["mfma_busy_cycles"] * r["launches"])
+        if mrows:
+            with open(os.path.join(dst, "r%s_pmc_mfma.csv" % rnd), "w", newline="") as fh:
+                wri = csv.DictWriter(fh, fieldnames=list(mrows[0].keys()))
+                wri.writeheader()
+                wri.writerows(mrows)
+            for r in mrows[:4]:
+                print("MFMA util %-36s grid=%-9d util=%.3f wait_any=%.3f lds_conflict=%.3f" %
+                      (r["kernel"][:36], r["grid_threads"], r["mfma_util"], r["wait_any_frac"], r["lds_conflict_frac"]))
     # the forward contraction of the headline workload's full chunk: the dominant kernel's traffic for bench.py
     fwd = [r for r in rows if r["kernel"].startswith("gemm_f64_kernel<false, true, 1>")]
     fwd.sort(key=lambda r: -r["grid_threads"])
