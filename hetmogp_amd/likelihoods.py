@@ -42,6 +42,10 @@ class _Lik(object):
         return predictive(self.name, m, v, **self.kwargs())
 
 
+def _safe_exp(f):
+    return np.exp(np.minimum(f, np.log(np.finfo(np.float64).max)))
+
+
 class Gaussian(_Lik):
     name = "Gaussian"
 
@@ -51,12 +55,19 @@ class Gaussian(_Lik):
     def kwargs(self):
         return {"sigma": self.sigma}
 
+    def samples(self, f, num_samples=1, Y_metadata=None):
+        return np.random.normal(loc=f, scale=self.sigma)   # gaussian.py:36-39
+
 
 class Bernoulli(_Lik):
     name = "Bernoulli"
 
     def __init__(self, gp_link=None):
         pass
+
+    def samples(self, f, num_samples=1, Y_metadata=None):
+        ef = _safe_exp(f)                                   # bernoulli.py:59-64
+        return np.random.binomial(n=1, p=np.clip(ef / (1 + ef), 1e-9, 1.0 - 1e-9))
 
 
 class HetGaussian(_Lik):
@@ -66,6 +77,9 @@ class HetGaussian(_Lik):
     def __init__(self, gp_link=None):
         pass
 
+    def samples(self, F, num_samples=1, Y_metadata=None):
+        return np.random.normal(loc=F[:, 0], scale=np.sqrt(_safe_exp(F[:, 1])))[:, None]   # hetgaussian.py:41-44
+
 
 class Poisson(_Lik):
     name = "Poisson"
@@ -73,12 +87,18 @@ class Poisson(_Lik):
     def __init__(self, gp_link=None):
         pass
 
+    def samples(self, f, num_samples=1, Y_metadata=None):
+        return np.random.poisson(lam=_safe_exp(f))         # poisson.py:51-54
+
 
 class Exponential(_Lik):
     name = "Exponential"
 
     def __init__(self, gp_link=None):
         pass
+
+    def samples(self, f, num_samples=1, Y_metadata=None):
+        return np.random.exponential(scale=np.clip(_safe_exp(-f), 1e-9, 1e9))   # exponential.py:52-56
 
 
 class Gamma(_Lik):
@@ -88,6 +108,10 @@ class Gamma(_Lik):
     def __init__(self, gp_link=None):
         pass
 
+    def samples(self, F, num_samples=1, Y_metadata=None):
+        eF = np.clip(_safe_exp(F), 1e-9, 1e9)              # gamma.py:43-50
+        return np.random.gamma(shape=eF[:, 0, None], scale=1.0 / eF[:, 1, None])
+
 
 class Beta(_Lik):
     name = "Beta"
@@ -95,6 +119,10 @@ class Beta(_Lik):
 
     def __init__(self, gp_link=None):
         pass
+
+    def samples(self, F, num_samples=1, Y_metadata=None):
+        eF = np.clip(_safe_exp(F), 1e-9, 1e9)              # beta.py:38-45
+        return np.random.beta(a=eF[:, 0, None], b=eF[:, 1, None])
 
 
 class Categorical(_Lik):
@@ -108,6 +136,14 @@ class Categorical(_Lik):
 
     def get_metadata(self):
         return 1, self.K - 1, self.K - 1                   # categorical.py:287-291
+
+    def samples(self, F, num_samples=1, Y_metadata=None):
+        eF = _safe_exp(F)                                   # categorical.py:65-75: labels 1..K
+        den = 1 + eF.sum(1)[:, None]
+        p = np.clip(np.hstack((eF / den, 1 / den)), 1e-9, 1 - 1e-9)
+        p = p / p.sum(1)[:, None]
+        u = np.random.rand(F.shape[0], 1)
+        return (1 + (u > np.cumsum(p, 1)).sum(1)).clip(1, self.K).astype(float)[:, None]
 
 
 class HetLikelihood(object):
@@ -137,6 +173,10 @@ class HetLikelihood(object):
 
     def specs(self):
         return [(l.name, l.kwargs()) for l in self.likelihoods_list]
+
+    def samples(self, F, Y_metadata):
+        """het_likelihood.py:72-83: one draw per task from its likelihood (host-side data generation)."""
+        return [l.samples(F[t], num_samples=1) for t, l in enumerate(self.likelihoods_list)]
 
     def var_exp(self, Y, mu_F, v_F, Y_metadata):
         return [l.var_exp(Y[t], mu_F[t], v_F[t]) for t, l in enumerate(self.likelihoods_list)]

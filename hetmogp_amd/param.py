@@ -81,7 +81,8 @@ def match(named_params, pattern):
 
 # paramz Logexp: theta = log(1 + exp(x)); gradient factor d theta / d x = 1 - exp(-theta)
 def logexp_f(x):
-    return np.where(x > 36.0, x, np.log1p(np.exp(np.minimum(x, 36.0))))
+    # paramz Logexp.f clips its argument to [-36, 36]: the transformed value never reaches exactly 0
+    return np.where(x > 36.0, x, np.log1p(np.exp(np.clip(x, -36.0, 36.0))))
 
 
 def logexp_finv(theta):

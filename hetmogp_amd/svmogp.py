@@ -235,18 +235,33 @@ class SVMOGP(object):
         return -float(self._log_marginal_likelihood[0, 0])
 
     def optimize(self, messages=False, max_iters=100, **kw):
-        """paramz Model.optimize default: scipy L-BFGS-B on (objective, gradient) over the free parameters."""
+        """paramz Model.optimize default: scipy L-BFGS-B on (objective, gradient) over the free parameters.  Like paramz's
+        `_objective_grads`, a failed evaluation (LinAlgError from the jitter ladder, the 'Sqi' ValueError, a non-finite
+        ELBO) returns an infinite objective so that the line search backs off instead of aborting; an evaluation that
+        reports v < 0 (the reference only prints 'v negative!', svmogp_inf.py:221, and carries on with a meaningless
+        ELBO) is treated the same way.  The parameters of the best finite evaluation are restored at the end."""
         from scipy.optimize import minimize
+        best = {"f": np.inf, "x": None}
 
         def f(x):
-            g = self._grads(x)
-            return self.objective_function(), g
+            try:
+                g = self._grads(x)
+                obj = self.objective_function()
+                bad = (not np.isfinite(obj)) or bool(self.last and self.last.get("v_negative"))
+            except (np.linalg.LinAlgError, ValueError, ZeroDivisionError):
+                g, obj, bad = np.zeros_like(x), np.inf, True
+            if bad:
+                return np.inf, np.clip(np.nan_to_num(g), -1e10, 1e10)
+            if obj < best["f"]:
+                best["f"], best["x"] = obj, np.array(x, copy=True)
+            return obj, g
 
         x0 = self.optimizer_array.copy()
         if x0.size == 0:
             return self
-        res = minimize(f, x0, jac=True, method="L-BFGS-B", options={"maxiter": int(max_iters), "disp": bool(messages)})
-        self.optimizer_array = res.x
+        res = minimize(f, x0, jac=True, method="L-BFGS-B", options={"maxiter": int(max_iters), "maxfun": int(max_iters),
+                                                                   "disp": bool(messages)})
+        self.optimizer_array = best["x"] if best["x"] is not None else res.x
         return self
 
     # ------------------------------------------------------------------------------------------ prediction

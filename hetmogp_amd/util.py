@@ -15,6 +15,38 @@ def get_batch_scales(X_all, X):
     return [float(xa.shape[0]) / float(x.shape[0]) for xa, x in zip(X_all, X)]
 
 
+def true_u_functions(X_list, Q):
+    """util.py:21-35: random three-sinusoid latent functions evaluated at each task's inputs."""
+    amplitude = (1.5 - 0.5) * np.random.rand(Q, 3) + 0.5
+    freq = (3 - 1) * np.random.rand(Q, 3) + 1
+    shift = 2 * np.random.rand(Q, 3)
+    u_functions = []
+    for X in X_list:
+        u_task = np.empty((X.shape[0], Q))
+        for q in range(Q):
+            u_task[:, q, None] = 3 * amplitude[q, 0] * np.cos(freq[q, 0] * np.pi * X + shift[q, 0] * np.pi) - \
+                2 * amplitude[q, 1] * np.sin(2 * freq[q, 1] * np.pi * X + shift[q, 1] * np.pi) + \
+                amplitude[q, 2] * np.cos(4 * freq[q, 2] * np.pi * X + shift[q, 2] * np.pi)
+        u_functions.append(u_task)
+    return u_functions
+
+
+def true_f_functions(true_u, W_list, D, likelihood_list, Y_metadata):
+    """util.py:37-50: F_t[:, j] = sum_q W_q[d] u_q for the functions d of task t."""
+    f_index = Y_metadata["function_index"].flatten()
+    d_index = Y_metadata["d_index"].flatten()
+    true_f = []
+    for t, u_task in enumerate(true_u):
+        _, num_f_task, _ = likelihood_list[t].get_metadata()
+        F = np.zeros((u_task.shape[0], num_f_task))
+        for q, W in enumerate(W_list):
+            for d in range(D):
+                if f_index[d] == t:
+                    F[:, d_index[d], None] += np.tile(W[d].T, (u_task.shape[0], 1)) * u_task[:, q, None]
+        true_f.append(F)
+    return true_f
+
+
 def mini_slices(n_samples, batch_size):
     """util.py:52-59: contiguous slices, the last one may be short."""
     n_batches, rest = divmod(n_samples, batch_size)
