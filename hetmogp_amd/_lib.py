@@ -78,7 +78,20 @@ EXPORTS = {
 }
 
 
+def _preload_torch_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so while this library links the system one (/opt/rocm).  Both can
+    live in one process, but only if PyTorch's copy initialises first (observed on ROCm 7.2 + torch 2.10/rocm7.0: with the
+    system runtime initialised first, torch.cuda.is_available() turns False and RCCL finds no GPU).  torch is optional
+    plumbing (device memory aliasing, torch.distributed); when it is installed, touch it before loading the library."""
+    try:
+        import torch
+        torch.cuda.is_available()
+    except Exception:
+        pass
+
+
 def _load():
+    _preload_torch_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "hetmogp_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
