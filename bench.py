@@ -30,6 +30,21 @@ PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X datasheet FP64 matrix peak (the microarc
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured achievable)
 
 
+class _StdoutToStderr(object):
+    """RCCL prints its version banner to stdout when the first communicator is created; the contract is ONE JSON line on
+    stdout, so everything before the result (process-group set-up, warm-up) runs with fd 1 pointed at stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -55,6 +70,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    guard = _StdoutToStderr()
+    guard.__enter__()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -85,6 +102,7 @@ def main():
     for _ in range(args.warmup):
         out = step()
     fence()
+    guard.__exit__()
     t0 = time.perf_counter()
     cat_ms, cat_n = {}, {}
     for _ in range(args.steps):

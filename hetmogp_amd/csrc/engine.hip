@@ -514,6 +514,8 @@ struct hmogp_engine {
   void begin(const hmogp_params* p) {
     HIP_TRY(hipSetDevice(device));
     began = false;
+    spans.clear();  // a failed evaluation may have left unmatched timing spans behind
+    pool_used = 0;
     for (int c = 0; c < NCAT; ++c) ms[c] = 0.0, launches[c] = 0;
     upload_params(p);
     HIP_TRY(hipEventRecord(ev_begin0, st));

@@ -396,3 +396,34 @@ def test_config4_like_eight_likelihoods_Q4_vs_oracle():
     out = e.step_finish()
     for k in KEYS:
         assert rel(out[k], want[k]) < TOL, k
+
+
+def test_error_conventions():
+    """Status codes surface as the reference's exception types: bad arguments -> ValueError, call-order
+    violations -> HetMOGPError(E_STATE), a non-PD K_uu after five jitter rungs -> LinAlgError (GPy jitchol, util.py:198)."""
+    from hetmogp_amd import _lib
+    from hetmogp_amd.engine import Engine
+    with pytest.raises(ValueError):
+        Engine([("Gaussian", {})], Q=9, M=8, P=1)                      # more latent GPs than HMOGP_MAXQ
+    with pytest.raises(ValueError):
+        Engine([("Categorical", {"K": 11})], Q=1, M=8, P=1)            # dim_f above HMOGP_MAXJ
+    with pytest.raises(ValueError):
+        Engine([("Gaussian", {})], Q=1, M=8, P=7)                      # input dimension above 4
+    specs = [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {})]
+    prm, prob, X, Y = synth(51, specs, [50, 40], 8, 2, 1, (1.0, 1.2))
+    e = make_engine(prob, X, Y)
+    with pytest.raises(_lib.HetMOGPError) as ei:
+        e.step_finish()                                                # finish without begin
+    assert ei.value.code == _lib.E_STATE
+    with pytest.raises(ValueError):
+        run(e, prm, row_begin=[0, 0], row_end=[51, 40])                # row range outside the task's data
+    bad = dict(prm)
+    bad["lengthscale"] = np.array([0.0, 1.0])
+    with pytest.raises(ValueError):
+        run(e, bad)
+    bad = dict(prm)
+    bad["variance"] = np.array([-1.0, 0.5])                            # K_uu = -I-like: not PD, non-positive diagonal
+    with pytest.raises(np.linalg.LinAlgError):
+        run(e, bad)
+    ok = run(e, prm)                                                   # the handle stays usable after errors
+    assert np.isfinite(ok["elbo"])
