@@ -143,7 +143,9 @@ void jitchol_batched(const double* Kuu, double* Luu, int Q, int M, const double*
 struct hmogp_engine {
   int T = 0, Q = 0, M = 0, P = 0, Df = 0, device = 0;
   long long chunk = 262144;
-  bool use_windows = false;
+  bool use_windows = false, cache_kuu = false, kuu_key_valid = false;
+  std::vector<double> h_Z, kuu_key;
+  std::vector<int> rung_request, kuu_rung;
   std::vector<int> f_index, d_index;
   std::vector<Task> tasks;
   hipStream_t st = nullptr;
@@ -228,6 +230,7 @@ struct hmogp_engine {
     if (Q > HMOGP_MAXQ) throw EngineError{HMOGP_E_INVALID, "Q exceeds HMOGP_MAXQ (8)"};
     if (c->chunk_rows > 0) chunk = c->chunk_rows;
     use_windows = (c->flags & HMOGP_CFG_EXACT_ZERO_WINDOWS) != 0;
+    cache_kuu = (c->flags & HMOGP_CFG_CACHE_KUU) != 0;
     if (use_windows && M > 8192) throw EngineError{HMOGP_E_INVALID, "exact-zero windows support M <= 8192"};
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -344,8 +347,11 @@ struct hmogp_engine {
       if (p->row_end) re[t] = p->row_end[t];
       if (rb[t] < 0 || re[t] > tasks[t].N || rb[t] > re[t]) throw EngineError{HMOGP_E_INVALID, "row range outside the task's data"};
     }
+    h_Z.assign(p->Z, p->Z + (size_t)M * Q * P);
+    rung_request.resize(Q);
     for (int q = 0; q < Q; ++q) {
       rung[q] = p->forced_rung ? p->forced_rung[q] : -2;
+      rung_request[q] = rung[q];
       if (!(h_ell[q] > 0.0)) throw EngineError{HMOGP_E_INVALID, "lengthscale must be positive"};
     }
     group_mask = p->group_mask;
@@ -378,11 +384,29 @@ struct hmogp_engine {
     Scope sc(this, CAT_MM, 0);
     const long long MM = (long long)M * M;
     const int ldz = Q * P;
-    for (int q = 0; q < Q; ++q)  // K_uu: both arguments passed (util.py:197) -> no forced diagonal
-      launch_rbf(dZ.d() + q * P, ldz, M, P, dZ.d() + q * P, ldz, M, h_var[q], h_ell[q], Kuu.d() + q * MM, false, st);
-    jitchol_batched(Kuu.d(), Luu.d(), Q, M, h_var.data(), rung.data(), dinfo.as<int>(), djit.d(), dscr.d(), st);
-    launch_trtri_batched(Luu.d(), tmpA.d(), tmpB.d(), Q, M, st);
-    launch_ltl_batched(tmpA.d(), Kuui.d(), Q, M, st);             // K_uu^-1          (util.py:199)
+    // K_uu, its jittered Cholesky factor and inverse depend on (Z, variance, lengthscale, forced rungs) only.  With
+    // HMOGP_CFG_CACHE_KUU they are reused while those inputs are bit-identical to the previous evaluation's -- the
+    // variational E-steps of VEM / SVI change q(u) only (util.py:294-306, svmogp.py:188-199).  The reference recomputes
+    // them on every call (util.py:181-200); the result is the same.
+    std::vector<double> key;
+    if (cache_kuu) {
+      key.assign(h_Z.begin(), h_Z.end());
+      key.insert(key.end(), h_var.begin(), h_var.end());
+      key.insert(key.end(), h_ell.begin(), h_ell.end());
+      for (int q = 0; q < Q; ++q) key.push_back((double)rung_request[q]);
+    }
+    if (cache_kuu && kuu_key_valid && key.size() == kuu_key.size() &&
+        std::memcmp(key.data(), kuu_key.data(), sizeof(double) * key.size()) == 0) {
+      rung = kuu_rung;
+    } else {
+      kuu_key_valid = false;
+      for (int q = 0; q < Q; ++q)  // K_uu: both arguments passed (util.py:197) -> no forced diagonal
+        launch_rbf(dZ.d() + q * P, ldz, M, P, dZ.d() + q * P, ldz, M, h_var[q], h_ell[q], Kuu.d() + q * MM, false, st);
+      jitchol_batched(Kuu.d(), Luu.d(), Q, M, h_var.data(), rung.data(), dinfo.as<int>(), djit.d(), dscr.d(), st);
+      launch_trtri_batched(Luu.d(), tmpA.d(), tmpB.d(), Q, M, st);
+      launch_ltl_batched(tmpA.d(), Kuui.d(), Q, M, st);             // K_uu^-1          (util.py:199)
+      if (cache_kuu) kuu_key.swap(key), kuu_rung = rung, kuu_key_valid = true;
+    }
     launch_unpack_tril(dLflat.d(), L.d(), Q, M, st);              // flat_to_triang   (svmogp_inf.py:193)
     mm(L.d(), false, L.d(), false, S.d());                        // S = L L^T        (:194-195)
     launch_gemv_batched(Kuui.d(), dmu.d(), a.d(), Q, M, 1, Q, st);  // a = K_uu^-1 m

@@ -43,7 +43,7 @@ def lik_param(name, **kw):
 class Engine(object):
     """specs: list of (likelihood class name, kwargs) per task, e.g. [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {})]."""
 
-    def __init__(self, specs, Q, M, P, device=0, chunk_rows=0, exact_zero_windows=False):
+    def __init__(self, specs, Q, M, P, device=0, chunk_rows=0, exact_zero_windows=False, cache_kuu=False):
         self.specs = [(n, dict(k)) for n, k in specs]
         self.T, self.Q, self.M, self.P = len(specs), int(Q), int(M), int(P)
         f_index, d_index = [], []
@@ -60,7 +60,8 @@ class Engine(object):
         cfg = _lib.Config(_lib.ABI_VERSION, self.T, self.Q, self.M, self.P, self.Df,
                           lik_id.ctypes.data_as(_lib.c_int32_p), _p(lik_par),
                           self.f_index.ctypes.data_as(_lib.c_int32_p), self.d_index.ctypes.data_as(_lib.c_int32_p),
-                          int(device), int(chunk_rows), _lib.CFG_EXACT_ZERO_WINDOWS if exact_zero_windows else 0)
+                          int(device), int(chunk_rows),
+                          (_lib.CFG_EXACT_ZERO_WINDOWS if exact_zero_windows else 0) | (_lib.CFG_CACHE_KUU if cache_kuu else 0))
         self._h = C.c_void_p()
         check(lib.hmogp_create(C.byref(cfg), C.byref(self._h)), None)
         self.N = [0] * self.T

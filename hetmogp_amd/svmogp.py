@@ -43,7 +43,7 @@ class SVMOGP(object):
         T = len(self.Ymulti_all)
         self.Xdim = Z.shape[1]
         self._engine = Engine(likelihood.specs(), self.num_latent_funcs, self.num_inducing, self.Xdim, device=device,
-                              chunk_rows=chunk_rows, exact_zero_windows=exact_zero_windows)
+                              chunk_rows=chunk_rows, exact_zero_windows=exact_zero_windows, cache_kuu=True)
         self._engine.set_data(self.Xmulti_all, self.Ymulti_all)
         # distributed=True (inside an initialised torch.distributed group, one process per GPU): the rows of every
         # evaluation are sharded over the ranks and the statistic bundle is all-reduced once (hetmogp_amd/dist.py); every

@@ -88,6 +88,9 @@ typedef struct {
 } hmogp_config;
 
 /* hmogp_config.flags */
+#define HMOGP_CFG_CACHE_KUU 2u /* opt-in: reuse K_uu, its Cholesky factor and inverse while (Z, variance, lengthscale,
+   forced rungs) are bit-identical to the previous evaluation's (VEM / SVI E-steps only move q(u)).  Off by default and
+   never used by bench.py, whose steps re-evaluate identical parameters.                                          */
 #define HMOGP_CFG_EXACT_ZERO_WINDOWS 1u /* opt-in: skip the parts of K_uf = k(X,Z) that are EXACTLY 0.0 in float64
    (exp underflow beyond ~38.6 lengthscales).  For spatially sorted inputs K_uf is banded and the row pass only touches
    the band; every skipped term is a product with an exact zero, so ELBO and gradients are unchanged (tested equal to

@@ -230,6 +230,32 @@ def test_empty_task_and_v_negative_flag():
     assert out["v_negative"] is True                                  # the reference prints 'v negative!' (svmogp_inf.py:221)
 
 
+def test_kuu_cache_is_invisible():
+    """HMOGP_CFG_CACHE_KUU (opt-in, used by the SVMOGP facade): K_uu / L_uu / K_uu^-1 are reused while Z and the kernel
+    hyper-parameters are bit-identical; results equal the uncached engine bit for bit through a sequence that moves
+    q(u) only (cache hit), then a lengthscale (miss), then Z (miss), then back (miss, then hit)."""
+    specs = [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {}), ("Poisson", {})]
+    prm, prob, X, Y = synth(23, specs, [300, 200, 250], 40, 2, 1, (1.0, 1.3))
+    plain, cached = make_engine(prob, X, Y), make_engine(prob, X, Y, cache_kuu=True)
+    rng = np.random.RandomState(0)
+    seq = [dict(prm)]
+    a = dict(prm); a["m_u"] = prm["m_u"] + 0.1 * rng.randn(*prm["m_u"].shape); seq.append(a)
+    b = dict(a); b["L_flat"] = a["L_flat"] * 1.1; seq.append(b)
+    c = dict(b); c["lengthscale"] = np.asarray(b["lengthscale"]) * 1.05; seq.append(c)
+    d = dict(c); d["Z"] = c["Z"] + 1e-3; seq.append(d)
+    seq += [b, b, prm]
+    for i, p in enumerate(seq):
+        o1, o2 = run(plain, p), run(cached, p)
+        assert o1["rungs"] == o2["rungs"]
+        for k in KEYS:
+            assert np.array_equal(np.asarray(o1[k]), np.asarray(o2[k])), (i, k)
+    # a forced jitter rung is part of the key
+    o1, o2 = run(plain, prm, forced_rung=[1, -1]), run(cached, prm, forced_rung=[1, -1])
+    assert o1["rungs"] == o2["rungs"] == [1, -1]
+    for k in KEYS:
+        assert np.array_equal(np.asarray(o1[k]), np.asarray(o2[k])), k
+
+
 @pytest.mark.slow
 def test_headline_size_properties():
     """BASELINE.json headline shape (N=200k/task would take the oracle hours): N_t = 50k, M = 1024, Q = 3 through
