@@ -75,7 +75,7 @@ struct GemmArgs {
   // role 1 only -- row statistics fused into the epilogue while the P~ tile is still in registers (replaces a separate
   // pass over K^ and P~):  for every row n of the tile and this block's 128 columns j
   //   p += K^_nj a_j,  c += P~_nj K^_nj,  pt += K^_nj a_j r2_nj,  ct += P~_nj K^_nj r2_nj      (r2 = |x_n - z_j|^2 / l^2)
-  // written as per-column-tile partials fs_part[stat][tile_col][n]; launch_combine_parts sums the column tiles.
+  // written as partials per 64-column half tile, fs_part[stat][2 * tile_col + half][n]; launch_combine_parts sums them.
   // Batched over the latents (nbatch): fs_part / fs_a / fs_z / fs_ell / win advance by their strides per batch.
   double* fs_part = nullptr;
   const double* fs_a = nullptr;    // [N]      a = Kuu^-1 m                         (+ batch * fs_sA)

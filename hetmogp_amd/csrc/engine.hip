@@ -319,7 +319,7 @@ struct hmogp_engine {
     for (DevBuf* b : {&vp, &vc, &vpt, &vct, &valpha, &vbeta, &valpha0, &vbeta0}) b->ensure(nv, true);
     colpart.ensure(sizeof(double) * ((rows + 255) / 256) * M * (1 + P) * Q);
     quadpart.ensure(sizeof(double) * (rows * 64 / 256 + 1) * HMOGP_MAXSCAL);
-    fwdpart.ensure(sizeof(double) * 4 * ((M + 127) / 128) * rows * Q);
+    fwdpart.ensure(sizeof(double) * 8 * ((M + 127) / 128) * rows * Q);  // 4 statistics x 2 column halves per tile
     if (use_windows) {
       const size_t tiles = (rows + 127) / 128, ncb = (M + 127) / 128;
       winrow.ensure(sizeof(int) * 2 * tiles * Q), wincol.ensure(sizeof(int) * 2 * ncb * Q), winhit.ensure(tiles * ncb);
@@ -454,7 +454,7 @@ struct hmogp_engine {
         {
           // forward contraction for all latents (batched), row statistics fused into its epilogue; P~ itself is only
           // stored when the Z gradient (its one remaining consumer, colstats) is requested
-          const long long sPart = 4LL * tiles * ldn;
+          const long long sPart = 8LL * tiles * ldn;
           {
           Scope sc(this, CAT_FWD, 1);
           GemmArgs g;
@@ -471,7 +471,7 @@ struct hmogp_engine {
           launch_gemm_f64(g, st);
           }
           Scope sc2(this, CAT_ROWSTATS, 1);  // sum of the per-column-tile partials of the fused row statistics
-          launch_combine_parts(fwdpart.d(), tiles, n, vp.d(), vc.d(), want_hyper ? vpt.d() : nullptr,
+          launch_combine_parts(fwdpart.d(), 2 * tiles, n, vp.d(), vc.d(), want_hyper ? vpt.d() : nullptr,
                                want_hyper ? vct.d() : nullptr, st, Q, sPart, ldn);
         }
         {
@@ -732,7 +732,7 @@ struct hmogp_engine {
         g.fs_ldz = ldz, g.fs_P = P, g.fs_hyper = 0, g.fs_ell = dell.d() + q;
         g.store_c = 0;
         launch_gemm_f64(g, st);
-        launch_combine_parts(fwdpart.d(), (M + 127) / 128, n, vp.d() + q * ldn, vc.d() + q * ldn, nullptr, nullptr, st);
+        launch_combine_parts(fwdpart.d(), 2 * ((M + 127) / 128), n, vp.d() + q * ldn, vc.d() + q * ldn, nullptr, nullptr, st);
       }
       launch_qf_combine(vp.d(), vc.d(), ldn, n, Q, Df, dW.d(), dkap.d(), dvar.d(), dm.d(), dv.d(), st);
       HIP_TRY(hipMemcpyAsync(m + r0 * Df, dm.p, sizeof(double) * n * Df, hipMemcpyDeviceToHost, st));
@@ -1023,11 +1023,14 @@ int hmogp_log_predictive(int32_t device, int32_t lik_id, double lik_param, int64
 int hmogp_bench_contraction(int32_t device, int32_t role, int64_t n, int32_t M, int32_t iters, double* avg_ms) {
   return guarded(nullptr, [&] {
     need_device(device);
-    if (n <= 0 || M <= 0 || iters <= 0 || !avg_ms || (role != 1 && role != 2)) throw EngineError{HMOGP_E_INVALID, "bad arguments"};
+    if (n <= 0 || M <= 0 || iters <= 0 || !avg_ms || role < 1 || role > 4) throw EngineError{HMOGP_E_INVALID, "bad arguments"};
     const long long MM = (long long)M * M;
     DevBuf A, B, Cc, beta, slabs;
     A.ensure(sizeof(double) * n * M), B.ensure(sizeof(double) * MM), Cc.ensure(sizeof(double) * std::max<long long>(n * M, MM));
     beta.ensure(sizeof(double) * n), slabs.ensure(sizeof(double) * MM * 64, true);
+    DevBuf part, ell;   // roles 3 / 4: forward contraction with the fused row-statistics epilogue (with / without P~ store)
+    part.ensure(sizeof(double) * 8 * ((M + 127) / 128) * n, true), ell.ensure(sizeof(double), true);
+    { const double one = 1.0; HIP_TRY(hipMemcpy(ell.p, &one, sizeof(double), hipMemcpyHostToDevice)); }
     std::vector<double> h((size_t)std::max<long long>(n * M, MM));
     unsigned long long s = 88172645463325252ULL;   // xorshift: full-range random operands (DVFS-realistic, guide rule 25)
     auto rnd = [&] { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (double)(s >> 11) / 9007199254740992.0 * 2.0 - 1.0; };
@@ -1040,7 +1043,11 @@ int hmogp_bench_contraction(int32_t device, int32_t role, int64_t n, int32_t M, 
     HIP_TRY(hipEventCreate(&e1));
     auto once = [&] {
       GemmArgs g;
-      if (role == 1) {
+      if (role != 2) {
+        if (role >= 3) {
+          g.fs_part = part.d(), g.fs_a = beta.d(), g.fs_x = beta.d(), g.fs_z = B.d(), g.fs_ldz = 1, g.fs_P = 1;
+          g.fs_hyper = 1, g.fs_ell = ell.d(), g.store_c = role == 3 ? 1 : 0;
+        }
         g.A = A.d(), g.lda = M, g.a_kmajor = 0;
         g.B = B.d(), g.ldb = M, g.b_kmajor = 1;
         g.C = Cc.d(), g.ldc = M;

@@ -99,6 +99,7 @@ __device__ __forceinline__ void store_kmajor(double* s, const double (&v)[8]) {
 template <bool A_KMAJOR, bool B_KMAJOR, int ROLE>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int tiles_n, int ntiles) {
   __shared__ __attribute__((aligned(16))) Tile lds;
+  __shared__ __attribute__((aligned(16))) double epi_a[ROLE == 1 ? 128 : 2];  // fused epilogue: vector a of the block's columns
 
   // ---- which tile / batch / k-range -----------------------------------------------------------------
   // Block b is observed to run on XCD b % 8 (speed only, never correctness).  Without a K split every XCD gets a
@@ -142,7 +143,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
     if (j0 >= whi || j0 + BN <= wlo) {  // no consumer ever reads this P~ tile: its statistics are exact zeros
       if (fs_part && threadIdx.x < 128 && i0 + (int)threadIdx.x < M)
         for (int st = 0; st < (g.fs_hyper ? 4 : 2); ++st)
-          fs_part[((long long)st * tiles_n + tj) * M + (i0 + threadIdx.x)] = 0.0;
+          for (int hf = 0; hf < 2; ++hf)
+            fs_part[((long long)st * 2 * tiles_n + 2 * tj + hf) * M + (i0 + threadIdx.x)] = 0.0;
       return;
     }
   }
@@ -172,6 +174,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
   // lower-only products: on a diagonal tile the wave that owns the strictly-upper 64 x 64 quadrant has nothing to
   // compute (it still takes part in staging and barriers)
   const bool idle_quadrant = g.lower_only && ti == tj && wm == 0 && wn == 1;
+  // ROLE 1 accumulates the TRANSPOSED 16 x 16 sub-tiles (operands swapped in the MFMA) with the B fragment's columns
+  // permuted, so that lane (lr, lk) register r of acc[a][b] holds P~[wm*64 + a*16 + lr][wn*64 + b*16 + 4*lk + r]:
+  // a lane owns 4 adjacent columns of ONE row -> the row statistics of the fused epilogue are in-lane sums plus two
+  // shuffle steps, and P~ is stored with 16-byte vectors.
+  constexpr bool SWAP = (ROLE == 1);
+  const int blr = SWAP ? 4 * (lr & 3) + (lr >> 2) : lr;
 
   f64x4 acc[4][4];
 #pragma unroll
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
       const double* pa = A_KMAJOR ? &lds.a[cur][(kk * 4 + lk) * KM_LD + wm * 64 + lr] : &lds.a[cur][(wm * 64 + lr) * RM_LD + kk * 4 + lk];
-      const double* pb = B_KMAJOR ? &lds.b[cur][(kk * 4 + lk) * KM_LD + wn * 64 + lr] : &lds.b[cur][(wn * 64 + lr) * RM_LD + kk * 4 + lk];
+      const double* pb = B_KMAJOR ? &lds.b[cur][(kk * 4 + lk) * KM_LD + wn * 64 + blr] : &lds.b[cur][(wn * 64 + blr) * RM_LD + kk * 4 + lk];
       double fa[4], fb[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -238,7 +246,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = SWAP ? __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[a][b], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
     }
     if (more) stage(cur ^ 1);
     __syncthreads();
@@ -249,110 +259,136 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
   // ---- epilogue: D fragment of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg -----------
   const double alpha = g.alpha, beta = (g.ksplit > 1) ? 0.0 : g.beta;
   if (ROLE == 1 && fs_part) {
-    // fused row statistics (see GemmArgs): the block's P~ tile is in registers, its K^ tile is re-read (L2/MALL-warm)
+    // Fused row statistics (see GemmArgs).  Lane (lr, lk) owns row rl = wm*64 + a*16 + lr and the column quads
+    // wn*64 + b*16 + 4*lk + (0..3), b = 0..3, of slice a: the statistics need the SAME elements of the K^ tile, so every
+    // lane re-reads exactly its own 16 values per slice (L2/MALL-warm) -- no cross-lane exchange.  They are fetched with
+    // LDS-DMA loads (global_load_lds_dwordx4: lane l's 16 bytes land at base + 16*l) into a wave-private double buffer,
+    // slice a+1 in flight while slice a is consumed, using no VGPRs (the accumulators fill the register file) and no
+    // block barriers.  Rows beyond the matrix are clamped (never written); ragged / unaligned column tiles take plain
+    // clamped loads.
     const int P = g.fs_P;
-    double av[4], zv[4][4], zsq[4];
+    const bool hyper = g.fs_hyper != 0;
+    const bool dma = ((g.lda & 1) == 0) && ((((uintptr_t)A) & 15) == 0) && (j0 + BN <= N);
+    double* flat = &lds.a[0][0];                  // Tile = 4 * TILE_DOUBLES contiguous doubles
+    double* stage = flat + w * 2048;              // [2 buffers][8 chunks (b, h)][64 lanes][2]
+    double* xs = flat + 4 * 2048;                 // [4][128] inputs of the block's rows / lengthscale (dimension-major)
+    double* zs = xs + 4 * 128;                    // [4][128] inducing inputs of the block's columns / lengthscale
+    static_assert(4 * 2048 + 2 * 4 * 128 <= 4 * TILE_DOUBLES, "epilogue scratch fits the tile buffers");
+    const int colq = j0 + wn * 64 + 4 * lk;       // + b*16 (+ 2h)
+    auto issue = [&](int a) {
+      const int grow = min(i0 + wm * 64 + a * 16 + lr, M - 1);
+      const double* src = A + (long long)grow * g.lda + colq;
+      double* dst = stage + (a & 1) * 1024;
+      if (dma) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int col = j0 + wn * 64 + b * 16 + lr;
-      const bool ok = col < N;
-      av[b] = ok ? g.fs_a[(long long)batch * g.fs_sA + col] : 0.0;
-      zsq[b] = 0.0;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        zv[b][p] = (ok && p < P) ? g.fs_z[(long long)batch * g.fs_sZ + (long long)col * g.fs_ldz + p] : 0.0;
-        zsq[b] += zv[b][p] * zv[b][p];
-      }
-    }
-    // LDS after the k-loop (which ended with a barrier): kbuf[32][130] (33 KB, over lds.a) holds one 32-row slice of the
-    // block's K^ tile, fetched with fully coalesced 16-byte loads; red[2][128][4] (8 KB, over lds.b) the row partials.
-    constexpr int KB_LD = 130;
-    double* kbuf = &lds.a[0][0];
-    double* red = &lds.b[0][0];
-    double* xs = red + 2 * 128 * 4;  // [128][4] inputs of the block's rows (staged once: no global latency in the row loop)
-    static_assert(32 * KB_LD <= 2 * TILE_DOUBLES && 2 * 128 * 4 + 128 * 4 <= 2 * TILE_DOUBLES, "epilogue scratch fits the tile buffers");
-    for (int e = t; e < 128 * 4; e += NTHREADS) {
-      const int rr = e >> 2, p = e & 3;
-      xs[e] = (i0 + rr < M && p < P) ? g.fs_x[(long long)(i0 + rr) * P + p] : 0.0;
-    }
-    const double ell_b = g.fs_ell[batch];
-    const double inv_l2 = 1.0 / (ell_b * ell_b);
-    const bool vecK = ((g.lda & 1) == 0) && ((((uintptr_t)A) & 15) == 0) && (j0 + BN <= N);
+        for (int c = 0; c < 8; ++c)               // chunk c = 2*b + h
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (c >> 1) * 16 + (c & 1) * 2),
+                                           (void __attribute__((address_space(3)))*)(dst + c * 128), 16, 0, 0);
+      } else {                                    // ragged / unaligned tile: same slots, plain clamped loads
+        const double* row = A + (long long)grow * g.lda;
 #pragma unroll 1
-    for (int a = 0; a < 4; ++a) {
-      // slice a = rows {wm*64 + a*16 + (0..15)} for wm = 0, 1: thread t stages row (t>>3), 16 columns from (t&7)*16
-      {
-        const int lrow = t >> 3, c16 = (t & 7) * 16;
-        const int grow = i0 + (lrow >> 4) * 64 + a * 16 + (lrow & 15);
-        const double* src = A + (long long)grow * g.lda + j0 + c16;
-        double* dst = kbuf + lrow * KB_LD + c16;
-        if (vecK && grow < M) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) *reinterpret_cast<f64x2*>(dst + 2 * e) = *reinterpret_cast<const f64x2*>(src + 2 * e);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) dst[e] = (grow < M && (j0 + c16 + e) < N) ? src[e] : 0.0;
+        for (int c = 0; c < 8; ++c) {
+          const int col = colq + (c >> 1) * 16 + (c & 1) * 2;
+          *reinterpret_cast<f64x2*>(dst + c * 128 + 2 * lane) = f64x2{row[min(col, N - 1)], row[min(col + 1, N - 1)]};
         }
       }
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rl = wm * 64 + a * 16 + 4 * r + lk, row = i0 + rl;
-        const bool rok = row < M;
-        double xv[4], xsq = 0.0;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          xv[p] = xs[rl * 4 + p];
-          xsq += xv[p] * xv[p];
-        }
-        (void)rok;
-        const double* krow = kbuf + (wm * 16 + 4 * r + lk) * KB_LD + wn * 64 + lr;
-        double sp = 0.0, sc = 0.0, spt = 0.0, sct = 0.0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const double kv = krow[b * 16];  // K^[row][j0 + wn*64 + b*16 + lr]
-          double pv;
-          switch (a) {  // acc[a] with a runtime slice index: select, never index (register arrays)
-            case 0: pv = acc[0][b][r]; break;
-            case 1: pv = acc[1][b][r]; break;
-            case 2: pv = acc[2][b][r]; break;
-            default: pv = acc[3][b][r]; break;
-          }
-          sp += kv * av[b];
-          sc += pv * kv;
-          if (g.fs_hyper) {
-            double dot = 0.0;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) dot += xv[p] * zv[b][p];
-            const double r2 = fmax(-2.0 * dot + (xsq + zsq[b]), 0.0) * inv_l2;
-            spt += kv * av[b] * r2;
-            sct += pv * kv * r2;
-          }
-        }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {  // sum over the 16 lanes that share this row
-          sp += __shfl_xor(sp, o, 64);
-          sc += __shfl_xor(sc, o, 64);
-          if (g.fs_hyper) {
-            spt += __shfl_xor(spt, o, 64);
-            sct += __shfl_xor(sct, o, 64);
-          }
-        }
-        if (lr == 0) {
-          double* o4 = red + ((wn * 128) + rl) * 4;
-          o4[0] = sp, o4[1] = sc, o4[2] = spt, o4[3] = sct;
-        }
+    };
+    issue(0);
+    {
+      const double inv_l = 1.0 / g.fs_ell[batch];
+      for (int e = t; e < 4 * 128; e += NTHREADS) {
+        const int p = e >> 7, rr = e & 127;
+        xs[e] = (hyper && i0 + rr < M && p < P) ? g.fs_x[(long long)(i0 + rr) * P + p] * inv_l : 0.0;
+        zs[e] = (hyper && j0 + rr < N && p < P) ? g.fs_z[(long long)batch * g.fs_sZ + (long long)(j0 + rr) * g.fs_ldz + p] * inv_l : 0.0;
       }
-      __syncthreads();  // kbuf is overwritten by the next slice
+      if (t < 128) epi_a[t] = (j0 + t < N) ? g.fs_a[(long long)batch * g.fs_sA + j0 + t] : 0.0;
     }
-    if (t < 128 && i0 + t < M) {
-      const int nst = g.fs_hyper ? 4 : 2;
-      for (int st = 0; st < nst; ++st)
-        fs_part[((long long)st * tiles_n + tj) * M + (i0 + t)] = red[t * 4 + st] + red[(128 + t) * 4 + st];
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // slice a has landed (and the previous partial stores)
+      if (a < 3) issue(a + 1);
+      const int rl = wm * 64 + a * 16 + lr;
+      double sp = 0.0, sc = 0.0, spt = 0.0, sct = 0.0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int cl = wn * 64 + b * 16 + 4 * lk;  // this lane's 4 adjacent columns of sub-tile b (within the tile)
+        const double* kp = stage + (a & 1) * 1024 + (2 * b) * 128 + 2 * lane;
+        const f64x2 k01 = *reinterpret_cast<const f64x2*>(kp), k23 = *reinterpret_cast<const f64x2*>(kp + 128);
+        const double kv[4] = {k01.x, k01.y, k23.x, k23.y};
+        const f64x2 a01 = *reinterpret_cast<const f64x2*>(epi_a + cl), a23 = *reinterpret_cast<const f64x2*>(epi_a + cl + 2);
+        const double av[4] = {a01.x, a01.y, a23.x, a23.y};
+        double r2[4] = {0.0, 0.0, 0.0, 0.0};
+        if (hyper) {
+#pragma unroll 1
+          for (int p = 0; p < P; ++p) {              // uniform trip count (P <= 4); rolled: bounded register pressure
+            const f64x2 z01 = *reinterpret_cast<const f64x2*>(zs + p * 128 + cl), z23 = *reinterpret_cast<const f64x2*>(zs + p * 128 + cl + 2);
+            const double zz[4] = {z01.x, z01.y, z23.x, z23.y};
+            const double xp = xs[p * 128 + rl];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const double d = xp - zz[r];
+              r2[r] += d * d;
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double pv = acc[a][b][r];
+          sp += kv[r] * av[r];
+          sc += pv * kv[r];
+          if (hyper) {
+            const double wv = kv[r] * r2[r];
+            spt += wv * av[r];
+            sct += pv * wv;
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {           // the four lanes (lk) that share this row
+        sp += __shfl_xor(sp, o, 64);
+        sc += __shfl_xor(sc, o, 64);
+        if (hyper) {
+          spt += __shfl_xor(spt, o, 64);
+          sct += __shfl_xor(sct, o, 64);
+        }
+      }
+      if (lk == 0 && i0 + rl < M) {                  // partial of column half (tj, wn): [stat][2*tiles_n][M]
+        double* o = fs_part + ((long long)(2 * tj + wn)) * M + (i0 + rl);
+        const long long ss = 2LL * tiles_n * M;
+        o[0] = sp, o[ss] = sc;
+        if (hyper) o[2 * ss] = spt, o[3 * ss] = sct;
+      }
     }
     if (!g.store_c) return;
   }
   if (idle_quadrant) return;  // the strictly-upper quadrant is never read (mirrored from the lower one)
+  if (SWAP) {  // lane (lr, lk): row wm*64 + a*16 + lr, columns wn*64 + b*16 + 4*lk + (0..3)
+    const bool vecC = ((g.ldc & 1) == 0) && ((((uintptr_t)C) & 15) == 0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int row = i0 + wm * 64 + a * 16 + lr;
+      if (row >= M) continue;
+      double* crow = C + (long long)row * g.ldc;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int col = j0 + wn * 64 + b * 16 + 4 * lk;
+        if (vecC && col + 3 < N && beta == 0.0) {
+          *reinterpret_cast<f64x2*>(crow + col) = f64x2{alpha * acc[a][b][0], alpha * acc[a][b][1]};
+          *reinterpret_cast<f64x2*>(crow + col + 2) = f64x2{alpha * acc[a][b][2], alpha * acc[a][b][3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (col + r < N) {
+              double val = alpha * acc[a][b][r];
+              if (beta != 0.0) val += beta * crow[col + r];
+              crow[col + r] = val;
+            }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
 #pragma unroll
