@@ -6,7 +6,7 @@
 
 #define HMOGP_WAVE 64
 #ifndef HMOGP_POTRF_NB
-#define HMOGP_POTRF_NB 32  // Cholesky / triangular-inverse panel width (32 or 64); dscr scratch is Q*M*HMOGP_POTRF_NB doubles
+#define HMOGP_POTRF_NB 32  // Cholesky / triangular-inverse panel width
 #endif
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -102,7 +102,7 @@ void launch_gemm_f64(const GemmArgs& g, hipStream_t stream);
 
 // ---- linear algebra on Q x M x M batches (linalg.hip) ---------------------------------------------------
 // In-place lower Cholesky of A[q]; info[q] = 0 or the 1-based index of the first non-positive pivot (LAPACK
-// dpotrf convention; the matrix content is then undefined). Upper triangle is zeroed. dscr: Q*M*HMOGP_POTRF_NB doubles.
+// dpotrf convention; the matrix content is then undefined). Upper triangle is zeroed. dscr: Q*M*M doubles (out-of-place factor).
 void launch_potrf_batched(double* A, int Q, int M, int* d_info, double* dscr, hipStream_t stream);
 // Linv[q] = L[q]^-1 (lower triangular, upper zero). `L` is preserved; tmp: Q*M*M doubles.
 void launch_trtri_batched(const double* L, double* Linv, double* tmp, int Q, int M, hipStream_t stream);

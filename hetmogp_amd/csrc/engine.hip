@@ -290,7 +290,7 @@ struct hmogp_engine {
     gL.ensure(sizeof(double) * ((long long)M * (M + 1) / 2) * Q);
     klout.ensure(sizeof(double) * Q * KL_BLOCKS * 5);
     rowout.ensure(sizeof(double) * Q * M * (2 + P));
-    dinfo.ensure(sizeof(int) * Q), djit.ensure(sizeof(double) * Q), dscr.ensure(sizeof(double) * Q * M * HMOGP_POTRF_NB);
+    dinfo.ensure(sizeof(int) * Q), djit.ensure(sizeof(double) * Q), dscr.ensure(sizeof(double) * Q * M * M);
     rung.assign(Q, -1);
   }
 
@@ -894,7 +894,7 @@ int hmogp_jitchol_inv(int32_t device, const double* A, int32_t Q, int32_t M, con
     const long long MM = (long long)M * M;
     DevBuf dA, dL, dLi, dT, dO, info, jit, scr;
     for (DevBuf* b : {&dA, &dL, &dLi, &dT, &dO}) b->ensure(sizeof(double) * MM * Q, true);
-    info.ensure(sizeof(int) * Q), jit.ensure(sizeof(double) * Q), scr.ensure(sizeof(double) * Q * M * HMOGP_POTRF_NB);
+    info.ensure(sizeof(int) * Q), jit.ensure(sizeof(double) * Q), scr.ensure(sizeof(double) * Q * M * M);
     HIP_TRY(hipMemcpy(dA.p, A, sizeof(double) * MM * Q, hipMemcpyHostToDevice));
     std::vector<double> dmean(Q);
     std::vector<int> r(Q);

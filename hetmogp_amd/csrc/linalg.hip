@@ -1,109 +1,217 @@
 // linalg.hip -- batched M x M linear algebra of the replicated part of the svmogp_inf path (gfx950).
 //
-//   potrf  : blocked right-looking lower Cholesky, LDS-resident 32 x 32 diagonal panels, trailing update on the
-//            FP64-MFMA GEMM.  Replaces LAPACK dpotrf behind GPy jitchol (hetmogp/util.py:198).
+//   potrf  : blocked right-looking lower Cholesky, one fused launch per 32-column panel (diagonal block in registers,
+//            panel solve, FP64-MFMA trailing update).  Replaces LAPACK dpotrf behind GPy jitchol (hetmogp/util.py:198).
 //   trtri  : triangular inverse by LDS diagonal-block inverses + log2(M/32) levels of batched GEMM merges.
 //   ltl    : (L L^T)^-1 = Linv^T Linv.  trtri + ltl replace LAPACK dpotri behind GPy dpotri
 //            (hetmogp/util.py:199, hetmogp/svmogp_inf.py:124).
 #include "common.h"
 
+long long* g_potrf_stamps = nullptr;  // probe_potrf.hip (-DPOTRF_STAMPS): phase time stamps of the first step launch
+
 namespace {
+
+#ifdef POTRF_STAMPS
+#define STAMP(i) do { if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) stamps[i] = clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 constexpr int NB = HMOGP_POTRF_NB;  // panel width (common.h)
 constexpr int NBP = NB + 1;  // padded LDS leading dimension
 
 // ---------------------------------------------------------------------------------------------- potrf
-// One launch per panel j.  Every block factorises the diagonal block redundantly in LDS (32^3/3 flops) and solves
-// 256 rows of the panel below it (one row per thread, L_jj read as LDS broadcasts).  The factorised diagonal block
-// is NOT written in place (late blocks of this launch still read the unfactorised one): block 0 parks it in
-// `dscr` ([Q][M][NB]) and potrf_finalize_kernel scatters it at the end.  info[q] != 0 makes the latent a no-op.
-__global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ Aall, int M, int j, int* __restrict__ info,
-                                                          double* __restrict__ dscr) {
-  __shared__ double D[NB][NBP];
+// Blocked right-looking lower Cholesky, ONE launch per 32-column panel j (the chain is latency-bound: 32 dependent
+// launches instead of the 64 of a separate panel-solve + trailing-GEMM pair).  Block (ti, tj), ti >= tj, owns the
+// 128 x 128 tile (ti, tj) of the trailing matrix W[j+32.., j+32..] and does everything that tile needs itself:
+//   1. factorises the 32 x 32 diagonal block W[j.., j..] (redundantly per block, first wave, in registers);
+//   2. solves the panel rows of row tiles ti and tj against it (one row per thread: threads 0..127 -> tile ti,
+//      128..255 -> tile tj) and parks them k-major in LDS;
+//   3. W_tile -= L21_i L21_j^T on the FP64 matrix cores (v_mfma_f64_16x16x4_f64, 4 waves x 64 x 64).
+// The factor is written OUT of place (`Lo`): blocks of this launch still read the
+// unfactorised panel of W.  Blocks (ti, 0) write the solved rows of tile ti, block 0 the diagonal block.
+// info[q] != 0 (LAPACK's pivot test: d <= 0 or NaN at column info-1) makes the latent a no-op for the later launches.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {  // wave-uniform broadcast through SGPRs
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+constexpr int LSP = 144;  // k-major leading dimension of the parked panel rows (same bank argument as gemm_f64.hip)
+
+// Factorisation of the 32 x 32 diagonal block by ONE wave, entirely in registers: lane r owns row r (lanes 32..63
+// mirror 0..31).  Column c needs the pivot from lane c and, for the rank-1 update, the scaled column entries L[c2][c]
+// from lanes c2 -- both by v_readlane broadcasts (compile-time lane numbers), no LDS round trips inside the recurrence.
+// Entries above the diagonal carry garbage that nothing reads.  Returns LAPACK's info (0, or 1 + the failing column).
+__device__ __forceinline__ int factor_diag_wave(double (*D)[NBP + 1], double* Dinv, int jb, int lane) {
+  const int r = lane & (NB - 1);
+  double a[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) a[c] = D[r][c];
+  int bad = 0;
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    const double d = readlane_f64(a[c], c);
+    if (c < jb && !bad && !(d > 0.0)) bad = c + 1;  // LAPACK: ajj <= 0 or NaN (uniform across lanes)
+    // pivot sqrt(d) and its reciprocal from v_rsq_f64 + Newton steps (a dependent chain of ~12 FMAs instead of an
+    // IEEE sqrt followed by an IEEE division; both end within an ulp or two of the correctly rounded values)
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * fma(-0.5 * d * y, y, 1.5);
+    y = y * fma(-0.5 * d * y, y, 1.5);
+    double piv = d * y;
+    piv = fma(0.5 * y, fma(-piv, piv, d), piv);
+    const double rinv = fma(y, fma(-piv, y, 1.0), y);
+    if (lane == c) Dinv[c] = rinv;
+    const double l = (r == c) ? piv : a[c] * rinv;
+    a[c] = l;
+#pragma unroll
+    for (int c2 = c + 1; c2 < NB; ++c2) a[c2] = fma(-l, readlane_f64(l, c2), a[c2]);
+  }
+  if (lane < NB)
+#pragma unroll
+    for (int c = 0; c < NB; ++c) D[r][c] = a[c];
+  return bad;
+}
+
+__global__ __launch_bounds__(320) void potrf_step_kernel(double* __restrict__ Wall, double* __restrict__ Lall, int M, int j,
+                                                         int* __restrict__ info, long long* stamps) {
+  STAMP(0);
+  __shared__ __attribute__((aligned(16))) double D[NB][NBP + 1];  // even leading dimension: 16-byte column pairs
+  __shared__ __attribute__((aligned(16))) double Ls[2][NB][LSP];
+  __shared__ double Dinv[NB];  // reciprocals of the pivots
   __shared__ int fail;
   const int q = blockIdx.y;
   if (info[q] != 0) return;
-  double* A = Aall + (long long)q * M * M;
-  const int jb = min(NB, M - j);
+  double* W = Wall + (long long)q * M * M;
+  double* Lo = Lall + (long long)q * M * M;
+  const int jb = min(NB, M - j), base = j + jb, rem = M - base;
   const int t = threadIdx.x;
+  int ti = 0, tj = 0;
+  {
+    const int v = blockIdx.x;
+    ti = (int)((sqrt(8.0 * (double)v + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= v) ++ti;
+    while (ti * (ti + 1) / 2 > v) --ti;
+    tj = v - ti * (ti + 1) / 2;
+  }
   if (t == 0) fail = 0;
   for (int e = t; e < NB * NB; e += blockDim.x) {
     const int r = e / NB, c = e % NB;
-    D[r][c] = (r < jb && c <= r) ? A[(long long)(j + r) * M + (j + c)] : 0.0;
+    D[r][c] = (r < jb && c <= r) ? W[(long long)(j + r) * M + (j + c)] : 0.0;
   }
   __syncthreads();
-  // The diagonal block is factorised by the first wave entirely in registers: lane r owns row r (32 doubles); column c
-  // needs the pivot from lane c and, for the rank-1 update, the scaled column entries L[c2][c] from lanes c2 -- both by
-  // wavefront shuffles (about 530 of them for the whole block), no LDS round trips or barriers inside the recurrence.
-  if (t < 64) {
-    const int r = t & (NB - 1);  // NB = 32: lanes 32..63 mirror lanes 0..31 (shuffles stay within the wave)
-    double a[NB];
+  STAMP(1);
+  // Wave 4 (threads 256..319) factorises the diagonal block while the other four have their panel rows in flight.
+  const int half = (t >> 7) & 1, tl = t & 127;
+  const int prow = base + (half ? tj : ti) * 128 + tl;
+  const bool pvalid = t < 256 && rem > 0 && prow < M;  // (a ragged last panel, jb < NB, has no rows below it: rem == 0)
+  double x[NB];
+  if (t >= 256) {
+    const int bad = factor_diag_wave(D, Dinv, jb, t & 63);
+    if (t == 256) fail = bad;
+  } else {
+    // Panel rows of the two row tiles (threads 0..127 -> tile ti, 128..255 -> tile tj): in flight while wave 4 factorises.
+    if (pvalid) {
+      const double* w = W + (long long)prow * M + j;
+      if ((M & 1) == 0) {
 #pragma unroll
-    for (int c = 0; c < NB; ++c) a[c] = D[r][c];
-    int bad = 0;
+        for (int c = 0; c < NB; c += 2) {
+          const f64x2 v2 = *reinterpret_cast<const f64x2*>(w + c);
+          x[c] = v2.x, x[c + 1] = v2.y;
+        }
+      } else {
 #pragma unroll
-    for (int c = 0; c < NB; ++c) {
-      const double d = __shfl(a[c], c, 64);
-      if (c < jb && !bad && !(d > 0.0)) bad = c + 1;  // LAPACK: ajj <= 0 or NaN (uniform across lanes)
-      const double piv = sqrt(d);
-      const double l = (r == c) ? piv : ((r > c) ? a[c] / piv : a[c]);
-      a[c] = l;
-#pragma unroll
-      for (int c2 = c + 1; c2 < NB; ++c2) {
-        const double lc2 = __shfl(l, c2, 64);
-        if (r >= c2) a[c2] -= l * lc2;
+        for (int c = 0; c < NB; ++c) x[c] = w[c];
       }
-    }
-    if (t < jb)
+    } else {
 #pragma unroll
-      for (int c = 0; c < NB; ++c) D[r][c] = a[c];
-    if (t == 0) fail = bad;
+      for (int c = 0; c < NB; ++c) x[c] = 0.0;
+    }
   }
   __syncthreads();
+  STAMP(2);
   if (fail) {
     if (blockIdx.x == 0 && t == 0) info[q] = j + fail;
     return;
   }
-  if (blockIdx.x == 0) {
-    double* ds = dscr + (long long)q * M * NB;
+  if (blockIdx.x == 0)
     for (int e = t; e < jb * NB; e += blockDim.x) {
       const int r = e / NB, c = e % NB;
-      ds[(long long)(j + r) * NB + c] = (c <= r) ? D[r][c] : 0.0;
+      if (c <= r) Lo[(long long)(j + r) * M + (j + c)] = D[r][c];
     }
-  }
-  // panel rows below the diagonal block:  x L_jj^T = a
-  const int row = j + jb + blockIdx.x * blockDim.x + t;
-  if (row < M) {
-    double* a = A + (long long)row * M + j;
-    double x[NB];
-#pragma unroll
-    for (int c = 0; c < NB; ++c) x[c] = (c < jb) ? a[c] : 0.0;
+  if (rem <= 0) return;
+  // x L_jj^T = w, right-looking: the updates of one column are independent FMAs (L_jj read as uniform LDS broadcasts)
+  if (t < 256) {
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
-      if (c < jb) {
-        double s = x[c];
+      x[c] *= Dinv[c];
 #pragma unroll
-        for (int k = 0; k < NB; ++k)
-          if (k < c) s -= x[k] * D[c][k];
-        x[c] = s / D[c][c];
-      }
+      for (int k = c + 1; k < NB; ++k) x[k] = fma(-x[c], D[k][c], x[k]);
+    }
+    if (pvalid && half == 0 && tj == 0) {
+      double* lo = Lo + (long long)prow * M + j;
+#pragma unroll
+      for (int c = 0; c < NB; ++c) lo[c] = x[c];
     }
 #pragma unroll
-    for (int c = 0; c < NB; ++c)
-      if (c < jb) a[c] = x[c];
+    for (int c = 0; c < NB; ++c) Ls[half][c][tl] = x[c];
   }
+  STAMP(7);
+  // This block's tile of the trailing matrix goes straight into the MFMA accumulators (D fragment: col = lane & 15,
+  // row = (lane >> 4) + 4 * reg); the loads are in flight across the barrier.
+  const int lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1, lr = lane & 15, lk = lane >> 4;
+  const bool idle = t >= 256 || (ti == tj && wm == 0 && wn == 1);  // factor wave; strictly-upper quadrant of a diagonal tile
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = base + ti * 128 + wm * 64 + a * 16 + 4 * r + lk;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int col = base + tj * 128 + wn * 64 + b * 16 + lr;
+        acc[a][b][r] = (!idle && row < M && col <= row) ? W[(long long)row * M + col] : 0.0;
+      }
+    }
+  __syncthreads();
+  STAMP(3);
+  if (idle) return;
+#pragma unroll
+  for (int kk = 0; kk < NB / 4; ++kk) {
+    double fa[4], fb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[i] = -Ls[0][kk * 4 + lk][wm * 64 + i * 16 + lr];  // W - L21_i L21_j^T
+      fb[i] = Ls[1][kk * 4 + lk][wn * 64 + i * 16 + lr];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+  }
+  STAMP(4);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = base + ti * 128 + wm * 64 + a * 16 + 4 * r + lk;
+      if (row >= M) continue;
+      double* wrow = W + (long long)row * M;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int col = base + tj * 128 + wn * 64 + b * 16 + lr;
+        if (col <= row) wrow[col] = acc[a][b][r];
+      }
+    }
+  STAMP(5);
 }
 
-// Zero the strict upper triangle and scatter the parked diagonal blocks.
-__global__ void potrf_finalize_kernel(double* __restrict__ A, int M, const double* __restrict__ dscr) {
+// A <- lower triangle of the out-of-place factor, zeros above the diagonal.
+__global__ void potrf_finalize_kernel(double* __restrict__ A, int M, const double* __restrict__ Lo) {
   const int q = blockIdx.z;
-  double* a = A + (long long)q * M * M;
+  const long long o = ((long long)q * M + blockIdx.y) * M;
   const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
   if (c >= M) return;
-  if (c > r)
-    a[(long long)r * M + c] = 0.0;
-  else if (c / NB == r / NB)
-    a[(long long)r * M + c] = dscr[((long long)q * M + r) * NB + (c % NB)];
+  A[o + c] = (c <= r) ? Lo[o + c] : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------- trtri
@@ -181,32 +289,15 @@ void launch_gemv_batched(const double* A, const double* x, double* y, int Q, int
   hipLaunchKernelGGL(gemv_kernel, dim3((M + 3) / 4, Q), dim3(256), 0, s, A, x, y, M, sx, incx);
 }
 
-void launch_potrf_batched(double* A, int Q, int M, int* d_info, double* dscr, hipStream_t stream) {
+// A (Q x M x M, in place) <- its lower Cholesky factor; `scr` is a Q x M x M scratch (the out-of-place factor).
+void launch_potrf_batched(double* A, int Q, int M, int* d_info, double* scr, hipStream_t stream) {
   HIP_TRY(hipMemsetAsync(d_info, 0, sizeof(int) * Q, stream));
   for (int j = 0; j < M; j += NB) {
-    const int jb = std::min(NB, M - j);
-    const int rem = M - j - jb;
-    const int nblk = std::max(1, (rem + 255) / 256);
-    hipLaunchKernelGGL(potrf_panel_kernel, dim3(nblk, Q), dim3(256), 0, stream, A, M, j, d_info, dscr);
-    if (rem > 0) {
-      GemmArgs g;
-      g.A = A + (long long)(j + jb) * M + j;
-      g.B = g.A;
-      g.C = A + (long long)(j + jb) * M + (j + jb);
-      g.M = g.N = rem;
-      g.K = jb;
-      g.lda = g.ldb = g.ldc = M;
-      g.nbatch = Q;
-      g.sA = g.sB = g.sC = (long long)M * M;
-      g.alpha = -1.0;
-      g.beta = 1.0;
-      g.a_kmajor = 0;
-      g.b_kmajor = 0;
-      g.lower_only = 1;
-      launch_gemm_f64(g, stream);
-    }
+    const int rem = M - j - std::min(NB, M - j);
+    const int T = (rem + 127) / 128;
+    hipLaunchKernelGGL(potrf_step_kernel, dim3(std::max(1, T * (T + 1) / 2), Q), dim3(320), 0, stream, A, scr, M, j, d_info, j == 0 ? g_potrf_stamps : nullptr);
   }
-  hipLaunchKernelGGL(potrf_finalize_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, stream, A, M, dscr);
+  hipLaunchKernelGGL(potrf_finalize_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, stream, A, M, scr);
 }
 
 // Linv = L^-1.  `tmp` is a Q x M x M scratch.
