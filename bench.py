@@ -82,8 +82,13 @@ def main():
 
     N, M, Q, P, T = args.rows, args.inducing, args.latents, 1, len(SPECS)
     prm, X, Y = make_case(SPECS, [N] * T, M=M, Q=Q, P=P, seed=20260929)
-    eng = Engine(SPECS, Q, M, P, device=local_rank)
+    eng = Engine(SPECS, Q, M, P, device=local_rank, reuse_outputs=True)   # gradients land in page-locked arrays
     eng.set_data(X, Y)                      # every rank holds the (tiny) raw data; it only touches its own rows
+    from hetmogp_amd.engine import pinned_empty
+    for k in ("Z", "m_u", "L_flat"):        # the optimiser's parameter vectors live in page-locked host memory: H2D by DMA
+        a = pinned_empty(np.shape(prm[k]))
+        a[...] = prm[k]
+        prm[k] = a
     reducer = hdist.StatsReducer(eng, device=local_rank) if world > 1 else None
     rb, re = hdist.shard_ranges([0] * T, [N] * T, rank, world)
 

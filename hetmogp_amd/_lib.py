@@ -74,6 +74,8 @@ EXPORTS = {
     "hmogp_log_predictive": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_int64, C.c_int32, C.c_uint64, c_double_p,
                                        c_double_p, c_double_p, c_double_p]),
     "hmogp_bench_contraction": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, c_double_p]),
+    "hmogp_host_alloc": (C.c_void_p, [C.c_uint64]),
+    "hmogp_host_free": (None, [C.c_void_p]),
     "hmogp_var_exp": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_int64, c_double_p, c_double_p, c_double_p,
                                 c_double_p, c_double_p, c_double_p]),
 }

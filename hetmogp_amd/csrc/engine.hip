@@ -780,6 +780,18 @@ extern "C" {
 
 int hmogp_abi_version(void) { return HMOGP_ABI_VERSION; }
 
+void* hmogp_host_alloc(uint64_t bytes) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || bytes == 0) return nullptr;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+void hmogp_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 int hmogp_create(const hmogp_config* cfg, hmogp_handle* out) {
   if (!out) return HMOGP_E_INVALID;
   *out = nullptr;

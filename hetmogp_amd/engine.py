@@ -40,10 +40,41 @@ def lik_param(name, **kw):
     return 0.0
 
 
+class _PinnedBlock(object):
+    """Owner of one hipHostMalloc allocation; freed when the last NumPy view goes away."""
+
+    def __init__(self, nbytes):
+        self.ptr = lib.hmogp_host_alloc(int(nbytes))
+        if not self.ptr:
+            raise MemoryError("hmogp_host_alloc(%d) failed" % nbytes)
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib.hmogp_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """NumPy array in page-locked host memory (hmogp_host_alloc): parameters kept in such arrays, and the gradients of an
+    ``Engine(reuse_outputs=True)``, move between host and HBM without the driver's staging copy."""
+    shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) if shape else 1
+    blk = _PinnedBlock(max(1, n) * dt.itemsize)
+    buf = (C.c_char * blk.nbytes).from_address(blk.ptr)
+    buf._owner = blk          # every NumPy view keeps `buf` (its base) alive, and with it the allocation
+    return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+
+
 class Engine(object):
     """specs: list of (likelihood class name, kwargs) per task, e.g. [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {})]."""
 
-    def __init__(self, specs, Q, M, P, device=0, chunk_rows=0, exact_zero_windows=False, cache_kuu=False):
+    def __init__(self, specs, Q, M, P, device=0, chunk_rows=0, exact_zero_windows=False, cache_kuu=False,
+                 reuse_outputs=False):
         self.specs = [(n, dict(k)) for n, k in specs]
         self.T, self.Q, self.M, self.P = len(specs), int(Q), int(M), int(P)
         f_index, d_index = [], []
@@ -66,6 +97,10 @@ class Engine(object):
         check(lib.hmogp_create(C.byref(cfg), C.byref(self._h)), None)
         self.N = [0] * self.T
         self.last = None
+        # reuse_outputs=True: g_m_u / g_L_u / g_Z are returned as views of page-locked arrays owned by the engine (DMA
+        # without the driver's staging copy); they are overwritten by the next evaluation -- copy what must persist.
+        self.reuse_outputs = bool(reuse_outputs)
+        self._pinned_out = None
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -120,8 +155,15 @@ class Engine(object):
 
     def _outputs(self, want_dL_dS=False):
         Q, M, P, Df = self.Q, self.M, self.P, self.Df
-        o = dict(elbo=np.zeros(1), g_m_u=np.zeros((M, Q)), g_L_u=np.zeros((self.Mtri, Q)), g_variance=np.zeros(Q),
-                 g_lengthscale=np.zeros(Q), g_W=np.zeros((Q, Df)), g_kappa=np.zeros((Q, Df)), g_Z=np.zeros((M, Q * P)))
+        if self.reuse_outputs:      # page-locked arrays owned by the engine, overwritten by the next evaluation
+            if self._pinned_out is None:
+                self._pinned_out = dict(g_m_u=pinned_empty((M, Q)), g_L_u=pinned_empty((self.Mtri, Q)),
+                                        g_Z=pinned_empty((M, Q * P)))
+            big = self._pinned_out
+        else:
+            big = dict(g_m_u=np.zeros((M, Q)), g_L_u=np.zeros((self.Mtri, Q)), g_Z=np.zeros((M, Q * P)))
+        o = dict(elbo=np.zeros(1), g_m_u=big["g_m_u"], g_L_u=big["g_L_u"], g_variance=np.zeros(Q),
+                 g_lengthscale=np.zeros(Q), g_W=np.zeros((Q, Df)), g_kappa=np.zeros((Q, Df)), g_Z=big["g_Z"])
         if want_dL_dS:
             o["dL_dS"] = np.zeros((Q, M, M))
         rung = np.zeros(Q, dtype=np.int32)

@@ -215,8 +215,16 @@ int hmogp_log_predictive(int32_t device, int32_t lik_id, double lik_param, int64
 
 /* Micro-benchmark of the two row-pass contractions on synthetic operands resident in HBM (tools/bench_gemm.py):
  * role 1: forward  P~[n,M] = K^[n,M] C[M,M];  role 2: weighted Gram  H[M,M] (lower tiles) = K^T diag(beta) K^ incl. the
- * slab reduction.  Returns the average milliseconds per launch over `iters` launches (HIP events).            */
+ * slab reduction; roles 3 / 4: role 1 with the fused row-statistics epilogue, with / without the P~ store.
+ * Returns the average milliseconds per launch over `iters` launches (HIP events).                              */
 int hmogp_bench_contraction(int32_t device, int32_t role, int64_t n, int32_t M, int32_t iters, double* avg_ms);
+
+/* Page-locked host memory (hipHostMalloc / hipHostFree).  Optional: parameter and gradient arrays that live in such
+ * memory are transferred by DMA without the driver's staging copy (the 12.6 MB L_flat / g_L_u at M = 1024, Q = 3 cost
+ * about 1 ms per evaluation from pageable memory).  Returns NULL without a HIP device or on failure.  No reference
+ * equivalent.                                                                                                       */
+void* hmogp_host_alloc(uint64_t bytes);
+void hmogp_host_free(void* p);
 
 #ifdef __cplusplus
 }

@@ -256,6 +256,33 @@ def test_kuu_cache_is_invisible():
         assert np.array_equal(np.asarray(o1[k]), np.asarray(o2[k])), k
 
 
+def test_pinned_parameters_and_reused_outputs():
+    """hmogp_host_alloc: parameters in page-locked arrays and gradients returned in engine-owned page-locked arrays
+    (reuse_outputs=True) give the same bits as the default pageable path; the reused arrays are overwritten by the
+    next evaluation."""
+    from hetmogp_amd.engine import pinned_empty
+    specs = [("Gaussian", {"sigma": 0.5}), ("Poisson", {})]
+    prm, prob, X, Y = synth(29, specs, [300, 250], 48, 2, 1, (1.0, 1.2))
+    plain, fast = make_engine(prob, X, Y), make_engine(prob, X, Y, reuse_outputs=True)
+    pp = dict(prm)
+    for k in ("Z", "m_u", "L_flat"):
+        a = pinned_empty(np.shape(prm[k]))
+        a[...] = prm[k]
+        pp[k] = a
+    o1, o2 = run(plain, prm), run(fast, pp)
+    for k in KEYS:
+        assert np.array_equal(np.asarray(o1[k]), np.asarray(o2[k])), k
+    gL = o2["g_L_u"]
+    keep = gL.copy()
+    pp["m_u"][...] = prm["m_u"] * 1.5
+    o3 = run(fast, pp)
+    assert o3["g_L_u"] is gL or np.shares_memory(o3["g_L_u"], gL)
+    assert not np.array_equal(keep, gL)                       # overwritten in place by the second evaluation
+    big = pinned_empty((1000, 7))
+    big[...] = 3.0
+    assert big.sum() == 21000.0 and big.flags["C_CONTIGUOUS"]
+
+
 @pytest.mark.slow
 def test_headline_size_properties():
     """BASELINE.json headline shape (N=200k/task would take the oracle hours): N_t = 50k, M = 1024, Q = 3 through
