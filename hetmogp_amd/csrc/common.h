@@ -85,6 +85,9 @@ struct GemmArgs {
   int fs_ldz = 0, fs_P = 1, fs_hyper = 0;
   long long fs_sPart = 0, fs_sA = 0, fs_sZ = 0;
   int store_c = 1;               // 0: do not write P~ at all (no consumer when the Z gradient is not requested)
+  int b_lower = 0;               // B is lower triangular (B[k][j] == 0 for k < j): the k-loop of column tile j starts at j0.
+                                 // Forward contraction with T = tril(C) + tril(C^T,-1) when only the quadratic forms
+                                 // k^T C k are wanted (no r2-weighted twins, no P~ store): half the products.
   // Exact-zero windows (rowpass.hip: launch_windows): K^ = s2 exp(-r2/2) underflows to exactly 0.0 beyond r ~ 38.6
   // lengthscales, so for spatially sorted rows it is banded.  role 1: win[2*ti], win[2*ti+1] = [lo, hi) column range
   // (multiples of 16) outside which every entry of row tile ti is exactly zero -> column tiles outside it are skipped

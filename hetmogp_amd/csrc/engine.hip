@@ -161,7 +161,7 @@ struct hmogp_engine {
   unsigned group_mask = HMOGP_GROUP_ALL;
   DevBuf dZ, dmu, dLflat, dvar, dell, dW, dkap;
   // M x M (each Q*M*M)
-  DevBuf Kuu, Luu, Kuui, L, S, KiS, KSK, C, Sqi, tmpA, tmpB, HK, G, GSK, dKmm, dLdS;
+  DevBuf Kuu, Luu, Kuui, L, S, KiS, KSK, C, Ctri, Sqi, tmpA, tmpB, HK, G, GSK, dKmm, dLdS;
   DevBuf a, Kr, gmu, gL, klout, rowout, dinfo, djit, dscr;
   // N x M workspaces and row vectors
   long long ws_rows = 0;
@@ -280,7 +280,7 @@ struct hmogp_engine {
     }
     // parameter + M x M buffers
     const size_t mmq = sizeof(double) * MM * Q;
-    for (DevBuf* b : {&Kuu, &Luu, &Kuui, &L, &S, &KiS, &KSK, &C, &Sqi, &tmpA, &tmpB, &HK, &G, &GSK, &dKmm, &dLdS}) b->ensure(mmq, true);
+    for (DevBuf* b : {&Kuu, &Luu, &Kuui, &L, &S, &KiS, &KSK, &C, &Ctri, &Sqi, &tmpA, &tmpB, &HK, &G, &GSK, &dKmm, &dLdS}) b->ensure(mmq, true);
     dZ.ensure(sizeof(double) * M * Q * P);
     dmu.ensure(sizeof(double) * M * Q);
     dLflat.ensure(sizeof(double) * ((long long)M * (M + 1) / 2) * Q);
@@ -413,6 +413,7 @@ struct hmogp_engine {
     mm(Kuui.d(), false, S.d(), true, KiS.d());
     mm(KiS.d(), false, Kuui.d(), true, KSK.d());
     launch_sub(KSK.d(), Kuui.d(), C.d(), MM * Q, st);             // C = K^-1 S K^-1 - K^-1
+    launch_tri_fold(C.d(), Ctri.d(), Q, M, st);                   // x^T Ctri x == x^T C x with a triangular matrix
     launch_trtri_batched(L.d(), tmpA.d(), tmpB.d(), Q, M, st);    // S^-1 = dpotri(L) (svmogp_inf.py:124)
     launch_ltl_batched(tmpA.d(), Sqi.d(), Q, M, st);
   }
@@ -459,7 +460,10 @@ struct hmogp_engine {
           Scope sc(this, CAT_FWD, 1);
           GemmArgs g;
           g.A = Kh.d(), g.lda = M, g.a_kmajor = 0, g.sA = sK;
-          g.B = C.d(), g.ldb = M, g.b_kmajor = 1, g.sB = MM;
+          // only the quadratic forms are wanted when neither the hyper-parameter nor the Z gradients are (SVI / VEM
+          // E-steps): the triangular fold of C gives them with half the products
+          const bool tri = !want_hyper && !want_z;
+          g.B = tri ? Ctri.d() : C.d(), g.ldb = M, g.b_kmajor = 1, g.sB = MM, g.b_lower = tri ? 1 : 0;
           g.C = Pt.d(), g.ldc = M, g.sC = sK;
           g.M = (int)n, g.N = M, g.K = M;
           g.nbatch = Q;
@@ -724,7 +728,7 @@ struct hmogp_engine {
         launch_rbf(dX.d(), P, n, P, dZ.d() + q * P, ldz, M, h_var[q], h_ell[q], kh, false, st, nullptr, false);
         GemmArgs g;
         g.A = kh, g.lda = M, g.a_kmajor = 0;
-        g.B = C.d() + q * MM, g.ldb = M, g.b_kmajor = 1;
+        g.B = Ctri.d() + q * MM, g.ldb = M, g.b_kmajor = 1, g.b_lower = 1;  // variances only: triangular fold of C
         g.C = pt, g.ldc = M;
         g.M = (int)n, g.N = M, g.K = M;
         g.role = 1;

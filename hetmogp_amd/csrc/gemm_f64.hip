@@ -148,6 +148,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
       return;
     }
   }
+  if (g.b_lower) wlo = max(wlo, min(j0, whi));  // rows k < j0 of a lower-triangular B are zeros for this column tile
   if (ROLE == 2 && win) {
     wlo = max(win[2 * ti], win[2 * tj]);
     whi = max(wlo, min(K, min(win[2 * ti + 1], win[2 * tj + 1])));

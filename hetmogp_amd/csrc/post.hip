@@ -21,6 +21,18 @@ __global__ void sub_kernel(const double* __restrict__ A, const double* __restric
   for (; i < n; i += stride) C[i] = A[i] - B[i];
 }
 
+// T = tril(C) + tril(C^T, -1): the lower-triangular matrix with x^T T x == x^T C x (C need not be exactly symmetric).
+// With it the quadratic forms k^T C k of the forward contraction cost half the products (GemmArgs::b_lower).
+__global__ void tri_fold_kernel(const double* __restrict__ C, double* __restrict__ T, int M) {
+  const long long o = (long long)blockIdx.z * M * M;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c >= M) return;
+  double v = 0.0;
+  if (c == r) v = C[o + (long long)r * M + c];
+  else if (c < r) v = C[o + (long long)r * M + c] + C[o + (long long)c * M + r];
+  T[o + (long long)r * M + c] = v;
+}
+
 // out[q][0] = sum(Kuui .* S), [1] = m^T a, [2] = sum log|diag Luu|, [3] = sum log|diag L|, [4] = #inf in Sqi
 __global__ __launch_bounds__(256) void kl_terms_kernel(const double* __restrict__ Kuui, const double* __restrict__ S,
                                                        const double* __restrict__ m_u, const double* __restrict__ a,
@@ -201,6 +213,9 @@ void launch_add_diag_copy(const double* src, double* dst, int Q, int M, const do
 void launch_sub(const double* A, const double* B, double* C, long long n, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(sub_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, s, A, B, C, n);
+}
+void launch_tri_fold(const double* C, double* T, int Q, int M, hipStream_t s) {
+  hipLaunchKernelGGL(tri_fold_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, C, T, M);
 }
 void launch_kl_terms(const double* Kuui, const double* S, const double* m_u, const double* a, const double* Luu,
                      const double* L, const double* Sqi, int Q, int M, double* out, hipStream_t s) {

@@ -256,6 +256,26 @@ def test_kuu_cache_is_invisible():
         assert np.array_equal(np.asarray(o1[k]), np.asarray(o2[k])), k
 
 
+def test_q_u_only_evaluation_uses_triangular_fold_and_matches_full():
+    """E-steps (group_mask = QU) take the forward contraction with T = tril(C) + tril(C^T,-1) (half the products); the
+    ELBO and the q(u) gradients must equal those of the full evaluation (ragged multi-tile M, two latents), and so must
+    predict_f, which uses the same fold."""
+    from oracle import svmogp_oracle as so
+    from hetmogp_amd import _lib
+    specs = [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {}), ("Gamma", {})]
+    prm, prob, X, Y = synth(31, specs, [700, 500, 600], 300, 2, 1, (1.0, 1.3))
+    e = make_engine(prob, X, Y)
+    full = run(e, prm)
+    qu = run(e, prm, group_mask=_lib.GROUP_QU)
+    for k in ("elbo", "g_m_u", "g_L_u"):
+        assert rel(qu[k], full[k]) < 1e-12, k
+    for k in ("g_variance", "g_lengthscale", "g_W", "g_kappa", "g_Z"):
+        assert not np.any(qu[k])
+    want = so.elbo_grad_fused(prm, prob, X, Y)
+    for k in ("elbo", "g_m_u", "g_L_u"):
+        assert rel(qu[k], want[k]) < TOL, k
+
+
 def test_pinned_parameters_and_reused_outputs():
     """hmogp_host_alloc: parameters in page-locked arrays and gradients returned in engine-owned page-locked arrays
     (reuse_outputs=True) give the same bits as the default pageable path; the reused arrays are overwritten by the
