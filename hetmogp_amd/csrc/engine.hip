@@ -180,6 +180,8 @@ struct hmogp_engine {
   double ms[NCAT] = {0};
   long long launches[NCAT] = {0};
   hipEvent_t ev_begin0 = nullptr, ev_begin1 = nullptr, ev_fin0 = nullptr, ev_fin1 = nullptr;
+  hipStream_t st2 = nullptr;  // second stream: the q(u)-only chain of u_algebra
+  hipEvent_t ev_fork = nullptr, ev_S = nullptr, ev_join = nullptr;
 
   hipEvent_t new_event() {
     if (pool_used == pool.size()) {
@@ -215,8 +217,9 @@ struct hmogp_engine {
 
   ~hmogp_engine() {
     for (auto e : pool) (void)hipEventDestroy(e);
-    for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1})
+    for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_S, ev_join})
       if (e) (void)hipEventDestroy(e);
+    if (st2) (void)hipStreamDestroy(st2);
     if (st) (void)hipStreamDestroy(st);
   }
 
@@ -238,6 +241,8 @@ struct hmogp_engine {
     if (device < 0 || device >= ndev) throw EngineError{HMOGP_E_NO_DEVICE, "HIP device ordinal out of range"};
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&ev_fork, &ev_S, &ev_join}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (hipEvent_t* e : {&ev_begin0, &ev_begin1, &ev_fin0, &ev_fin1}) HIP_TRY(hipEventCreate(e));
     f_index.assign(c->f_index, c->f_index + Df);
     d_index.assign(c->d_index, c->d_index + Df);
@@ -366,7 +371,7 @@ struct hmogp_engine {
 
   // batched (over q) M x M GEMM helper
   void mm(const double* A, bool a_k, const double* B, bool b_k, double* Cc, double alpha = 1.0, long long sA = -1,
-          int lda = -1) {
+          int lda = -1, hipStream_t stream = nullptr) {
     GemmArgs g;
     const long long MM = (long long)M * M;
     g.A = A, g.B = B, g.C = Cc;
@@ -376,7 +381,7 @@ struct hmogp_engine {
     g.sA = sA >= 0 ? sA : MM, g.sB = g.sC = MM;
     g.a_kmajor = a_k, g.b_kmajor = b_k;
     g.alpha = alpha;
-    launch_gemm_f64(g, st);
+    launch_gemm_f64(g, stream ? stream : st);
   }
 
   // ------------------------------------------------------------------------------------------ u algebra
@@ -388,6 +393,16 @@ struct hmogp_engine {
     // HMOGP_CFG_CACHE_KUU they are reused while those inputs are bit-identical to the previous evaluation's -- the
     // variational E-steps of VEM / SVI change q(u) only (util.py:294-306, svmogp.py:188-199).  The reference recomputes
     // them on every call (util.py:181-200); the result is the same.
+    // The chain that only depends on q(u)'s factor -- L, S = L L^T, S^-1 -- runs on a second stream, concurrently with
+    // the (latency-bound, few-CU) factorisation and inversion of K_uu; scratch: HK, G (unused before hmogp_step_finish).
+    HIP_TRY(hipEventRecord(ev_fork, st));
+    HIP_TRY(hipStreamWaitEvent(st2, ev_fork, 0));
+    launch_unpack_tril(dLflat.d(), L.d(), Q, M, st2);             // flat_to_triang   (svmogp_inf.py:193)
+    mm(L.d(), false, L.d(), false, S.d(), 1.0, -1, -1, st2);      // S = L L^T        (:194-195)
+    HIP_TRY(hipEventRecord(ev_S, st2));
+    launch_trtri_batched(L.d(), HK.d(), G.d(), Q, M, st2);        // S^-1 = dpotri(L) (svmogp_inf.py:124)
+    launch_ltl_batched(HK.d(), Sqi.d(), Q, M, st2);
+    HIP_TRY(hipEventRecord(ev_join, st2));
     std::vector<double> key;
     if (cache_kuu) {
       key.assign(h_Z.begin(), h_Z.end());
@@ -407,15 +422,13 @@ struct hmogp_engine {
       launch_ltl_batched(tmpA.d(), Kuui.d(), Q, M, st);             // K_uu^-1          (util.py:199)
       if (cache_kuu) kuu_key.swap(key), kuu_rung = rung, kuu_key_valid = true;
     }
-    launch_unpack_tril(dLflat.d(), L.d(), Q, M, st);              // flat_to_triang   (svmogp_inf.py:193)
-    mm(L.d(), false, L.d(), false, S.d());                        // S = L L^T        (:194-195)
     launch_gemv_batched(Kuui.d(), dmu.d(), a.d(), Q, M, 1, Q, st);  // a = K_uu^-1 m
+    HIP_TRY(hipStreamWaitEvent(st, ev_S, 0));
     mm(Kuui.d(), false, S.d(), true, KiS.d());
     mm(KiS.d(), false, Kuui.d(), true, KSK.d());
     launch_sub(KSK.d(), Kuui.d(), C.d(), MM * Q, st);             // C = K^-1 S K^-1 - K^-1
     launch_tri_fold(C.d(), Ctri.d(), Q, M, st);                   // x^T Ctri x == x^T C x with a triangular matrix
-    launch_trtri_batched(L.d(), tmpA.d(), tmpB.d(), Q, M, st);    // S^-1 = dpotri(L) (svmogp_inf.py:124)
-    launch_ltl_batched(tmpA.d(), Sqi.d(), Q, M, st);
+    HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));
   }
 
   // ------------------------------------------------------------------------------------------ row pass
@@ -568,18 +581,24 @@ struct hmogp_engine {
       mm(Hq(0), false, Kuui.d(), true, HK.d(), 1.0, per_q);          // H K^-1
       mm(Kuui.d(), false, HK.d(), true, G.d());                      // G = K^-1 H K^-1  (dVE_dS, svmogp_inf.py:148)
       launch_gemv_batched(Kuui.d(), Hq(0) + oR, Kr.d(), Q, M, per_q, 1, st);  // K^-1 r  (dVE_dmu, :144)
+      // two independent tails: the K_uu-side gradients stay on the main stream, the q(u) gradients and the KL terms
+      // go to the second one
+      HIP_TRY(hipEventRecord(ev_fork, st));
+      HIP_TRY(hipStreamWaitEvent(st2, ev_fork, 0));
+      if (want_qu) {
+        launch_dlds(G.d(), Kuui.d(), Sqi.d(), dLdS.d(), MM * Q, st2);
+        mm(dLdS.d(), false, L.d(), true, tmpA.d(), 1.0, -1, -1, st2);  // dL_dS L        (:175-177)
+        launch_pack_gl(tmpA.d(), gL.d(), Q, M, st2);
+        launch_gmu(Kr.d(), a.d(), gmu.d(), Q, M, st2);
+      }
+      launch_kl_terms(Kuui.d(), S.d(), dmu.d(), a.d(), Luu.d(), L.d(), Sqi.d(), Q, M, klout.d(), st2);
+      HIP_TRY(hipEventRecord(ev_join, st2));
       if (want_hz) {
         mm(G.d(), false, KiS.d(), false, GSK.d());                   // G S K^-1        (tmp_dv, :151)
         launch_dkmm(G.d(), GSK.d(), Kuui.d(), KSK.d(), Kr.d(), a.d(), dKmm.d(), Q, M, st);
         launch_kzz_rows(dKmm.d(), dZ.d(), Q * P, P, dvar.d(), dell.d(), Q, M, rowout.d(), st);
       }
-      if (want_qu) {
-        launch_dlds(G.d(), Kuui.d(), Sqi.d(), dLdS.d(), MM * Q, st);
-        mm(dLdS.d(), false, L.d(), true, tmpA.d());                  // dL_dS L          (:175-177)
-        launch_pack_gl(tmpA.d(), gL.d(), Q, M, st);
-        launch_gmu(Kr.d(), a.d(), gmu.d(), Q, M, st);
-      }
-      launch_kl_terms(Kuui.d(), S.d(), dmu.d(), a.d(), Luu.d(), L.d(), Sqi.d(), Q, M, klout.d(), st);
+      HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));
     }
     // ---- device -> host ------------------------------------------------------------------------------
     std::vector<double> hg(NG), hkl((size_t)Q * KL_BLOCKS * 5), htail(Q * (per_q - oDZ)), hrow(want_hz ? (size_t)Q * M * (2 + P) : 0);
