@@ -142,7 +142,7 @@ void jitchol_batched(const double* Kuu, double* Luu, int Q, int M, const double*
 // =================================================================================================== engine
 struct hmogp_engine {
   int T = 0, Q = 0, M = 0, P = 0, Df = 0, device = 0;
-  long long chunk = 262144;
+  long long chunk = 1048576;  // rows per pool (hmogp_config.chunk_rows); workspaces are sized by the rows actually streamed
   bool use_windows = false, cache_kuu = false, kuu_key_valid = false;
   std::vector<double> h_Z, kuu_key;
   std::vector<int> rung_request, kuu_rung;
@@ -166,7 +166,7 @@ struct hmogp_engine {
   // N x M workspaces and row vectors
   long long ws_rows = 0;
   DevBuf Kh, Pt, vp, vc, vpt, vct, valpha, vbeta, valpha0, vbeta0;
-  DevBuf stats, slabs, colpart, quadpart, fwdpart, winrow, wincol, winhit;
+  DevBuf stats, slabs, colpart, quadpart, fwdpart, winrow, wincol, winhit, Xws;
   bool began = false, evaluated = false;
 
   // timing
@@ -320,7 +320,7 @@ struct hmogp_engine {
     rows = std::max<long long>(rows, 1);
     if (rows <= ws_rows) return;
     const size_t nm = sizeof(double) * rows * M * Q, nv = sizeof(double) * rows * Q;
-    Kh.ensure(nm), Pt.ensure(nm);
+    Kh.ensure(nm), Pt.ensure(nm), Xws.ensure(sizeof(double) * rows * P);
     for (DevBuf* b : {&vp, &vc, &vpt, &vct, &valpha, &vbeta, &valpha0, &vbeta0}) b->ensure(nv, true);
     colpart.ensure(sizeof(double) * ((rows + 255) / 256) * M * (1 + P) * Q);
     quadpart.ensure(sizeof(double) * (rows * 64 / 256 + 1) * HMOGP_MAXSCAL);
@@ -437,39 +437,66 @@ struct hmogp_engine {
     const int ldz = Q * P;
     const bool want_hyper = (group_mask & (HMOGP_GROUP_HYPER | HMOGP_GROUP_Z)) != 0;
     const bool want_z = (group_mask & HMOGP_GROUP_Z) != 0;
+    // Rows are streamed in POOLS of at most `chunk` rows.  Everything between the covariance construction and the
+    // quadrature, and everything after it, is independent of which task a row belongs to (K^ C_q, the row statistics,
+    // the weighted Gram and the column statistics only see rows), so a pool concatenates row ranges ("segments") of
+    // consecutive tasks: one forward contraction, one Gram product and one column-statistics pass per pool instead of
+    // one per task -- fewer, larger launches (tails, launch-bound reductions; matters most for minibatches and for
+    // the per-rank shares of a multi-GPU run).  Only K_uf construction and the quadrature run per segment.  The
+    // exact-zero windows need spatially sorted rows per launch, so that mode keeps one task per pool.
+    struct Seg { int t; long long r0, n, off; };
+    std::vector<std::vector<Seg>> pools;
+    {
+      std::vector<Seg> cur;
+      long long fill = 0;
+      for (int t = 0; t < T; ++t)
+        for (long long r0 = rb[t]; r0 < re[t];) {
+          const long long n = std::min(chunk - fill, re[t] - r0);
+          cur.push_back(Seg{t, r0, n, fill});
+          fill += n, r0 += n;
+          if (fill == chunk || use_windows) pools.push_back(cur), cur.clear(), fill = 0;
+        }
+      if (!cur.empty()) pools.push_back(cur);
+    }
     long long maxrows = 1;
-    for (int t = 0; t < T; ++t) maxrows = std::max(maxrows, std::min(chunk, re[t] - rb[t]));
+    for (auto& pl : pools) maxrows = std::max(maxrows, pl.back().off + pl.back().n);
     ensure_workspace(maxrows);
     const long long ldn = ws_rows;
     HIP_TRY(hipMemsetAsync(stats.p, 0, sizeof(double) * nstats, st));
-    const int tiles = (M + 127) / 128, ntl = tiles * (tiles + 1) / 2;
+    const int tiles = (M + 127) / 128;
     const long long wtiles = (ws_rows + 127) / 128;
-    (void)ntl;
-    for (int t = 0; t < T; ++t) {
-      Task& k = tasks[t];
-      for (long long r0 = rb[t]; r0 < re[t]; r0 += chunk) {
-        const long long n = std::min(chunk, re[t] - r0);
-        const double* X = k.X.d() + r0 * P;
-        const long long sK = ldn * M;                       // per-latent stride of the K^ / P~ workspaces
-        const int ncb = (M + 127) / 128;
-        int* rw = use_windows ? winrow.as<int>() : nullptr;  // [Q][wtiles][2]
-        int* cw = use_windows ? wincol.as<int>() : nullptr;  // [Q][ncb][2]
-        {
-          // K_uf for all latents in one launch (grid.z = latent)
-          Scope sc(this, CAT_RBF, use_windows ? 1 + 3 * Q : 1);
+    const long long sK = ldn * M;                           // per-latent stride of the K^ / P~ workspaces
+    const int ncb = (M + 127) / 128;
+    for (auto& pl : pools) {
+      const long long n = pl.back().off + pl.back().n;      // rows of this pool
+      int* rw = use_windows ? winrow.as<int>() : nullptr;    // [Q][wtiles][2]
+      int* cw = use_windows ? wincol.as<int>() : nullptr;    // [Q][ncb][2]
+      const double* X = tasks[pl[0].t].X.d() + pl[0].r0 * P; // inputs of the pool's rows
+      if (pl.size() > 1) {
+        for (auto& sg : pl)
+          HIP_TRY(hipMemcpyAsync(Xws.d() + sg.off * P, tasks[sg.t].X.d() + sg.r0 * P, sizeof(double) * sg.n * P,
+                                 hipMemcpyDeviceToDevice, st));
+        X = Xws.d();
+      }
+      {
+        // K_uf for all latents in one launch per segment (grid.z = latent)
+        Scope sc(this, CAT_RBF, (int)pl.size() + (use_windows ? 3 * Q : 0));
+        for (auto& sg : pl) {
+          const double* Xs = tasks[sg.t].X.d() + sg.r0 * P;
           if (use_windows)
             for (int q = 0; q < Q; ++q)
-              launch_windows(X, n, P, dZ.d() + q * P, ldz, M, h_ell[q], rw + 2 * wtiles * q, cw + 2 * ncb * q,
+              launch_windows(Xs, sg.n, P, dZ.d() + q * P, ldz, M, h_ell[q], rw + 2 * wtiles * q, cw + 2 * ncb * q,
                              winhit.as<unsigned char>(), st);
           RbfBatch rbt;
           rbt.nq = Q, rbt.var = dvar.d(), rbt.ell = dell.d(), rbt.sZ = P, rbt.sK = sK, rbt.sWin = 2 * wtiles;
-          launch_rbf(X, P, n, P, dZ.d(), ldz, M, 0.0, 1.0, Kh.d(), false, st, rw, false, &rbt);
+          launch_rbf(Xs, P, sg.n, P, dZ.d(), ldz, M, 0.0, 1.0, Kh.d() + sg.off * M, false, st, rw, false, &rbt);
         }
+      }
+      {
+        // forward contraction for all latents (batched), row statistics fused into its epilogue; P~ itself is only
+        // stored when the Z gradient (its one remaining consumer, colstats) is requested
+        const long long sPart = 8LL * tiles * ldn;
         {
-          // forward contraction for all latents (batched), row statistics fused into its epilogue; P~ itself is only
-          // stored when the Z gradient (its one remaining consumer, colstats) is requested
-          const long long sPart = 8LL * tiles * ldn;
-          {
           Scope sc(this, CAT_FWD, 1);
           GemmArgs g;
           g.A = Kh.d(), g.lda = M, g.a_kmajor = 0, g.sA = sK;
@@ -486,19 +513,21 @@ struct hmogp_engine {
           g.store_c = want_z ? 1 : 0;
           g.win = rw, g.win_stride = 2 * wtiles;
           launch_gemm_f64(g, st);
-          }
-          Scope sc2(this, CAT_ROWSTATS, 1);  // sum of the per-column-tile partials of the fused row statistics
-          launch_combine_parts(fwdpart.d(), 2 * tiles, n, vp.d(), vc.d(), want_hyper ? vpt.d() : nullptr,
-                               want_hyper ? vct.d() : nullptr, st, Q, sPart, ldn);
         }
-        {
-          Scope sc(this, CAT_QUAD, 2);
+        Scope sc2(this, CAT_ROWSTATS, 1);  // sum of the per-column-tile partials of the fused row statistics
+        launch_combine_parts(fwdpart.d(), 2 * tiles, n, vp.d(), vc.d(), want_hyper ? vpt.d() : nullptr,
+                             want_hyper ? vct.d() : nullptr, st, Q, sPart, ldn);
+      }
+      {
+        Scope sc(this, CAT_QUAD, 2 * (int)pl.size());
+        for (auto& sg : pl) {
+          Task& k = tasks[sg.t];
           QuadArgs qa;
-          qa.lik = k.lik, qa.lik_param = k.param, qa.dimf = k.dimf, qa.Q = Q, qa.N = n;
-          qa.y = k.Y.d() + r0;
-          qa.yaux = k.Yaux.p ? k.Yaux.d() + r0 : nullptr;
-          qa.p = vp.d(), qa.c = vc.d();
-          qa.pt = want_hyper ? vpt.d() : nullptr, qa.ct = want_hyper ? vct.d() : nullptr;
+          qa.lik = k.lik, qa.lik_param = k.param, qa.dimf = k.dimf, qa.Q = Q, qa.N = sg.n;
+          qa.y = k.Y.d() + sg.r0;
+          qa.yaux = k.Yaux.p ? k.Yaux.d() + sg.r0 : nullptr;
+          qa.p = vp.d() + sg.off, qa.c = vc.d() + sg.off;
+          qa.pt = want_hyper ? vpt.d() + sg.off : nullptr, qa.ct = want_hyper ? vct.d() + sg.off : nullptr;
           qa.ldn = ldn;
           std::memset(qa.w, 0, sizeof(qa.w)), std::memset(qa.w0, 0, sizeof(qa.w0)), std::memset(qa.kap, 0, sizeof(qa.kap));
           std::memset(qa.var, 0, sizeof(qa.var));
@@ -510,43 +539,44 @@ struct hmogp_engine {
               qa.kap[q][j] = h_kap[q * Df + k.d0 + j];
             }
           }
-          qa.scale = h_bs[t];
-          qa.alpha = valpha.d(), qa.beta = vbeta.d(), qa.alpha0 = valpha0.d(), qa.beta0 = vbeta0.d();
+          qa.scale = h_bs[sg.t];
+          qa.alpha = valpha.d() + sg.off, qa.beta = vbeta.d() + sg.off;
+          qa.alpha0 = valpha0.d() + sg.off, qa.beta0 = vbeta0.d() + sg.off;
           qa.partials = quadpart.d();
           launch_quad(qa, st);
-          launch_reduce_rows(quadpart.d(), quad_blocks(k.lik, n), k.nscal, k.offsets.as<long long>(), stats.d(), true, st);
+          launch_reduce_rows(quadpart.d(), quad_blocks(k.lik, sg.n), k.nscal, k.offsets.as<long long>(), stats.d(), true, st);
         }
+      }
+      {
+        // H_q += K^T diag(beta) K^ for all latents (svmogp_inf.py:145-147 summed over d)
+        const int ksplit = use_windows ? std::min(8, gram_ksplit(n, M)) : gram_ksplit(n, M);
+        slabs.ensure(sizeof(double) * MM * 64 * Q, true);
+        GemmArgs g;
+        g.A = Kh.d(), g.lda = M, g.a_kmajor = 1, g.sA = sK;
+        g.B = Kh.d(), g.ldb = M, g.b_kmajor = 1, g.sB = sK;
+        g.kscale = vbeta.d(), g.sS = ldn;
+        g.C = slabs.d(), g.ldc = M, g.sC = MM * 64;
+        g.M = g.N = M, g.K = (int)n;
+        g.nbatch = Q;
+        g.lower_only = 1;
+        g.ksplit = ksplit, g.sSplit = MM;
+        g.role = 2;
+        g.win = cw, g.win_stride = 2 * ncb;
         {
-          // H_q += K^T diag(beta) K^ for all latents (svmogp_inf.py:145-147 summed over d)
-          const int ksplit = use_windows ? std::min(8, gram_ksplit(n, M)) : gram_ksplit(n, M);
-          slabs.ensure(sizeof(double) * MM * 64 * Q, true);
-          GemmArgs g;
-          g.A = Kh.d(), g.lda = M, g.a_kmajor = 1, g.sA = sK;
-          g.B = Kh.d(), g.ldb = M, g.b_kmajor = 1, g.sB = sK;
-          g.kscale = vbeta.d(), g.sS = ldn;
-          g.C = slabs.d(), g.ldc = M, g.sC = MM * 64;
-          g.M = g.N = M, g.K = (int)n;
-          g.nbatch = Q;
-          g.lower_only = 1;
-          g.ksplit = ksplit, g.sSplit = MM;
-          g.role = 2;
-          g.win = cw, g.win_stride = 2 * ncb;
-          {
-            Scope sc(this, CAT_GRAM, 1);
-            launch_gemm_f64(g, st);
-          }
-          Scope sc2(this, CAT_COLSTATS, 1);  // row-range slabs -> bundle (accounted with the column statistics)
-          launch_reduce_slabs_lower(slabs.d(), ksplit, M, Hq(0), true, st, Q, MM * 64, per_q);
+          Scope sc(this, CAT_GRAM, 1);
+          launch_gemm_f64(g, st);
         }
-        {
-          Scope sc(this, CAT_COLSTATS, 2);
-          const long long len = (long long)M * (1 + P), nsp = (n + 255) / 256;
-          ColBatch cb;
-          cb.nq = Q, cb.sK = sK, cb.sA = M, cb.sV = ldn, cb.sZ = P, cb.sPart = nsp * len, cb.sWin = 2 * ncb;
-          launch_colstats(Kh.d(), Pt.d(), a.d(), valpha.d(), valpha0.d(), vbeta0.d(), X, P, dZ.d(), ldz, n, M, 256, want_z,
-                          colpart.d(), st, cw, &cb);
-          launch_reduce_slabs(colpart.d(), (int)nsp, len, len, Hq(0) + oR, true, st, Q, nsp * len, per_q);
-        }
+        Scope sc2(this, CAT_COLSTATS, 1);  // row-range slabs -> bundle (accounted with the column statistics)
+        launch_reduce_slabs_lower(slabs.d(), ksplit, M, Hq(0), true, st, Q, MM * 64, per_q);
+      }
+      {
+        Scope sc(this, CAT_COLSTATS, 2);
+        const long long len = (long long)M * (1 + P), nsp = (n + 255) / 256;
+        ColBatch cb;
+        cb.nq = Q, cb.sK = sK, cb.sA = M, cb.sV = ldn, cb.sZ = P, cb.sPart = nsp * len, cb.sWin = 2 * ncb;
+        launch_colstats(Kh.d(), Pt.d(), a.d(), valpha.d(), valpha0.d(), vbeta0.d(), X, P, dZ.d(), ldz, n, M, 256, want_z,
+                        colpart.d(), st, cw, &cb);
+        launch_reduce_slabs(colpart.d(), (int)nsp, len, len, Hq(0) + oR, true, st, Q, nsp * len, per_q);
       }
     }
     launch_mirror_lower(Hq(0), Q, M, per_q, st);

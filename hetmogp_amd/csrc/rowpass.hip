@@ -398,17 +398,35 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const double* __restri
     *d = accumulate ? (*d + s) : s;
   }
 }
-// dst[i] (+)= sum_s slabs[s*stride + i], i < len ; coalesced over i
+// dst[i] (+)= sum_s slabs[s*stride + i], i < len.  Block = 16 columns x 16 slab lanes: thread (c, g) sums the slabs
+// g, g+16, ... of column c (independent loads, 128-byte segments), the 16 partial sums are added in a fixed order.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const double* __restrict__ slabs, int nslabs, long long stride,
                                                            long long len, double* __restrict__ dst, int accumulate,
                                                            long long sSlabs, long long sDst) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= len) return;
+  __shared__ double part[16][17];
+  const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const long long i = (long long)blockIdx.x * 16 + c;
   slabs += (long long)blockIdx.y * sSlabs;
   dst += (long long)blockIdx.y * sDst;
-  double s = 0.0;
-  for (int b = 0; b < nslabs; ++b) s += slabs[b * stride + i];
-  dst[i] = accumulate ? dst[i] + s : s;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (i < len) {
+    int b = g;
+    for (; b + 48 < nslabs; b += 64) {
+      s0 += slabs[b * stride + i];
+      s1 += slabs[(b + 16) * stride + i];
+      s2 += slabs[(b + 32) * stride + i];
+      s3 += slabs[(b + 48) * stride + i];
+    }
+    for (; b < nslabs; b += 16) s0 += slabs[b * stride + i];
+  }
+  part[g][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && i < len) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += part[k][c];
+    dst[i] = accumulate ? dst[i] + s : s;
+  }
 }
 // dst[i][j] (+)= sum_s slabs[s][i][j] over the LOWER 128 x 128 tiles only (the Gram product never writes the others)
 __global__ __launch_bounds__(256) void reduce_slabs_lower_kernel(const double* __restrict__ slabs, int nslabs, int M,
@@ -677,7 +695,7 @@ void launch_reduce_rows(const double* partials, long long nrows, int len, const 
 void launch_reduce_slabs(const double* slabs, int nslabs, long long stride, long long len, double* dst, bool accumulate,
                          hipStream_t s, int nb, long long sSlabs, long long sDst) {
   if (len <= 0) return;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((len + 255) / 256), nb), dim3(256), 0, s, slabs, nslabs, stride, len,
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((len + 15) / 16), nb), dim3(256), 0, s, slabs, nslabs, stride, len,
                      dst, accumulate ? 1 : 0, sSlabs, sDst);
 }
 
