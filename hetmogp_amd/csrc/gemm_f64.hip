@@ -171,9 +171,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
   const bool fullB = alignB && (j0 + BN <= N);
 
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int wm = w >> 1, wn = w & 1, lr = lane & 15, lk = lane >> 4;
-  // lower-only products: on a diagonal tile the wave that owns the strictly-upper 64 x 64 quadrant has nothing to
-  // compute (it still takes part in staging and barriers)
+  const int lr = lane & 15, lk = lane >> 4;
+  // Lower-only products, diagonal tiles.  ROLE 2 (the weighted Gram, 8 of its 36 tiles at M = 1024) spreads the 36
+  // sub-tiles on or below the diagonal over all four waves: the two diagonal quadrants keep their 10 lower sub-tiles
+  // each (`mma_mode` 1), and the full quadrant (1,0) is shared by its own wave (sub-tile rows 0..1, mode 2) and the
+  // wave whose quadrant (0,1) is never read (rows 2..3, mode 3): at most 10 MFMAs per wave and k4-step instead of 16.
+  // Elsewhere (ROLE 0) the wave of the strictly-upper quadrant just idles (it still stages and takes the barriers).
+  const bool diag2 = ROLE == 2 && g.lower_only && ti == tj;
+  const int wm = (diag2 && w == 1) ? 1 : (w >> 1), wn = (diag2 && w == 1) ? 0 : (w & 1);
+  const int mma_mode = !diag2 ? 0 : ((w == 0 || w == 3) ? 1 : (w == 2 ? 2 : 3));
   const bool idle_quadrant = g.lower_only && ti == tj && wm == 0 && wn == 1;
   // ROLE 1 accumulates the TRANSPOSED 16 x 16 sub-tiles (operands swapped in the MFMA) with the B fragment's columns
   // permuted, so that lane (lr, lk) register r of acc[a][b] holds P~[wm*64 + a*16 + lr][wn*64 + b*16 + 4*lk + r]:
@@ -224,6 +230,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
     }
   };
 
+  // one k-step of MFMAs over the sub-tiles of this wave: MODE 0 all 16, 1 the 10 with b <= a, 2 rows a < 2, 3 rows a >= 2
+  auto mma = [&](int buf, auto mode_c) {
+    constexpr int MODE = decltype(mode_c)::value;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const double* pa = A_KMAJOR ? &lds.a[buf][(kk * 4 + lk) * KM_LD + wm * 64 + lr] : &lds.a[buf][(wm * 64 + lr) * RM_LD + kk * 4 + lk];
+      const double* pb = B_KMAJOR ? &lds.b[buf][(kk * 4 + lk) * KM_LD + wn * 64 + blr] : &lds.b[buf][(wn * 64 + blr) * RM_LD + kk * 4 + lk];
+      double fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (!(MODE == 2 && i >= 2) && !(MODE == 3 && i < 2)) fa[i] = pa[i * 16 * (A_KMAJOR ? 1 : RM_LD)];
+        fb[i] = pb[i * 16 * (B_KMAJOR ? 1 : RM_LD)];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if ((MODE == 1 && b > a) || (MODE == 2 && a >= 2) || (MODE == 3 && a < 2)) continue;
+          acc[a][b] = SWAP ? __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[a][b], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+    }
+  };
+
   int cur = 0;
   if (kbeg < kend) {
     load(kbeg);
@@ -233,23 +263,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     const bool more = (k0 + BK) < kend;
     if (more) load(k0 + BK);
-    if (!idle_quadrant)
-#pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      const double* pa = A_KMAJOR ? &lds.a[cur][(kk * 4 + lk) * KM_LD + wm * 64 + lr] : &lds.a[cur][(wm * 64 + lr) * RM_LD + kk * 4 + lk];
-      const double* pb = B_KMAJOR ? &lds.b[cur][(kk * 4 + lk) * KM_LD + wn * 64 + blr] : &lds.b[cur][(wn * 64 + blr) * RM_LD + kk * 4 + lk];
-      double fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = pa[i * 16 * (A_KMAJOR ? 1 : RM_LD)];
-        fb[i] = pb[i * 16 * (B_KMAJOR ? 1 : RM_LD)];
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          acc[a][b] = SWAP ? __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[a][b], 0, 0, 0)
-                           : __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    if (ROLE == 2 && mma_mode != 0) {
+      if (mma_mode == 1) mma(cur, std::integral_constant<int, 1>{});
+      else if (mma_mode == 2) mma(cur, std::integral_constant<int, 2>{});
+      else mma(cur, std::integral_constant<int, 3>{});
+    } else if (!idle_quadrant) {
+      mma(cur, std::integral_constant<int, 0>{});
     }
     if (more) stage(cur ^ 1);
     __syncthreads();
@@ -392,6 +411,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
   }
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
+    if ((mma_mode == 2 && a >= 2) || (mma_mode == 3 && a < 2)) continue;  // the other wave of the shared quadrant
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = i0 + wm * 64 + a * 16 + 4 * r + lk;
