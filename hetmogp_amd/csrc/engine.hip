@@ -86,12 +86,15 @@ int lik_dimf(int lik, double param) {
 }
 
 // Row ranges per weighted-Gram launch: a multiple of 8 (one range per XCD at a time), each >= 32 k-steps of 16 rows,
-// enough blocks (lower tiles x ranges) for >= 8 rounds over the 256 CUs, at most 64 slabs.
+// enough blocks (lower tiles x ranges) for >= 8 rounds over the 256 CUs, at most KS_MAX slabs.
+constexpr int KS_MAX = 256;  // most row ranges (slabs) of the weighted Gram
 int gram_ksplit(long long n, int M) {
   const int tiles = (M + 127) / 128, ntl = tiles * (tiles + 1) / 2;
   const long long ksteps = (n + 15) / 16;
-  long long want = (8 * 256 + ntl - 1) / ntl;
-  want = std::min<long long>(std::min<long long>(64, std::max<long long>(1, ksteps / 32)), want);
+  // enough blocks to fill the chip several times over, and row ranges of at most ~8192 rows (the tiles of one range drift
+  // apart as they stream it; shorter ranges keep the shared K^ rows in that XCD's L2)
+  long long want = std::max<long long>((8 * 256 + ntl - 1) / ntl, n / 8192);
+  want = std::min<long long>(std::min<long long>(KS_MAX, std::max<long long>(1, ksteps / 32)), want);
   return (int)(want >= 8 ? (want / 8) * 8 : std::max<long long>(1, want));
 }
 
@@ -550,12 +553,12 @@ struct hmogp_engine {
       {
         // H_q += K^T diag(beta) K^ for all latents (svmogp_inf.py:145-147 summed over d)
         const int ksplit = use_windows ? std::min(8, gram_ksplit(n, M)) : gram_ksplit(n, M);
-        slabs.ensure(sizeof(double) * MM * 64 * Q, true);
+        slabs.ensure(sizeof(double) * MM * ksplit * Q, true);
         GemmArgs g;
         g.A = Kh.d(), g.lda = M, g.a_kmajor = 1, g.sA = sK;
         g.B = Kh.d(), g.ldb = M, g.b_kmajor = 1, g.sB = sK;
         g.kscale = vbeta.d(), g.sS = ldn;
-        g.C = slabs.d(), g.ldc = M, g.sC = MM * 64;
+        g.C = slabs.d(), g.ldc = M, g.sC = MM * ksplit;
         g.M = g.N = M, g.K = (int)n;
         g.nbatch = Q;
         g.lower_only = 1;
@@ -567,7 +570,7 @@ struct hmogp_engine {
           launch_gemm_f64(g, st);
         }
         Scope sc2(this, CAT_COLSTATS, 1);  // row-range slabs -> bundle (accounted with the column statistics)
-        launch_reduce_slabs_lower(slabs.d(), ksplit, M, Hq(0), true, st, Q, MM * 64, per_q);
+        launch_reduce_slabs_lower(slabs.d(), ksplit, M, Hq(0), true, st, Q, MM * ksplit, per_q);
       }
       {
         Scope sc(this, CAT_COLSTATS, 2);
@@ -1092,7 +1095,7 @@ int hmogp_bench_contraction(int32_t device, int32_t role, int64_t n, int32_t M, 
     const long long MM = (long long)M * M;
     DevBuf A, B, Cc, beta, slabs;
     A.ensure(sizeof(double) * n * M), B.ensure(sizeof(double) * MM), Cc.ensure(sizeof(double) * std::max<long long>(n * M, MM));
-    beta.ensure(sizeof(double) * n), slabs.ensure(sizeof(double) * MM * 64, true);
+    beta.ensure(sizeof(double) * n), slabs.ensure(sizeof(double) * MM * gram_ksplit(n, M), true);
     DevBuf part, ell;   // roles 3 / 4: forward contraction with the fused row-statistics epilogue (with / without P~ store)
     part.ensure(sizeof(double) * 8 * ((M + 127) / 128) * n, true), ell.ensure(sizeof(double), true);
     { const double one = 1.0; HIP_TRY(hipMemcpy(ell.p, &one, sizeof(double), hipMemcpyHostToDevice)); }
