@@ -234,7 +234,12 @@ struct hmogp_engine {
     if (T < 1 || Q < 1 || M < 1 || Df < 1) throw EngineError{HMOGP_E_INVALID, "T, Q, M, Df must be >= 1"};
     if (P < 1 || P > 4) throw EngineError{HMOGP_E_INVALID, "input dimension P must be 1..4"};
     if (Q > HMOGP_MAXQ) throw EngineError{HMOGP_E_INVALID, "Q exceeds HMOGP_MAXQ (8)"};
-    if (c->chunk_rows > 0) chunk = c->chunk_rows;
+    if (c->chunk_rows > 0) {
+      chunk = c->chunk_rows;
+    } else {  // default pool: up to 2^20 rows, the K^ / P~ workspaces (2 * Q * rows * M doubles) kept under ~64 GB of the 288
+      const long long fit = (64LL << 30) / (16LL * Q * M);
+      chunk = std::max<long long>(4096, std::min<long long>(1048576, fit / 1024 * 1024));
+    }
     use_windows = (c->flags & HMOGP_CFG_EXACT_ZERO_WINDOWS) != 0;
     cache_kuu = (c->flags & HMOGP_CFG_CACHE_KUU) != 0;
     if (use_windows && M > 8192) throw EngineError{HMOGP_E_INVALID, "exact-zero windows support M <= 8192"};

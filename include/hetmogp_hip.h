@@ -82,8 +82,8 @@ typedef struct {
   const int32_t* f_index;   /* [Df] task owning function d      (Y_metadata['function_index'])        */
   const int32_t* d_index;   /* [Df] column of d inside its task (Y_metadata['d_index'])               */
   int32_t device;           /* HIP device ordinal                                                    */
-  int64_t chunk_rows;       /* rows of one task processed per pass (0 = default 262144); bounds the
-                               N x M workspaces: 2 * Q * chunk_rows * M * 8 bytes                    */
+  int64_t chunk_rows;       /* rows streamed per pass, across tasks (0 = default: up to 2^20, less when
+                               2 * Q * rows * M * 8 bytes of N x M workspace would exceed ~64 GB)     */
   uint32_t flags;           /* HMOGP_CFG_*                                                           */
 } hmogp_config;
 
