@@ -85,9 +85,12 @@ struct GemmArgs {
   int fs_ldz = 0, fs_P = 1, fs_hyper = 0;
   long long fs_sPart = 0, fs_sA = 0, fs_sZ = 0;
   int store_c = 1;               // 0: do not write P~ at all (no consumer when the Z gradient is not requested)
-  int b_lower = 0;               // B is lower triangular (B[k][j] == 0 for k < j): the k-loop of column tile j starts at j0.
-                                 // Forward contraction with T = tril(C) + tril(C^T,-1) when only the quadratic forms
-                                 // k^T C k are wanted (no r2-weighted twins, no P~ store): half the products.
+  // Triangular operands: op(A) is M x K, op(B) is K x N; the k-loop of tile (i0, j0) is trimmed to the products that
+  // can be non-zero.   a_tri = +1: op(A)[i][k] == 0 for k > i (lower)  -> k < i0 + 128;   -1: == 0 for k < i -> k >= i0
+  //                    b_tri = +1: op(B)[k][j] == 0 for k < j (lower)  -> k >= j0;        -1: == 0 for k > j -> k < j0 + 128
+  // Uses: forward contraction against T = tril(C) + tril(C^T,-1) when only the quadratic forms k^T C k are wanted (b_tri
+  // = +1, half the products); S = L L^T, (L L^T)^-1 = Linv^T Linv, dL/dS L and the triangular-inverse merges.
+  int a_tri = 0, b_tri = 0;
   // Exact-zero windows (rowpass.hip: launch_windows): K^ = s2 exp(-r2/2) underflows to exactly 0.0 beyond r ~ 38.6
   // lengthscales, so for spatially sorted rows it is banded.  role 1: win[2*ti], win[2*ti+1] = [lo, hi) column range
   // (multiples of 16) outside which every entry of row tile ti is exactly zero -> column tiles outside it are skipped

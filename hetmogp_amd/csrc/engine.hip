@@ -379,7 +379,7 @@ struct hmogp_engine {
 
   // batched (over q) M x M GEMM helper
   void mm(const double* A, bool a_k, const double* B, bool b_k, double* Cc, double alpha = 1.0, long long sA = -1,
-          int lda = -1, hipStream_t stream = nullptr) {
+          int lda = -1, hipStream_t stream = nullptr, int a_tri = 0, int b_tri = 0) {
     GemmArgs g;
     const long long MM = (long long)M * M;
     g.A = A, g.B = B, g.C = Cc;
@@ -389,6 +389,7 @@ struct hmogp_engine {
     g.sA = sA >= 0 ? sA : MM, g.sB = g.sC = MM;
     g.a_kmajor = a_k, g.b_kmajor = b_k;
     g.alpha = alpha;
+    g.a_tri = a_tri, g.b_tri = b_tri;
     launch_gemm_f64(g, stream ? stream : st);
   }
 
@@ -406,7 +407,7 @@ struct hmogp_engine {
     HIP_TRY(hipEventRecord(ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(st2, ev_fork, 0));
     launch_unpack_tril(dLflat.d(), L.d(), Q, M, st2);             // flat_to_triang   (svmogp_inf.py:193)
-    mm(L.d(), false, L.d(), false, S.d(), 1.0, -1, -1, st2);      // S = L L^T        (:194-195)
+    mm(L.d(), false, L.d(), false, S.d(), 1.0, -1, -1, st2, +1, -1);  // S = L L^T    (:194-195), L lower
     HIP_TRY(hipEventRecord(ev_S, st2));
     launch_trtri_batched(L.d(), HK.d(), G.d(), Q, M, st2);        // S^-1 = dpotri(L) (svmogp_inf.py:124)
     launch_ltl_batched(HK.d(), Sqi.d(), Q, M, st2);
@@ -511,7 +512,7 @@ struct hmogp_engine {
           // only the quadratic forms are wanted when neither the hyper-parameter nor the Z gradients are (SVI / VEM
           // E-steps): the triangular fold of C gives them with half the products
           const bool tri = !want_hyper && !want_z;
-          g.B = tri ? Ctri.d() : C.d(), g.ldb = M, g.b_kmajor = 1, g.sB = MM, g.b_lower = tri ? 1 : 0;
+          g.B = tri ? Ctri.d() : C.d(), g.ldb = M, g.b_kmajor = 1, g.sB = MM, g.b_tri = tri ? 1 : 0;
           g.C = Pt.d(), g.ldc = M, g.sC = sK;
           g.M = (int)n, g.N = M, g.K = M;
           g.nbatch = Q;
@@ -625,7 +626,7 @@ struct hmogp_engine {
       HIP_TRY(hipStreamWaitEvent(st2, ev_fork, 0));
       if (want_qu) {
         launch_dlds(G.d(), Kuui.d(), Sqi.d(), dLdS.d(), MM * Q, st2);
-        mm(dLdS.d(), false, L.d(), true, tmpA.d(), 1.0, -1, -1, st2);  // dL_dS L        (:175-177)
+        mm(dLdS.d(), false, L.d(), true, tmpA.d(), 1.0, -1, -1, st2, 0, +1);  // dL_dS L (:175-177), L lower
         launch_pack_gl(tmpA.d(), gL.d(), Q, M, st2);
         launch_gmu(Kr.d(), a.d(), gmu.d(), Q, M, st2);
       }
@@ -785,7 +786,7 @@ struct hmogp_engine {
         launch_rbf(dX.d(), P, n, P, dZ.d() + q * P, ldz, M, h_var[q], h_ell[q], kh, false, st, nullptr, false);
         GemmArgs g;
         g.A = kh, g.lda = M, g.a_kmajor = 0;
-        g.B = Ctri.d() + q * MM, g.ldb = M, g.b_kmajor = 1, g.b_lower = 1;  // variances only: triangular fold of C
+        g.B = Ctri.d() + q * MM, g.ldb = M, g.b_kmajor = 1, g.b_tri = 1;  // variances only: triangular fold of C
         g.C = pt, g.ldc = M;
         g.M = (int)n, g.N = M, g.K = M;
         g.role = 1;

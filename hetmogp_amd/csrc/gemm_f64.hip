@@ -148,7 +148,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
       return;
     }
   }
-  if (g.b_lower) wlo = max(wlo, min(j0, whi));  // rows k < j0 of a lower-triangular B are zeros for this column tile
+  if (g.a_tri > 0) whi = min(whi, i0 + BM);       // triangular operands (GemmArgs::a_tri / b_tri): trimmed k-range
+  if (g.b_tri < 0) whi = min(whi, j0 + BN);
+  if (g.a_tri < 0) wlo = max(wlo, i0);
+  if (g.b_tri > 0) wlo = max(wlo, j0);
+  wlo = min(wlo, whi);
   if (ROLE == 2 && win) {
     wlo = max(win[2 * ti], win[2 * tj]);
     whi = max(wlo, min(K, min(win[2 * ti + 1], win[2 * tj + 1])));

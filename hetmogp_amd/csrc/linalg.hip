@@ -329,6 +329,7 @@ void launch_trtri_batched(const double* L, double* Linv, double* tmp, int Q, int
     g.sA = g.sB = g.sC = pstride;
     g.nouter = Q;
     g.oA = g.oB = g.oC = MM;
+    g.b_tri = +1;  // X11 is lower triangular
     launch_gemm_f64(g, stream);
     // X21 = -X22 * T     (r x s) = (r x r)(r x s)
     GemmArgs h;
@@ -350,6 +351,7 @@ void launch_trtri_batched(const double* L, double* Linv, double* tmp, int Q, int
     h.nouter = Q;
     h.oA = h.oB = h.oC = MM;
     h.alpha = -1.0;
+    h.a_tri = +1;  // X22 is lower triangular
     launch_gemm_f64(h, stream);
   }
 }
@@ -363,6 +365,7 @@ void launch_ltl_batched(const double* Linv, double* Out, int Q, int M, hipStream
   g.lda = g.ldb = g.ldc = M;
   g.a_kmajor = 1;
   g.b_kmajor = 1;
+  g.a_tri = -1, g.b_tri = +1;  // op(A) = Linv^T upper, op(B) = Linv lower: k >= max(i0, j0)
   g.nbatch = Q;
   g.sA = g.sB = g.sC = (long long)M * M;
   launch_gemm_f64(g, stream);

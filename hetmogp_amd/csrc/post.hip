@@ -22,7 +22,7 @@ __global__ void sub_kernel(const double* __restrict__ A, const double* __restric
 }
 
 // T = tril(C) + tril(C^T, -1): the lower-triangular matrix with x^T T x == x^T C x (C need not be exactly symmetric).
-// With it the quadratic forms k^T C k of the forward contraction cost half the products (GemmArgs::b_lower).
+// With it the quadratic forms k^T C k of the forward contraction cost half the products (GemmArgs::b_tri).
 __global__ void tri_fold_kernel(const double* __restrict__ C, double* __restrict__ T, int M) {
   const long long o = (long long)blockIdx.z * M * M;
   const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
