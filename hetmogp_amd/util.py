@@ -117,16 +117,33 @@ class Adadelta(object):
         self.n_iter = 0
 
     def __iter__(self):
+        # Same operations in the same order as the formulas above (bit-identical iterates), written in place: at the
+        # sizes of the path (1.6 M parameters at M = 1024, Q = 3) the temporaries of the one-line forms cost more than
+        # a gradient evaluation on the GPU.
+        t1, t2 = np.empty_like(self.wrt), np.empty_like(self.wrt)
+        step1 = np.empty_like(self.wrt)
         while True:
             d, o, m = self.decay, self.offset, self.momentum
-            step1 = self.step * m
+            np.multiply(self.step, m, out=step1)
             self.wrt -= step1
             g = self.fprime(self.wrt)
-            self.gms = d * self.gms + (1 - d) * g ** 2
-            step2 = np.sqrt(self.sms + o) / np.sqrt(self.gms + o) * g * self.step_rate
-            self.wrt -= step2
-            self.step = step1 + step2
-            self.sms = d * self.sms + (1 - d) * self.step ** 2
+            np.multiply(g, g, out=t1)                      # gms = d * gms + (1 - d) * g ** 2
+            t1 *= (1 - d)
+            self.gms *= d
+            self.gms += t1
+            np.add(self.sms, o, out=t1)                    # step2 = sqrt(sms + o) / sqrt(gms + o) * g * step_rate
+            np.sqrt(t1, out=t1)
+            np.add(self.gms, o, out=t2)
+            np.sqrt(t2, out=t2)
+            t1 /= t2
+            t1 *= g
+            t1 *= self.step_rate
+            self.wrt -= t1
+            np.add(step1, t1, out=self.step)               # step = step1 + step2
+            np.multiply(self.step, self.step, out=t2)      # sms = d * sms + (1 - d) * step ** 2
+            t2 *= (1 - d)
+            self.sms *= d
+            self.sms += t2
             self.n_iter += 1
             yield dict(n_iter=self.n_iter, gradient=g, step=self.step)
 
