@@ -77,7 +77,10 @@ __global__ __launch_bounds__(256) void rbf_kernel(const double* __restrict__ X, 
       if (n0 + r == c) r20 = 0.0;
       if (n0 + r == c + 1) r21 = 0.0;
     }
-    const double k0 = var * exp(-0.5 * r20), k1 = var * exp(-0.5 * r21);
+    // exp(-r2/2) underflows to exactly 0.0 beyond r2 ~ 1490.3: a wave whose 128 columns are all past that writes the
+    // zeros without evaluating the exponential (same values; NaNs fail the comparison and take the full path)
+    double k0 = 0.0, k1 = 0.0;
+    if (!__all(r20 > 1492.0 && r21 > 1492.0)) k0 = var * exp(-0.5 * r20), k1 = var * exp(-0.5 * r21);
     double* out = K + (n0 + r) * M + c;
     if (vec)
       *reinterpret_cast<f64x2*>(out) = f64x2{k0, k1};
