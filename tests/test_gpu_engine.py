@@ -105,7 +105,7 @@ def synth(seed, specs, Ns, M, Q, P, cs):
             Y.append(np.clip(rng.beta(2.0, 3.0, (n, 1)), 1e-4, 1 - 1e-4))
         else:
             Y.append(rng.randint(1, kw["K"] + 1, (n, 1)).astype(float))
-    h = 1.0 / (M - 1) if P == 1 else M ** (-1.0 / P)
+    h = 1.0 / max(M - 1, 1) if P == 1 else M ** (-1.0 / P)
     if P == 1:
         base = np.linspace(0, 1, M)[:, None]
     else:                      # regular grid (random inducing points make cond(K_uu) ~ 1e6: conditioning-limited parity)
@@ -274,6 +274,26 @@ def test_q_u_only_evaluation_uses_triangular_fold_and_matches_full():
     want = so.elbo_grad_fused(prm, prob, X, Y)
     for k in ("elbo", "g_m_u", "g_L_u"):
         assert rel(qu[k], want[k]) < TOL, k
+
+
+@pytest.mark.parametrize("case", [
+    dict(specs=[("Poisson", {})], Ns=[37], M=1, Q=1, P=1, cs=(1.0,)),                       # a single inducing point
+    dict(specs=[("Gaussian", {"sigma": 0.3})], Ns=[1], M=5, Q=2, P=1, cs=(1.0, 2.0)),       # a single data row
+    dict(specs=[("Bernoulli", {}), ("Exponential", {})], Ns=[129, 127], M=33, Q=8, P=1, cs=(1.0,) * 8),   # Q = HMOGP_MAXQ
+    dict(specs=[("HetGaussian", {}), ("Beta", {})], Ns=[65, 200], M=27, Q=2, P=3, cs=(1.0, 1.5)),        # 3-D inputs
+    dict(specs=[("Categorical", {"K": 3}), ("Gamma", {})], Ns=[90, 0], M=16, Q=1, P=4, cs=(1.2,)),      # 4-D, empty task
+    dict(specs=[("Gaussian", {"sigma": 1.0})] * 6, Ns=[50, 60, 70, 80, 90, 100], M=64, Q=3, P=2, cs=(1.0, 1.2, 0.9)),
+], ids=["M1", "N1", "Q8", "P3", "P4_empty", "T6_2d"])
+def test_odd_shapes_vs_oracle(case):
+    """Corner shapes against the NumPy oracle: M = 1, N = 1, Q = 8 latents, 3-D / 4-D inputs, an empty task, six tasks;
+    every one also through row pools smaller than a task (chunk_rows = 48), which must not change anything."""
+    from oracle import svmogp_oracle as so
+    prm, prob, X, Y = synth(41, case["specs"], case["Ns"], case["M"], case["Q"], case["P"], case["cs"])
+    want = so.elbo_grad_fused(prm, prob, X, Y)
+    for kw in ({}, {"chunk_rows": 48}):
+        out = run(make_engine(prob, X, Y, **kw), prm)
+        for k in KEYS:
+            assert rel(out[k], want[k]) < TOL, (k, kw)
 
 
 def test_pinned_parameters_and_reused_outputs():
