@@ -370,7 +370,9 @@ struct hmogp_engine {
     group_mask = p->group_mask;
     HIP_TRY(hipMemcpyAsync(dZ.p, p->Z, sizeof(double) * M * Q * P, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dmu.p, p->m_u, sizeof(double) * M * Q, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dLflat.p, p->L_flat, sizeof(double) * Mtri * Q, hipMemcpyHostToDevice, st));
+    // the one large parameter (12.6 MB at M = 1024, Q = 3) goes up on the second stream, whose chain is its only consumer
+    // (u_algebra): the K_uu chain on the main stream starts without waiting for it
+    HIP_TRY(hipMemcpyAsync(dLflat.p, p->L_flat, sizeof(double) * Mtri * Q, hipMemcpyHostToDevice, st2));
     HIP_TRY(hipMemcpyAsync(dvar.p, h_var.data(), sizeof(double) * Q, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dell.p, h_ell.data(), sizeof(double) * Q, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dW.p, h_W.data(), sizeof(double) * Q * Df, hipMemcpyHostToDevice, st));
@@ -629,6 +631,11 @@ struct hmogp_engine {
         mm(dLdS.d(), false, L.d(), true, tmpA.d(), 1.0, -1, -1, st2, 0, +1);  // dL_dS L (:175-177), L lower
         launch_pack_gl(tmpA.d(), gL.d(), Q, M, st2);
         launch_gmu(Kr.d(), a.d(), gmu.d(), Q, M, st2);
+        // the large gradient leaves on this stream as soon as it exists, beside the K_uu-side tail of the main stream
+        if (out->g_L_u && (group_mask & HMOGP_GROUP_QU))
+          HIP_TRY(hipMemcpyAsync(out->g_L_u, gL.p, sizeof(double) * Mtri * Q, hipMemcpyDeviceToHost, st2));
+        if (out->g_m_u && (group_mask & HMOGP_GROUP_QU))
+          HIP_TRY(hipMemcpyAsync(out->g_m_u, gmu.p, sizeof(double) * M * Q, hipMemcpyDeviceToHost, st2));
       }
       launch_kl_terms(Kuui.d(), S.d(), dmu.d(), a.d(), Luu.d(), L.d(), Sqi.d(), Q, M, klout.d(), st2);
       HIP_TRY(hipEventRecord(ev_join, st2));
@@ -648,14 +655,8 @@ struct hmogp_engine {
                              hipMemcpyDeviceToHost, st));
     if (want_hz) HIP_TRY(hipMemcpyAsync(hrow.data(), rowout.p, sizeof(double) * hrow.size(), hipMemcpyDeviceToHost, st));
     const bool qu = (group_mask & HMOGP_GROUP_QU) != 0;
-    if (out->g_m_u) {
-      if (qu) HIP_TRY(hipMemcpyAsync(out->g_m_u, gmu.p, sizeof(double) * M * Q, hipMemcpyDeviceToHost, st));
-      else std::memset(out->g_m_u, 0, sizeof(double) * M * Q);
-    }
-    if (out->g_L_u) {
-      if (qu) HIP_TRY(hipMemcpyAsync(out->g_L_u, gL.p, sizeof(double) * Mtri * Q, hipMemcpyDeviceToHost, st));
-      else std::memset(out->g_L_u, 0, sizeof(double) * Mtri * Q);
-    }
+    if (out->g_m_u && !qu) std::memset(out->g_m_u, 0, sizeof(double) * M * Q);      // (copied on the second stream otherwise)
+    if (out->g_L_u && !qu) std::memset(out->g_L_u, 0, sizeof(double) * Mtri * Q);
     if (out->dL_dS) HIP_TRY(hipMemcpyAsync(out->dL_dS, dLdS.p, sizeof(double) * MM * Q, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(ev_fin1, st));
     HIP_TRY(hipStreamSynchronize(st));
