@@ -296,6 +296,19 @@ def test_odd_shapes_vs_oracle(case):
             assert rel(out[k], want[k]) < TOL, (k, kw)
 
 
+def test_repeated_evaluations_are_bit_identical():
+    """No floating-point atomics anywhere (two-level deterministic reductions, fixed stream joins): the same parameters
+    give the same bits every time, on the same engine and on a fresh one."""
+    specs = [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {}), ("Poisson", {}), ("Gamma", {})]
+    prm, prob, X, Y = synth(43, specs, [900, 700, 800, 600], 260, 3, 1, (1.0, 1.2, 0.9))
+    e = make_engine(prob, X, Y)
+    first = run(e, prm)
+    for i in range(4):
+        again = run(e if i < 3 else make_engine(prob, X, Y), prm)
+        for k in KEYS:
+            assert np.array_equal(np.asarray(first[k]), np.asarray(again[k])), (i, k)
+
+
 def test_pinned_parameters_and_reused_outputs():
     """hmogp_host_alloc: parameters in page-locked arrays and gradients returned in engine-owned page-locked arrays
     (reuse_outputs=True) give the same bits as the default pageable path; the reused arrays are overwritten by the
