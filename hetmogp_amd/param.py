@@ -8,8 +8,13 @@ import numpy as np
 
 
 class Param(np.ndarray):
-    def __new__(cls, name, input_array, positive=False):
-        obj = np.array(np.atleast_1d(input_array), dtype=np.float64).view(cls)   # copy: detached from the caller
+    def __new__(cls, name, input_array, positive=False, storage=None):
+        src = np.atleast_1d(np.asarray(input_array, dtype=np.float64))
+        if storage is not None:      # caller-provided buffer of the same shape (e.g. page-locked: engine.pinned_empty)
+            storage[...] = src
+            obj = storage.view(cls)
+        else:
+            obj = np.array(src, dtype=np.float64).view(cls)                   # copy: detached from the caller
         obj.name = name
         obj._grad = np.zeros(obj.shape)
         obj._fixed = [False]

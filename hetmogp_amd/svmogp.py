@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib
 from . import util
-from .engine import Engine
+from .engine import Engine, pinned_empty
 from .param import Param, match, logexp_f, logexp_finv, logexp_gradfactor
 
 
@@ -43,7 +43,9 @@ class SVMOGP(object):
         T = len(self.Ymulti_all)
         self.Xdim = Z.shape[1]
         self._engine = Engine(likelihood.specs(), self.num_latent_funcs, self.num_inducing, self.Xdim, device=device,
-                              chunk_rows=chunk_rows, exact_zero_windows=exact_zero_windows, cache_kuu=True)
+                              chunk_rows=chunk_rows, exact_zero_windows=exact_zero_windows, cache_kuu=True,
+                              reuse_outputs=True)   # gradients arrive in engine-owned page-locked arrays, copied into
+                                                    # the parameters' .gradient fields by parameters_changed()
         self._engine.set_data(self.Xmulti_all, self.Ymulti_all)
         # distributed=True (inside an initialised torch.distributed group, one process per GPU): the rows of every
         # evaluation are sharded over the ranks and the statistic bundle is all-reduced once (hetmogp_amd/dist.py); every
@@ -66,15 +68,16 @@ class SVMOGP(object):
             self.set_data(*self.new_batch())
 
         Ztiled = np.tile(Z, (1, self.num_latent_funcs))                   # svmogp.py:52
-        self.Z = Param("inducing inputs", Ztiled)
+        # the three large parameters live in page-locked host memory: they reach the GPU by DMA without a staging copy
+        self.Z = Param("inducing inputs", Ztiled, storage=pinned_empty(Ztiled.shape))
         _, self.B_list = util.LCM(input_dim=self.Xdim, output_dim=self.num_output_funcs, rank=1,
                                   kernels_list=self.kern_list, W_list=self.W_list, kappa_list=self.kappa_list)
         M, Q = self.num_inducing, self.num_latent_funcs
-        self.q_u_means = Param("m_u", 2.5 * np.random.randn(M, Q))        # svmogp.py:66-67
+        self.q_u_means = Param("m_u", 2.5 * np.random.randn(M, Q), storage=pinned_empty((M, Q)))   # svmogp.py:66-67
         r, c = np.tril_indices(M)
         chols = np.zeros((M * (M + 1) // 2, Q))
         chols[r == c, :] = 1.0                                             # triang_to_flat(identity), :68
-        self.q_u_chols = Param("L_u", chols)
+        self.q_u_chols = Param("L_u", chols, storage=pinned_empty(chols.shape))
         self.vem_step = True                                               # True = VE step, False = VM step
         self.ve_count = 0
         self.elbo = np.zeros((1, 1))

@@ -116,34 +116,43 @@ class Adadelta(object):
         self.step = np.zeros_like(wrt)
         self.n_iter = 0
 
+    _BLOCK = 32768      # elements per cache block (8 arrays x 256 KB)
+
     def __iter__(self):
-        # Same operations in the same order as the formulas above (bit-identical iterates), written in place: at the
-        # sizes of the path (1.6 M parameters at M = 1024, Q = 3) the temporaries of the one-line forms cost more than
-        # a gradient evaluation on the GPU.
-        t1, t2 = np.empty_like(self.wrt), np.empty_like(self.wrt)
-        step1 = np.empty_like(self.wrt)
+        # Same operations in the same order as the formulas above (bit-identical iterates), but in place and cache-blocked:
+        # at the sizes of the path (1.6 M parameters at M = 1024, Q = 3) twenty full-length NumPy passes cost more than a
+        # gradient evaluation on the GPU; block by block the eight arrays stay in the host's L2.
+        n = self.wrt.size
+        wrt, gms, sms, step = (a.reshape(-1) for a in (self.wrt, self.gms, self.sms, self.step))
+        step1 = np.empty(n)
+        blocks = [(b, min(n, b + self._BLOCK)) for b in range(0, n, self._BLOCK)]
+        s1, s2 = np.empty(self._BLOCK), np.empty(self._BLOCK)
         while True:
-            d, o, m = self.decay, self.offset, self.momentum
-            np.multiply(self.step, m, out=step1)
-            self.wrt -= step1
+            d, o, m, rate = self.decay, self.offset, self.momentum, self.step_rate
+            for b, e in blocks:
+                np.multiply(step[b:e], m, out=step1[b:e])
+                wrt[b:e] -= step1[b:e]
             g = self.fprime(self.wrt)
-            np.multiply(g, g, out=t1)                      # gms = d * gms + (1 - d) * g ** 2
-            t1 *= (1 - d)
-            self.gms *= d
-            self.gms += t1
-            np.add(self.sms, o, out=t1)                    # step2 = sqrt(sms + o) / sqrt(gms + o) * g * step_rate
-            np.sqrt(t1, out=t1)
-            np.add(self.gms, o, out=t2)
-            np.sqrt(t2, out=t2)
-            t1 /= t2
-            t1 *= g
-            t1 *= self.step_rate
-            self.wrt -= t1
-            np.add(step1, t1, out=self.step)               # step = step1 + step2
-            np.multiply(self.step, self.step, out=t2)      # sms = d * sms + (1 - d) * step ** 2
-            t2 *= (1 - d)
-            self.sms *= d
-            self.sms += t2
+            gf = np.ascontiguousarray(g, dtype=np.float64).reshape(-1)
+            for b, e in blocks:
+                t1, t2, gb = s1[:e - b], s2[:e - b], gf[b:e]
+                np.multiply(gb, gb, out=t1)                # gms = d * gms + (1 - d) * g ** 2
+                t1 *= (1 - d)
+                gms[b:e] *= d
+                gms[b:e] += t1
+                np.add(sms[b:e], o, out=t1)                # step2 = sqrt(sms + o) / sqrt(gms + o) * g * step_rate
+                np.sqrt(t1, out=t1)
+                np.add(gms[b:e], o, out=t2)
+                np.sqrt(t2, out=t2)
+                t1 /= t2
+                t1 *= gb
+                t1 *= rate
+                wrt[b:e] -= t1
+                np.add(step1[b:e], t1, out=step[b:e])      # step = step1 + step2
+                np.multiply(step[b:e], step[b:e], out=t2)  # sms = d * sms + (1 - d) * step ** 2
+                t2 *= (1 - d)
+                sms[b:e] *= d
+                sms[b:e] += t2
             self.n_iter += 1
             yield dict(n_iter=self.n_iter, gradient=g, step=self.step)
 
