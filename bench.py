@@ -166,6 +166,8 @@ def main():
                              "launches": cat_n["rbf_cross_cov"],
                              "avg_launch_ms": cat_ms["rbf_cross_cov"] / max(cat_n["rbf_cross_cov"], 1)},
             "kernel_ms_per_step": {k: v / args.steps for k, v in cat_ms.items()},
+            # the weighted Gram shares the device with the HBM-bound column statistics (second stream): its span is longer
+            # than when it runs alone, and gram_gemm + colstats_reduce overlap (they do not add up to the wall time)
             "gram_tflops": gram_flops / (cat_ms["gram_gemm"] / 1e3) / 1e12 if cat_ms["gram_gemm"] > 0 else 0.0,
             "elbo": out["elbo"],
         }

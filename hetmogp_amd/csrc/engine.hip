@@ -186,7 +186,7 @@ struct hmogp_engine {
   long long launches[NCAT] = {0};
   hipEvent_t ev_begin0 = nullptr, ev_begin1 = nullptr, ev_fin0 = nullptr, ev_fin1 = nullptr;
   hipStream_t st2 = nullptr;  // second stream: the q(u)-only chain of u_algebra
-  hipEvent_t ev_fork = nullptr, ev_S = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_S = nullptr, ev_join = nullptr, ev_col = nullptr;
 
   hipEvent_t new_event() {
     if (pool_used == pool.size()) {
@@ -199,15 +199,16 @@ struct hmogp_engine {
   struct Scope {
     hmogp_engine* e;
     Span s;
-    Scope(hmogp_engine* eng, int cat, int nlaunch) : e(eng) {
+    hipStream_t stream;
+    Scope(hmogp_engine* eng, int cat, int nlaunch, hipStream_t on = nullptr) : e(eng), stream(on ? on : eng->st) {
       s.cat = cat;
       s.a = e->new_event();
       s.b = e->new_event();
       e->launches[cat] += nlaunch;
-      (void)hipEventRecord(s.a, e->st);
+      (void)hipEventRecord(s.a, stream);
     }
     ~Scope() {
-      (void)hipEventRecord(s.b, e->st);
+      (void)hipEventRecord(s.b, stream);
       e->spans.push_back(s);
     }
   };
@@ -222,7 +223,7 @@ struct hmogp_engine {
 
   ~hmogp_engine() {
     for (auto e : pool) (void)hipEventDestroy(e);
-    for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_S, ev_join})
+    for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_S, ev_join, ev_col})
       if (e) (void)hipEventDestroy(e);
     if (hstage) (void)hipHostFree(hstage);
     if (st2) (void)hipStreamDestroy(st2);
@@ -253,7 +254,7 @@ struct hmogp_engine {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
-    for (hipEvent_t* e : {&ev_fork, &ev_S, &ev_join}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t* e : {&ev_fork, &ev_S, &ev_join, &ev_col}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (hipEvent_t* e : {&ev_begin0, &ev_begin1, &ev_fin0, &ev_fin1}) HIP_TRY(hipEventCreate(e));
     f_index.assign(c->f_index, c->f_index + Df);
     d_index.assign(c->d_index, c->d_index + Df);
@@ -561,6 +562,10 @@ struct hmogp_engine {
           launch_reduce_rows(quadpart.d(), quad_blocks(k.lik, sg.n), k.nscal, k.offsets.as<long long>(), stats.d(), true, st);
         }
       }
+      // The column statistics (HBM-bound: K^ and P~ streamed once) run on the second stream BESIDE the weighted Gram
+      // (MFMA-bound): both only need the row weights of the quadrature and write disjoint parts of the bundle.
+      HIP_TRY(hipEventRecord(ev_fork, st));
+      HIP_TRY(hipStreamWaitEvent(st2, ev_fork, 0));
       {
         // H_q += K^T diag(beta) K^ for all latents (svmogp_inf.py:145-147 summed over d)
         const int ksplit = use_windows ? std::min(8, gram_ksplit(n, M)) : gram_ksplit(n, M);
@@ -580,18 +585,20 @@ struct hmogp_engine {
           Scope sc(this, CAT_GRAM, 1);
           launch_gemm_f64(g, st);
         }
+        {
+          Scope sc(this, CAT_COLSTATS, 2, st2);
+          const long long len = (long long)M * (1 + P), nsp = (n + 255) / 256;
+          ColBatch cb;
+          cb.nq = Q, cb.sK = sK, cb.sA = M, cb.sV = ldn, cb.sZ = P, cb.sPart = nsp * len, cb.sWin = 2 * ncb;
+          launch_colstats(Kh.d(), Pt.d(), a.d(), valpha.d(), valpha0.d(), vbeta0.d(), X, P, dZ.d(), ldz, n, M, 256, want_z,
+                          colpart.d(), st2, cw, &cb);
+          launch_reduce_slabs(colpart.d(), (int)nsp, len, len, Hq(0) + oR, true, st2, Q, nsp * len, per_q);
+        }
+        HIP_TRY(hipEventRecord(ev_col, st2));
         Scope sc2(this, CAT_COLSTATS, 1);  // row-range slabs -> bundle (accounted with the column statistics)
         launch_reduce_slabs_lower(slabs.d(), ksplit, M, Hq(0), true, st, Q, MM * ksplit, per_q);
       }
-      {
-        Scope sc(this, CAT_COLSTATS, 2);
-        const long long len = (long long)M * (1 + P), nsp = (n + 255) / 256;
-        ColBatch cb;
-        cb.nq = Q, cb.sK = sK, cb.sA = M, cb.sV = ldn, cb.sZ = P, cb.sPart = nsp * len, cb.sWin = 2 * ncb;
-        launch_colstats(Kh.d(), Pt.d(), a.d(), valpha.d(), valpha0.d(), vbeta0.d(), X, P, dZ.d(), ldz, n, M, 256, want_z,
-                        colpart.d(), st, cw, &cb);
-        launch_reduce_slabs(colpart.d(), (int)nsp, len, len, Hq(0) + oR, true, st, Q, nsp * len, per_q);
-      }
+      HIP_TRY(hipStreamWaitEvent(st, ev_col, 0));      // the workspaces are reused by the next pool
     }
     launch_mirror_lower(Hq(0), Q, M, per_q, st);
   }
