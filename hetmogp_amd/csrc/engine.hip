@@ -186,7 +186,7 @@ struct hmogp_engine {
   long long launches[NCAT] = {0};
   hipEvent_t ev_begin0 = nullptr, ev_begin1 = nullptr, ev_fin0 = nullptr, ev_fin1 = nullptr;
   hipStream_t st2 = nullptr;  // second stream: the q(u)-only chain of u_algebra
-  hipEvent_t ev_fork = nullptr, ev_S = nullptr, ev_join = nullptr, ev_col = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_S = nullptr, ev_join = nullptr, ev_col = nullptr, ev_kuf = nullptr;
 
   hipEvent_t new_event() {
     if (pool_used == pool.size()) {
@@ -223,7 +223,7 @@ struct hmogp_engine {
 
   ~hmogp_engine() {
     for (auto e : pool) (void)hipEventDestroy(e);
-    for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_S, ev_join, ev_col})
+    for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_S, ev_join, ev_col, ev_kuf})
       if (e) (void)hipEventDestroy(e);
     if (hstage) (void)hipHostFree(hstage);
     if (st2) (void)hipStreamDestroy(st2);
@@ -254,7 +254,7 @@ struct hmogp_engine {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
-    for (hipEvent_t* e : {&ev_fork, &ev_S, &ev_join, &ev_col}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t* e : {&ev_fork, &ev_S, &ev_join, &ev_col, &ev_kuf}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (hipEvent_t* e : {&ev_begin0, &ev_begin1, &ev_fin0, &ev_fin1}) HIP_TRY(hipEventCreate(e));
     f_index.assign(c->f_index, c->f_index + Df);
     d_index.assign(c->d_index, c->d_index + Df);
@@ -437,6 +437,15 @@ struct hmogp_engine {
       launch_ltl_batched(tmpA.d(), Kuui.d(), Q, M, st);             // K_uu^-1          (util.py:199)
       if (cache_kuu) kuu_key.swap(key), kuu_rung = rung, kuu_key_valid = true;
     }
+    // K_uf of the first pool only needs X, Z and the kernel hyper-parameters.  It goes on the second stream (behind the
+    // q(u) chain, which has finished by now: the jitter ladder above synchronised with the host) and overlaps the tail
+    // of the K_uu chain -- bandwidth-bound next to small latency-bound products.  (Not next to the Cholesky itself:
+    // its 32 dependent launches starve behind an HBM-bound kernel that fills every CU.)
+    if (!pools.empty()) {
+      kuf_pool(pools[0], st2);
+      HIP_TRY(hipEventRecord(ev_kuf, st2));
+      kuf_prefetched = true;
+    }
     launch_gemv_batched(Kuui.d(), dmu.d(), a.d(), Q, M, 1, Q, st);  // a = K_uu^-1 m
     HIP_TRY(hipStreamWaitEvent(st, ev_S, 0));
     mm(Kuui.d(), false, S.d(), true, KiS.d());
@@ -446,36 +455,60 @@ struct hmogp_engine {
     HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));
   }
 
+  // ------------------------------------------------------------------------------------------ row pools
+  // Rows are streamed in POOLS of at most `chunk` rows.  Everything between the covariance construction and the
+  // quadrature, and everything after it, is independent of which task a row belongs to (K^ C_q, the row statistics,
+  // the weighted Gram and the column statistics only see rows), so a pool concatenates row ranges ("segments") of
+  // consecutive tasks: one forward contraction, one Gram product and one column-statistics pass per pool instead of
+  // one per task -- fewer, larger launches (tails, launch-bound reductions; matters most for minibatches and for
+  // the per-rank shares of a multi-GPU run).  Only K_uf construction and the quadrature run per segment.  The
+  // exact-zero windows need spatially sorted rows per launch, so that mode keeps one task per pool.
+  struct Seg { int t; long long r0, n, off; };
+  std::vector<std::vector<Seg>> pools;
+  bool kuf_prefetched = false;
+  void plan_pools() {
+    pools.clear();
+    kuf_prefetched = false;
+    std::vector<Seg> cur;
+    long long fill = 0;
+    for (int t = 0; t < T; ++t)
+      for (long long r0 = rb[t]; r0 < re[t];) {
+        const long long n = std::min(chunk - fill, re[t] - r0);
+        cur.push_back(Seg{t, r0, n, fill});
+        fill += n, r0 += n;
+        if (fill == chunk || use_windows) pools.push_back(cur), cur.clear(), fill = 0;
+      }
+    if (!cur.empty()) pools.push_back(cur);
+    long long maxrows = 1;
+    for (auto& pl : pools) maxrows = std::max(maxrows, pl.back().off + pl.back().n);
+    ensure_workspace(maxrows);
+  }
+  // K_uf = k_q(X, Z_q) of one pool, all latents in one launch per segment (grid.z = latent), on `stream`
+  void kuf_pool(const std::vector<Seg>& pl, hipStream_t stream) {
+    const int ldz = Q * P, ncb = (M + 127) / 128;
+    const long long wtiles = (ws_rows + 127) / 128, sK = ws_rows * M;
+    int* rw = use_windows ? winrow.as<int>() : nullptr;    // [Q][wtiles][2]
+    int* cw = use_windows ? wincol.as<int>() : nullptr;    // [Q][ncb][2]
+    Scope sc(this, CAT_RBF, (int)pl.size() + (use_windows ? 3 * Q : 0), stream);
+    for (auto& sg : pl) {
+      const double* Xs = tasks[sg.t].X.d() + sg.r0 * P;
+      if (use_windows)
+        for (int q = 0; q < Q; ++q)
+          launch_windows(Xs, sg.n, P, dZ.d() + q * P, ldz, M, h_ell[q], rw + 2 * wtiles * q, cw + 2 * ncb * q,
+                         winhit.as<unsigned char>(), stream);
+      RbfBatch rbt;
+      rbt.nq = Q, rbt.var = dvar.d(), rbt.ell = dell.d(), rbt.sZ = P, rbt.sK = sK, rbt.sWin = 2 * wtiles;
+      launch_rbf(Xs, P, sg.n, P, dZ.d(), ldz, M, 0.0, 1.0, Kh.d() + sg.off * M, false, stream, rw, false, &rbt);
+    }
+  }
+
   // ------------------------------------------------------------------------------------------ row pass
   void row_pass() {
     const long long MM = (long long)M * M;
     const int ldz = Q * P;
     const bool want_hyper = (group_mask & (HMOGP_GROUP_HYPER | HMOGP_GROUP_Z)) != 0;
     const bool want_z = (group_mask & HMOGP_GROUP_Z) != 0;
-    // Rows are streamed in POOLS of at most `chunk` rows.  Everything between the covariance construction and the
-    // quadrature, and everything after it, is independent of which task a row belongs to (K^ C_q, the row statistics,
-    // the weighted Gram and the column statistics only see rows), so a pool concatenates row ranges ("segments") of
-    // consecutive tasks: one forward contraction, one Gram product and one column-statistics pass per pool instead of
-    // one per task -- fewer, larger launches (tails, launch-bound reductions; matters most for minibatches and for
-    // the per-rank shares of a multi-GPU run).  Only K_uf construction and the quadrature run per segment.  The
-    // exact-zero windows need spatially sorted rows per launch, so that mode keeps one task per pool.
-    struct Seg { int t; long long r0, n, off; };
-    std::vector<std::vector<Seg>> pools;
-    {
-      std::vector<Seg> cur;
-      long long fill = 0;
-      for (int t = 0; t < T; ++t)
-        for (long long r0 = rb[t]; r0 < re[t];) {
-          const long long n = std::min(chunk - fill, re[t] - r0);
-          cur.push_back(Seg{t, r0, n, fill});
-          fill += n, r0 += n;
-          if (fill == chunk || use_windows) pools.push_back(cur), cur.clear(), fill = 0;
-        }
-      if (!cur.empty()) pools.push_back(cur);
-    }
-    long long maxrows = 1;
-    for (auto& pl : pools) maxrows = std::max(maxrows, pl.back().off + pl.back().n);
-    ensure_workspace(maxrows);
+    // (pools: see plan_pools())
     const long long ldn = ws_rows;
     HIP_TRY(hipMemsetAsync(stats.p, 0, sizeof(double) * nstats, st));
     const int tiles = (M + 127) / 128;
@@ -493,20 +526,10 @@ struct hmogp_engine {
                                  hipMemcpyDeviceToDevice, st));
         X = Xws.d();
       }
-      {
-        // K_uf for all latents in one launch per segment (grid.z = latent)
-        Scope sc(this, CAT_RBF, (int)pl.size() + (use_windows ? 3 * Q : 0));
-        for (auto& sg : pl) {
-          const double* Xs = tasks[sg.t].X.d() + sg.r0 * P;
-          if (use_windows)
-            for (int q = 0; q < Q; ++q)
-              launch_windows(Xs, sg.n, P, dZ.d() + q * P, ldz, M, h_ell[q], rw + 2 * wtiles * q, cw + 2 * ncb * q,
-                             winhit.as<unsigned char>(), st);
-          RbfBatch rbt;
-          rbt.nq = Q, rbt.var = dvar.d(), rbt.ell = dell.d(), rbt.sZ = P, rbt.sK = sK, rbt.sWin = 2 * wtiles;
-          launch_rbf(Xs, P, sg.n, P, dZ.d(), ldz, M, 0.0, 1.0, Kh.d() + sg.off * M, false, st, rw, false, &rbt);
-        }
-      }
+      if (&pl == &pools[0] && kuf_prefetched)
+        HIP_TRY(hipStreamWaitEvent(st, ev_kuf, 0));          // built on the second stream beside the tail of the K_uu chain
+      else
+        kuf_pool(pl, st);
       {
         // forward contraction for all latents (batched), row statistics fused into its epilogue; P~ itself is only
         // stored when the Z gradient (its one remaining consumer, colstats) is requested
@@ -611,6 +634,7 @@ struct hmogp_engine {
     for (int c = 0; c < NCAT; ++c) ms[c] = 0.0, launches[c] = 0;
     upload_params(p);
     HIP_TRY(hipEventRecord(ev_begin0, st));
+    plan_pools();
     u_algebra();
     row_pass();
     HIP_TRY(hipEventRecord(ev_begin1, st));
