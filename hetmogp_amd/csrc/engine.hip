@@ -252,8 +252,13 @@ struct hmogp_engine {
       throw EngineError{HMOGP_E_NO_DEVICE, "no HIP device visible (this library has no CPU path)"};
     if (device < 0 || device >= ndev) throw EngineError{HMOGP_E_NO_DEVICE, "HIP device ordinal out of range"};
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+    {  // the main stream carries the latency-bound chains: highest priority, so that its (small) launches are dispatched
+       // ahead of the bandwidth-bound work that runs beside them on the second stream
+      int lo = 0, hi = 0;
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
+      HIP_TRY(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, lo));
+    }
     for (hipEvent_t* e : {&ev_fork, &ev_S, &ev_join, &ev_col, &ev_kuf}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (hipEvent_t* e : {&ev_begin0, &ev_begin1, &ev_fin0, &ev_fin1}) HIP_TRY(hipEventCreate(e));
     f_index.assign(c->f_index, c->f_index + Df);
@@ -418,6 +423,15 @@ struct hmogp_engine {
     launch_trtri_batched(L.d(), HK.d(), G.d(), Q, M, st2);        // S^-1 = dpotri(L) (svmogp_inf.py:124)
     launch_ltl_batched(HK.d(), Sqi.d(), Q, M, st2);
     HIP_TRY(hipEventRecord(ev_join, st2));
+    // K_uf of the first pool only needs X, Z and the kernel hyper-parameters: it goes on the second (low-priority) stream
+    // behind the q(u) chain and overlaps the K_uu chain -- bandwidth-bound work filling the CUs that the latency-bound
+    // launches of the high-priority main stream leave idle.  (With equal priorities the Cholesky's 32 dependent launches
+    // starve behind a kernel that fills every CU.)
+    if (!pools.empty()) {
+      kuf_pool(pools[0], st2);
+      HIP_TRY(hipEventRecord(ev_kuf, st2));
+      kuf_prefetched = true;
+    }
     std::vector<double> key;
     if (cache_kuu) {
       key.assign(h_Z.begin(), h_Z.end());
@@ -436,15 +450,6 @@ struct hmogp_engine {
       launch_trtri_batched(Luu.d(), tmpA.d(), tmpB.d(), Q, M, st);
       launch_ltl_batched(tmpA.d(), Kuui.d(), Q, M, st);             // K_uu^-1          (util.py:199)
       if (cache_kuu) kuu_key.swap(key), kuu_rung = rung, kuu_key_valid = true;
-    }
-    // K_uf of the first pool only needs X, Z and the kernel hyper-parameters.  It goes on the second stream (behind the
-    // q(u) chain, which has finished by now: the jitter ladder above synchronised with the host) and overlaps the tail
-    // of the K_uu chain -- bandwidth-bound next to small latency-bound products.  (Not next to the Cholesky itself:
-    // its 32 dependent launches starve behind an HBM-bound kernel that fills every CU.)
-    if (!pools.empty()) {
-      kuf_pool(pools[0], st2);
-      HIP_TRY(hipEventRecord(ev_kuf, st2));
-      kuf_prefetched = true;
     }
     launch_gemv_batched(Kuui.d(), dmu.d(), a.d(), Q, M, 1, Q, st);  // a = K_uu^-1 m
     HIP_TRY(hipStreamWaitEvent(st, ev_S, 0));
