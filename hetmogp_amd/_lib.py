@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhetmogp_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 # likelihood ids (class names of the reference's likelihoods/<name>.py)
 LIK_GAUSSIAN, LIK_BERNOULLI, LIK_HETGAUSSIAN, LIK_CATEGORICAL, LIK_POISSON, LIK_EXPONENTIAL, LIK_GAMMA, LIK_BETA = range(8)
 LIK_IDS_BY_NAME = dict(Gaussian=0, Bernoulli=1, HetGaussian=2, Categorical=3, Poisson=4, Exponential=5, Gamma=6, Beta=7)
@@ -19,6 +19,15 @@ FLAG_V_NEGATIVE = 1
 GROUP_QU, GROUP_HYPER, GROUP_Z, GROUP_ALL = 1, 2, 4, 7
 CFG_EXACT_ZERO_WINDOWS = 1
 CFG_CACHE_KUU = 2
+QUIRK_GAMMA_BETA_PI, QUIRK_CATEGORICAL_DM, QUIRK_STALE_W, QUIRK_W_DIAG, QUIRK_KAPPA_DIAG = 1, 2, 4, 8, 16
+QUIRKS_REFERENCE, QUIRKS_EXACT = 31, 0
+
+
+def quirk_mask(q):
+    """"reference" | "exact" | int mask -> int."""
+    if isinstance(q, str):
+        return {"reference": QUIRKS_REFERENCE, "exact": QUIRKS_EXACT}[q]
+    return int(q)
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -29,7 +38,8 @@ c_uint32_p = C.POINTER(C.c_uint32)
 class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("T", C.c_int32), ("Q", C.c_int32), ("M", C.c_int32), ("P", C.c_int32),
                 ("Df", C.c_int32), ("lik_id", c_int32_p), ("lik_param", c_double_p), ("f_index", c_int32_p),
-                ("d_index", c_int32_p), ("device", C.c_int32), ("chunk_rows", C.c_int64), ("flags", C.c_uint32)]
+                ("d_index", c_int32_p), ("device", C.c_int32), ("chunk_rows", C.c_int64), ("flags", C.c_uint32),
+                ("quirks", C.c_uint32)]
 
 
 class Params(C.Structure):
@@ -58,12 +68,22 @@ EXPORTS = {
     "hmogp_step_finish": (C.c_int, [C.c_void_p, C.POINTER(Outputs)]),
     "hmogp_stats_read": (C.c_int, [C.c_void_p, c_double_p]),
     "hmogp_stats_write": (C.c_int, [C.c_void_p, c_double_p]),
+    "hmogp_wire_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_int64_p]),
+    "hmogp_wire_pack": (C.c_int, [C.c_void_p]),
+    "hmogp_wire_unpack": (C.c_int, [C.c_void_p]),
+    "hmogp_wire_read": (C.c_int, [C.c_void_p, c_double_p]),
+    "hmogp_wire_write": (C.c_int, [C.c_void_p, c_double_p]),
     "hmogp_posterior_u": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "hmogp_natgrad_step": (C.c_int, [C.c_void_p, C.c_double, c_double_p, c_double_p]),
     "hmogp_predict_f": (C.c_int, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p]),
     "hmogp_last_timings": (C.c_int, [C.c_void_p, c_double_p, c_int64_p]),
     "hmogp_rbf_cross_cov": (C.c_int, [C.c_int32, c_double_p, C.c_int64, c_double_p, C.c_int32, C.c_int32, C.c_double,
                                       C.c_double, c_double_p]),
+    "hmogp_rbf_cross_cov_ex": (C.c_int, [C.c_int32, c_double_p, C.c_int64, c_double_p, C.c_int32, C.c_int32, C.c_double,
+                                         C.c_double, C.c_int32, c_double_p]),
+    "hmogp_debug_raw_grads": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
+    "hmogp_var_exp_ex": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_uint32, C.c_int64, c_double_p, c_double_p,
+                                   c_double_p, c_double_p, c_double_p, c_double_p]),
     "hmogp_jitchol_inv": (C.c_int, [C.c_int32, c_double_p, C.c_int32, C.c_int32, c_int32_p, c_double_p, c_double_p,
                                     c_int32_p]),
     "hmogp_potri": (C.c_int, [C.c_int32, c_double_p, C.c_int32, C.c_int32, c_double_p]),
@@ -119,6 +139,12 @@ class HetMOGPError(RuntimeError):
         self.msg = msg
 
 
+class InvalidArgument(ValueError):
+    """HMOGP_E_INVALID: a programming / ABI error (bad row range, missing array, non-positive lengthscale ...).  A
+    ValueError subclass so existing handlers keep working, but distinct from the reference's numerical ValueError
+    ("Sqi: Cholesky representation unstable") so that optimisers do not swallow it as a failed evaluation."""
+
+
 def check(rc, handle=None):
     """Map C-ABI status codes onto the exception types the reference raises on the same conditions."""
     if rc == 0:
@@ -131,5 +157,5 @@ def check(rc, handle=None):
     if rc == E_SQI_UNSTABLE:
         raise ValueError(msg)                         # svmogp_inf.py:126-127
     if rc == E_INVALID:
-        raise ValueError(msg)
+        raise InvalidArgument(msg)
     raise HetMOGPError(rc, msg)

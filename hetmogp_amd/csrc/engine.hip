@@ -147,6 +147,7 @@ struct hmogp_engine {
   int T = 0, Q = 0, M = 0, P = 0, Df = 0, device = 0;
   long long chunk = 1048576;  // rows per pool (hmogp_config.chunk_rows); workspaces are sized by the rows actually streamed
   bool use_windows = false, cache_kuu = false, kuu_key_valid = false;
+  unsigned quirks = HMOGP_QUIRKS_REFERENCE;
   std::vector<double> h_Z, kuu_key;
   std::vector<int> rung_request, kuu_rung;
   std::vector<int> f_index, d_index;
@@ -169,7 +170,8 @@ struct hmogp_engine {
   // N x M workspaces and row vectors
   long long ws_rows = 0;
   DevBuf Kh, Pt, vp, vc, vpt, vct, valpha, vbeta, valpha0, vbeta0;
-  DevBuf stats, slabs, colpart, quadpart, fwdpart, winrow, wincol, winhit, Xws, dstage;
+  DevBuf stats, wire, slabs, colpart, quadpart, fwdpart, winrow, wincol, winhit, Xws, dstage;
+  long long nwire = 0;  // float64 words of the wire format (lower triangles of H_q only; rowpass.hip: wire_tri_kernel)
   double* hstage = nullptr;  // page-locked landing buffer of the small per-evaluation results
   size_t hstage_cap = 0;
   bool began = false, evaluated = false;
@@ -246,6 +248,8 @@ struct hmogp_engine {
     }
     use_windows = (c->flags & HMOGP_CFG_EXACT_ZERO_WINDOWS) != 0;
     cache_kuu = (c->flags & HMOGP_CFG_CACHE_KUU) != 0;
+    quirks = c->quirks;
+    if (quirks & ~HMOGP_QUIRKS_REFERENCE) throw EngineError{HMOGP_E_INVALID, "unknown bits in hmogp_config.quirks"};
     if (use_windows && M > 8192) throw EngineError{HMOGP_E_INVALID, "exact-zero windows support M <= 8192"};
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -285,6 +289,7 @@ struct hmogp_engine {
     per_q = oSWK + Df;
     nstats = NG + Q * per_q;
     stats.ensure(sizeof(double) * nstats, true);
+    nwire = NG + Q * ((long long)M * (M + 1) / 2 + (per_q - MM));
     for (int t = 0; t < T; ++t) {
       Task& k = tasks[t];
       const int J = k.dimf;
@@ -358,8 +363,11 @@ struct hmogp_engine {
     h_ell.assign(p->lengthscale, p->lengthscale + Q);
     h_W.assign(p->W, p->W + Q * Df);
     h_kap.assign(p->kappa, p->kappa + Q * Df);
-    h_W0.assign(p->W0 ? p->W0 : p->W, (p->W0 ? p->W0 : p->W) + Q * Df);
-    h_kap0.assign(p->kappa0 ? p->kappa0 : p->kappa, (p->kappa0 ? p->kappa0 : p->kappa) + Q * Df);
+    const bool stale = (quirks & HMOGP_QUIRK_STALE_W) != 0;   // exact mode: the chain factors are the live W / kappa
+    const double* w0 = (stale && p->W0) ? p->W0 : p->W;
+    const double* k0 = (stale && p->kappa0) ? p->kappa0 : p->kappa;
+    h_W0.assign(w0, w0 + Q * Df);
+    h_kap0.assign(k0, k0 + Q * Df);
     h_bs.assign(T, 1.0);
     if (p->batch_scale) h_bs.assign(p->batch_scale, p->batch_scale + T);
     rb.assign(T, 0), re.resize(T);
@@ -583,6 +591,7 @@ struct hmogp_engine {
             }
           }
           qa.scale = h_bs[sg.t];
+          qa.quirks = quirks;
           qa.alpha = valpha.d() + sg.off, qa.beta = vbeta.d() + sg.off;
           qa.alpha0 = valpha0.d() + sg.off, qa.beta0 = vbeta0.d() + sg.off;
           qa.partials = quadpart.d();
@@ -628,7 +637,17 @@ struct hmogp_engine {
       }
       HIP_TRY(hipStreamWaitEvent(st, ev_col, 0));      // the workspaces are reused by the next pool
     }
-    launch_mirror_lower(Hq(0), Q, M, per_q, st);
+    // (H_q holds its lower triangle only from here to hmogp_step_finish, which mirrors it: the exchange step of a
+    // multi-GPU run all-reduces the triangle, wire_pack / wire_unpack)
+  }
+
+  // bundle <-> wire format, synchronous at return (the caller's all-reduce runs on another stream / library)
+  void wire_copy(int dir) {
+    if (!began) throw EngineError{HMOGP_E_STATE, "wire pack / unpack outside hmogp_step_begin .. hmogp_step_finish"};
+    HIP_TRY(hipSetDevice(device));
+    wire.ensure(sizeof(double) * nwire, true);
+    launch_wire_copy(stats.d(), wire.d(), NG, Q, M, per_q, dir, st);
+    HIP_TRY(hipStreamSynchronize(st));
   }
 
   void begin(const hmogp_params* p) {
@@ -658,6 +677,7 @@ struct hmogp_engine {
     HIP_TRY(hipEventRecord(ev_fin0, st));
     {
       Scope sc(this, CAT_MM, 0);
+      launch_mirror_lower(Hq(0), Q, M, per_q, st);                   // the row pass / the exchange fill the lower triangle
       mm(Hq(0), false, Kuui.d(), true, HK.d(), 1.0, per_q);          // H K^-1
       mm(Kuui.d(), false, HK.d(), true, G.d());                      // G = K^-1 H K^-1  (dVE_dS, svmogp_inf.py:148)
       launch_gemv_batched(Kuui.d(), Hq(0) + oR, Kr.d(), Q, M, per_q, 1, st);  // K^-1 r  (dVE_dmu, :144)
@@ -756,8 +776,11 @@ struct hmogp_engine {
       }
       if (out->g_lengthscale) out->g_lengthscale[q] = hy ? (s2 / ell + sl / ell) : 0.0;
       for (int d = 0; d < Df; ++d) {
-        if (out->g_W) out->g_W[q * Df + d] = hy ? (h_W[q * Df + d] * sgv[d] + swk[d]) : 0.0;  // util.py:230 + :252
-        if (out->g_kappa) out->g_kappa[q * Df + d] = hy ? sgv[d] : 0.0;                         // util.py:231
+        // util.py:230 + :252 (quirk Q4: the K_ff-diagonal part is W sum(gv); the true value is 2 W variance sum(gv))
+        const double wdiag = (quirks & HMOGP_QUIRK_W_DIAG) ? h_W[q * Df + d] * sgv[d] : 2.0 * h_W[q * Df + d] * var * sgv[d];
+        if (out->g_W) out->g_W[q * Df + d] = hy ? (wdiag + swk[d]) : 0.0;
+        // util.py:231 (quirk Q5: sum(gv); the true value is variance sum(gv))
+        if (out->g_kappa) out->g_kappa[q * Df + d] = hy ? ((quirks & HMOGP_QUIRK_KAPPA_DIAG) ? sgv[d] : var * sgv[d]) : 0.0;
       }
       if (out->g_Z)
         for (int m = 0; m < M; ++m)
@@ -782,6 +805,79 @@ struct hmogp_engine {
       HIP_TRY(hipMemcpyAsync(winv, tmpA.p, sizeof(double) * MM * Q, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
+  }
+
+  // Inner-protocol debug export (include/hetmogp_hip.h: hmogp_debug_raw_grads): the gradient dictionary of
+  // SVMOGPInf.inference (svmogp_inf.py:107) rebuilt from what the last evaluation left in HBM -- dKmm, a, P~ of the one
+  // pool, p / c row statistics -- plus one more quadrature pass that writes the per-function d ve/dm, d ve/dv rows.
+  void debug_raw(double* o_kmm, double* o_kmn, double* o_kdiag) {
+    if (!evaluated) throw EngineError{HMOGP_E_STATE, "no finished evaluation"};
+    if ((group_mask & HMOGP_GROUP_ALL) != HMOGP_GROUP_ALL) throw EngineError{HMOGP_E_STATE, "debug export needs group_mask = HMOGP_GROUP_ALL"};
+    if (pools.size() != 1) throw EngineError{HMOGP_E_STATE, "debug export needs all rows in one pool (small N)"};
+    HIP_TRY(hipSetDevice(device));
+    const long long MM = (long long)M * M, ldn = ws_rows;
+    if (o_kmm) HIP_TRY(hipMemcpyAsync(o_kmm, dKmm.p, sizeof(double) * MM * Q, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (!o_kmn && !o_kdiag) return;
+    const auto& pl = pools[0];
+    std::vector<long long> nt(T, 0), off(T, 0);
+    for (auto& sg : pl) {
+      if (nt[sg.t] == 0) off[sg.t] = sg.off;
+      nt[sg.t] += sg.n;   // a task's segments are contiguous inside the pool
+    }
+    long long nmax = 1;
+    for (int t = 0; t < T; ++t) nmax = std::max(nmax, nt[t]);
+    DevBuf gm, gv, tile;
+    std::vector<DevBuf> gmt(T), gvt(T);
+    for (auto& sg : pl) {
+      Task& k = tasks[sg.t];
+      gmt[sg.t].ensure(sizeof(double) * nt[sg.t] * k.dimf), gvt[sg.t].ensure(sizeof(double) * nt[sg.t] * k.dimf);
+      QuadArgs qa;
+      qa.lik = k.lik, qa.lik_param = k.param, qa.dimf = k.dimf, qa.Q = Q, qa.N = sg.n;
+      qa.y = k.Y.d() + sg.r0;
+      qa.yaux = k.Yaux.p ? k.Yaux.d() + sg.r0 : nullptr;
+      qa.p = vp.d() + sg.off, qa.c = vc.d() + sg.off, qa.pt = vpt.d() + sg.off, qa.ct = vct.d() + sg.off;
+      qa.ldn = ldn;
+      std::memset(qa.w, 0, sizeof(qa.w)), std::memset(qa.w0, 0, sizeof(qa.w0)), std::memset(qa.kap, 0, sizeof(qa.kap));
+      std::memset(qa.var, 0, sizeof(qa.var));
+      for (int q = 0; q < Q; ++q) {
+        qa.var[q] = h_var[q];
+        for (int j = 0; j < k.dimf; ++j) {
+          qa.w[q][j] = h_W[q * Df + k.d0 + j];
+          qa.w0[q][j] = h_W0[q * Df + k.d0 + j];
+          qa.kap[q][j] = h_kap[q * Df + k.d0 + j];
+        }
+      }
+      qa.scale = h_bs[sg.t];
+      qa.quirks = quirks;
+      qa.alpha = valpha.d() + sg.off, qa.beta = vbeta.d() + sg.off;      // rewritten with identical values
+      qa.alpha0 = valpha0.d() + sg.off, qa.beta0 = vbeta0.d() + sg.off;
+      qa.partials = quadpart.d();
+      const long long within = sg.off - off[sg.t];
+      qa.out_gm = gmt[sg.t].d() + within * k.dimf, qa.out_gv = gvt[sg.t].d() + within * k.dimf;
+      launch_quad(qa, st);
+    }
+    tile.ensure(sizeof(double) * nmax * M);
+    std::vector<double> hgv;
+    size_t o1 = 0, o2 = 0;
+    for (int q = 0; q < Q; ++q)
+      for (int d = 0; d < Df; ++d) {
+        const int t = f_index[d], j = d_index[d], J = tasks[t].dimf;
+        const long long n = nt[t];
+        if (o_kmn && n > 0) {
+          launch_raw_kmn(a.d() + (long long)q * M, gmt[t].d(), gvt[t].d(), J, j, h_W[q * Df + d],
+                         Pt.d() + (long long)q * ldn * M + off[t] * M, M, n, tile.d(), st);
+          HIP_TRY(hipMemcpyAsync(o_kmn + o1, tile.p, sizeof(double) * n * M, hipMemcpyDeviceToHost, st));
+          HIP_TRY(hipStreamSynchronize(st));
+        }
+        o1 += (size_t)n * M;
+        if (o_kdiag && n > 0) {
+          hgv.resize((size_t)n * J);
+          HIP_TRY(hipMemcpy(hgv.data(), gvt[t].p, sizeof(double) * n * J, hipMemcpyDeviceToHost));
+          for (long long i = 0; i < n; ++i) o_kdiag[o2 + i] = hgv[(size_t)i * J + j];
+        }
+        o2 += (size_t)n;
+      }
   }
 
   // Natural-gradient update of q(u_q) = N(m_q, S_q) from the gradients of the last evaluation (the
@@ -962,6 +1058,44 @@ int hmogp_stats_write(hmogp_handle h, const double* host) {
   });
 }
 
+int hmogp_wire_buffer(hmogp_handle h, void** device_ptr, int64_t* count) {
+  if (!h || !device_ptr || !count) return HMOGP_E_INVALID;
+  return guarded(h, [&] {
+    HIP_TRY(hipSetDevice(h->device));
+    h->wire.ensure(sizeof(double) * h->nwire, true);
+    *device_ptr = h->wire.p;
+    *count = h->nwire;
+  });
+}
+
+int hmogp_wire_pack(hmogp_handle h) {
+  if (!h) return HMOGP_E_INVALID;
+  return guarded(h, [&] { h->wire_copy(0); });
+}
+
+int hmogp_wire_unpack(hmogp_handle h) {
+  if (!h) return HMOGP_E_INVALID;
+  return guarded(h, [&] { h->wire_copy(1); });
+}
+
+int hmogp_wire_read(hmogp_handle h, double* host) {
+  if (!h || !host) return HMOGP_E_INVALID;
+  return guarded(h, [&] {
+    HIP_TRY(hipSetDevice(h->device));
+    h->wire.ensure(sizeof(double) * h->nwire, true);
+    HIP_TRY(hipMemcpy(host, h->wire.p, sizeof(double) * h->nwire, hipMemcpyDeviceToHost));
+  });
+}
+
+int hmogp_wire_write(hmogp_handle h, const double* host) {
+  if (!h || !host) return HMOGP_E_INVALID;
+  return guarded(h, [&] {
+    HIP_TRY(hipSetDevice(h->device));
+    h->wire.ensure(sizeof(double) * h->nwire, true);
+    HIP_TRY(hipMemcpy(h->wire.p, host, sizeof(double) * h->nwire, hipMemcpyHostToDevice));
+  });
+}
+
 int hmogp_step_finish(hmogp_handle h, hmogp_outputs* out) {
   if (!h) return HMOGP_E_INVALID;
   return guarded(h, [&] { h->finish(out); });
@@ -978,6 +1112,11 @@ int hmogp_elbo_grad(hmogp_handle h, const hmogp_params* p, hmogp_outputs* out) {
 int hmogp_posterior_u(hmogp_handle h, double* woodbury_vector, double* woodbury_inv) {
   if (!h) return HMOGP_E_INVALID;
   return guarded(h, [&] { h->posterior_u(woodbury_vector, woodbury_inv); });
+}
+
+int hmogp_debug_raw_grads(hmogp_handle h, double* dL_dKmm, double* dL_dKmn, double* dL_dKdiag) {
+  if (!h) return HMOGP_E_INVALID;
+  return guarded(h, [&] { h->debug_raw(dL_dKmm, dL_dKmn, dL_dKdiag); });
 }
 
 int hmogp_natgrad_step(hmogp_handle h, double gamma, double* m_u_new, double* L_flat_new) {
@@ -1002,6 +1141,11 @@ int hmogp_last_timings(hmogp_handle h, double* out_ms8, int64_t* launches8) {
 // ---- building blocks -----------------------------------------------------------------------------------
 int hmogp_rbf_cross_cov(int32_t device, const double* X, int64_t N, const double* Z, int32_t M, int32_t P, double variance,
                         double lengthscale, double* K) {
+  return hmogp_rbf_cross_cov_ex(device, X, N, Z, M, P, variance, lengthscale, 1, K);
+}
+
+int hmogp_rbf_cross_cov_ex(int32_t device, const double* X, int64_t N, const double* Z, int32_t M, int32_t P, double variance,
+                           double lengthscale, int32_t exact, double* K) {
   return guarded(nullptr, [&] {
     need_device(device);
     if (N <= 0 || M <= 0 || !X || !Z || !K) throw EngineError{HMOGP_E_INVALID, "bad arguments"};
@@ -1009,7 +1153,7 @@ int hmogp_rbf_cross_cov(int32_t device, const double* X, int64_t N, const double
     dX.ensure(sizeof(double) * N * P), dZ.ensure(sizeof(double) * M * P), dK.ensure(sizeof(double) * N * M);
     HIP_TRY(hipMemcpy(dX.p, X, sizeof(double) * N * P, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dZ.p, Z, sizeof(double) * M * P, hipMemcpyHostToDevice));
-    launch_rbf(dX.d(), P, N, P, dZ.d(), P, M, variance, lengthscale, dK.d(), false, nullptr);
+    launch_rbf(dX.d(), P, N, P, dZ.d(), P, M, variance, lengthscale, dK.d(), false, nullptr, nullptr, exact != 0);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(K, dK.p, sizeof(double) * N * M, hipMemcpyDeviceToHost));
   });
@@ -1086,6 +1230,11 @@ int hmogp_gemm_f64(int32_t device, int32_t transA, int32_t transB, int32_t M, in
 
 int hmogp_var_exp(int32_t device, int32_t lik_id, double lik_param, int64_t N, const double* y, const double* m,
                   const double* v, double* ve, double* dm, double* dv) {
+  return hmogp_var_exp_ex(device, lik_id, lik_param, HMOGP_QUIRKS_REFERENCE, N, y, m, v, ve, dm, dv);
+}
+
+int hmogp_var_exp_ex(int32_t device, int32_t lik_id, double lik_param, uint32_t quirks, int64_t N, const double* y,
+                     const double* m, const double* v, double* ve, double* dm, double* dv) {
   return guarded(nullptr, [&] {
     need_device(device);
     if (lik_id == HMOGP_LIK_GAUSSIAN && !(lik_param > 0.0)) lik_param = 0.5;
@@ -1098,7 +1247,7 @@ int hmogp_var_exp(int32_t device, int32_t lik_id, double lik_param, int64_t N, c
     HIP_TRY(hipMemcpy(dy.p, y, sizeof(double) * N, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dmm.p, m, sizeof(double) * N * J, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dvv.p, v, sizeof(double) * N * J, hipMemcpyHostToDevice));
-    launch_var_exp(lik_id, J, lik_param, N, dy.d(), dmm.d(), dvv.d(), dve.d(), ddm.d(), ddv.d(), nullptr);
+    launch_var_exp(lik_id, J, lik_param, N, dy.d(), dmm.d(), dvv.d(), dve.d(), ddm.d(), ddv.d(), nullptr, quirks);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(ve, dve.p, sizeof(double) * N, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(dm, ddm.p, sizeof(double) * N * J, hipMemcpyDeviceToHost));

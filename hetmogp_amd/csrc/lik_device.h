@@ -176,7 +176,7 @@ __device__ __forceinline__ void lik_beta_wave(double y, const double* m, const d
 // categorical.py:37-46,77-82,102-222.  K classes, D = K-1 functions, labels 1..K (class K = reference class),
 // 10^D tensor nodes strided over the wave.  `etab` is a per-wave LDS table [D][10] of exp(f_k(node i)).
 __device__ __forceinline__ void lik_categorical_wave(double y, const double* m, const double* v, int K, int lane,
-                                                     double* etab, LikOut& o) {
+                                                     double* etab, unsigned quirks, LikOut& o) {
   const int D = K - 1;
   for (int e = lane; e < D * 10; e += 64) {
     const int k = e / 10, i = e - 10 * k;
@@ -188,9 +188,10 @@ __device__ __forceinline__ void lik_categorical_wave(double y, const double* m, 
   const int label = (int)y;  // 1..K
   const bool valid = (y == (double)label) && label >= 1 && label <= K;
   double ve = 0.0;
-  double hv[HMOGP_MAXJ];
+  double hv[HMOGP_MAXJ], gx[HMOGP_MAXJ];
+  const bool exact_dm = (quirks & HMOGP_QUIRK_CATEGORICAL_DM) == 0;
 #pragma unroll
-  for (int k = 0; k < HMOGP_MAXJ; ++k) hv[k] = 0.0;
+  for (int k = 0; k < HMOGP_MAXJ; ++k) hv[k] = gx[k] = 0.0;
   for (int n = lane; n < total; n += 64) {
     double e[HMOGP_MAXJ];
     double w = 1.0, esum = 0.0;
@@ -233,6 +234,7 @@ __device__ __forceinline__ void lik_categorical_wave(double y, const double* m, 
         for (int j = 0; j < HMOGP_MAXJ; ++j)
           if (j < D && j != d) num += fmin(e[j] * e[d], 1.79769313486231570815e308);
         hv[d] += w * (num / den2);
+        if (exact_dm) gx[d] += w * ((label == d + 1 ? 1.0 : 0.0) - e[d] / den);  // E[d log p_y / d f_d], softmax
       }
     }
   }
@@ -244,7 +246,12 @@ __device__ __forceinline__ void lik_categorical_wave(double y, const double* m, 
     if (d < D) {
       const double s = wave_sum(hv[d]);
       o.gv[d] = valid ? -0.5 * s : 0.0;
-      o.gm[d] = ((label == d + 1 ? 1.0 : 0.0) - (valid ? 1.0 : 0.0)) * wpow;  // quirk Q2
+      if (exact_dm) {
+        const double g = wave_sum(gx[d]);
+        o.gm[d] = valid ? g : 0.0;
+      } else {
+        o.gm[d] = ((label == d + 1 ? 1.0 : 0.0) - (valid ? 1.0 : 0.0)) * wpow;  // quirk Q2
+      }
     }
   }
 }
@@ -444,7 +451,7 @@ __host__ __device__ constexpr int lik_lanes(int lik) {
 // every lane.  `etab` (per-wave LDS, HMOGP_MAXJ*10 doubles) is only used by Categorical.
 template <int LIK>
 __device__ __forceinline__ void lik_eval(double y, double yaux, const double* m, const double* v, double param, int lane,
-                                         double* etab, LikOut& o) {
+                                         double* etab, unsigned quirks, LikOut& o) {
   if (LIK == HMOGP_LIK_GAUSSIAN)
     lik_gaussian(y, m[0], v[0], param, o);
   else if (LIK == HMOGP_LIK_HETGAUSSIAN)
@@ -456,5 +463,10 @@ __device__ __forceinline__ void lik_eval(double y, double yaux, const double* m,
   else if (LIK == HMOGP_LIK_BETA)
     lik_beta_wave(y, m, v, lane, o);
   else
-    lik_categorical_wave(y, m, v, (int)param, lane, etab, o);
+    lik_categorical_wave(y, m, v, (int)param, lane, etab, quirks, o);
+  if ((LIK == HMOGP_LIK_GAMMA || LIK == HMOGP_LIK_BETA) && !(quirks & HMOGP_QUIRK_GAMMA_BETA_PI)) {
+    o.ve *= M_PI;  // exact mode: undo the second division of each dimension's weights by sqrt(pi) (quirk Q1)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) o.gm[j] *= M_PI, o.gv[j] *= M_PI;
+  }
 }

@@ -24,6 +24,7 @@ struct QuadArgs {
   double kap[HMOGP_MAXQ][HMOGP_MAXJ];  // live kappa
   double var[HMOGP_MAXQ];              // RBF variances
   double scale = 1.0;                  // batch_scale[t]
+  unsigned quirks = 0x1fu;             // HMOGP_QUIRK_* (default: reproduce the reference)
   double* alpha = nullptr;             // [Q][ldn] outputs: row weights of the backward pass
   double* beta = nullptr;
   double* alpha0 = nullptr;
@@ -31,6 +32,8 @@ struct QuadArgs {
   double* partials = nullptr;          // [nblocks][nscal]
   double* out_mu = nullptr;            // optional [N][dimf]: q(f) mean / variance (prediction, parity tests)
   double* out_v = nullptr;
+  double* out_gm = nullptr;            // optional [N][dimf]: scaled d ve / d m, d ve / d v (inner-protocol debug export)
+  double* out_gv = nullptr;
 };
 
 // per-latent strides of the batched (grid.z = latent) row kernels
@@ -48,7 +51,7 @@ struct ColBatch {
 long long quad_blocks(int lik, long long N);
 void launch_quad(const QuadArgs& a, hipStream_t s);
 void launch_var_exp(int lik, int J, double param, long long N, const double* y, const double* m, const double* v, double* ve,
-                    double* dm, double* dv, hipStream_t s);
+                    double* dm, double* dv, hipStream_t s, unsigned quirks = 0x1fu);
 // K[n][m] = var * exp(-r2/2); X rows have stride ldx, Z rows stride ldz (block q of the M x Q*P inducing array)
 // predictive mean / variance of y: m, v [N][J] -> mean, var [N][Jp]; T = Gauss-Hermite order (10 or 20)
 void launch_predictive(int lik, int J, int Jp, double param, int T, long long N, const double* m, const double* v,
@@ -73,4 +76,9 @@ void launch_reduce_rows(const double* partials, long long nrows, int len, const 
 void launch_reduce_slabs(const double* slabs, int nslabs, long long stride, long long len, double* dst, bool accumulate,
                          hipStream_t s, int nb = 1, long long sSlabs = 0, long long sDst = 0);
 void launch_mirror_lower(double* A, int Q, int M, long long stride, hipStream_t s);
+// statistic bundle <-> wire format (lower triangles of H_q only); dir 0 = pack, 1 = unpack (lower triangle only)
+void launch_wire_copy(double* bundle, double* wire, long long NG, int Q, int M, long long per_q, int dir, hipStream_t s);
+// inner-protocol debug export: out[m][n] = a[m] gm[n][j] + 2 w gv[n][j] Pt[n][m]   (svmogp_inf.py:157-161), out is [M][N]
+void launch_raw_kmn(const double* a, const double* gm, const double* gv, int J, int j, double w, const double* Pt, int M,
+                    long long N, double* out, hipStream_t s);
 void launch_gammaln1p(const double* y, double* out, long long N, hipStream_t s);

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void quad_kernel(QuadArgs a) {
   o.ve = 0.0;
 #pragma unroll
   for (int j = 0; j < HMOGP_MAXJ; ++j) o.gm[j] = o.gv[j] = 0.0;
-  if (valid) lik_eval<LIK>(a.y[n], a.yaux ? a.yaux[n] : 0.0, mu, vv, a.lik_param, lane, etab[w], o);
+  if (valid) lik_eval<LIK>(a.y[n], a.yaux ? a.yaux[n] : 0.0, mu, vv, a.lik_param, lane, etab[w], a.quirks, o);
   if (a.out_mu && lead) {
     for (int j = 0; j < J; ++j) {
       a.out_mu[n * J + j] = mu[j];
@@ -274,6 +274,12 @@ __global__ __launch_bounds__(256) void quad_kernel(QuadArgs a) {
   for (int j = 0; j < HMOGP_MAXJ; ++j) {
     o.gm[j] *= s;
     o.gv[j] *= s;
+  }
+  if (a.out_gm && lead) {
+    for (int j = 0; j < J; ++j) {
+      a.out_gm[n * J + j] = o.gm[j];
+      a.out_gv[n * J + j] = o.gv[j];
+    }
   }
   emit(0, o.ve);
   emit(1, (lead && neg) ? 1.0 : 0.0);
@@ -471,6 +477,46 @@ __global__ void mirror_lower_kernel(double* __restrict__ A, int M, long long str
   if (c < M && c > r) a[(long long)r * M + c] = a[(long long)c * M + r];
 }
 
+// Wire format of the statistic bundle (what a multi-GPU run all-reduces): H_q is symmetric and the row pass only fills its
+// lower triangle, so only that triangle travels -- [head NG | per q: tril(H_q) row-major packed (M(M+1)/2) | tail (per_q - M*M)].
+// dir 0: bundle -> wire, dir 1: wire -> bundle (lower triangle; hmogp_step_finish mirrors it).
+__global__ void wire_tri_kernel(double* __restrict__ bundle_q0, double* __restrict__ wire_q0, int M, long long per_q,
+                                long long wire_per_q, int dir) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c > r) return;
+  double* h = bundle_q0 + (long long)blockIdx.z * per_q + (long long)r * M + c;
+  double* w = wire_q0 + (long long)blockIdx.z * wire_per_q + (long long)r * (r + 1) / 2 + c;
+  if (dir == 0) *w = *h;
+  else *h = *w;
+}
+// head (q == gridDim.y - 1 ... see launcher) and per-latent tails
+__global__ void wire_rest_kernel(double* __restrict__ bundle, double* __restrict__ wire, long long NG, long long MM,
+                                 long long Mtri, long long per_q, long long wire_per_q, int Q, int dir) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long tail = per_q - MM;
+  if (i < NG) {
+    if (dir == 0) wire[i] = bundle[i];
+    else bundle[i] = wire[i];
+    return;
+  }
+  const long long k = i - NG;
+  if (k >= tail * Q) return;
+  const long long q = k / tail, e = k - q * tail;
+  double* b = bundle + NG + q * per_q + MM + e;
+  double* w = wire + NG + q * wire_per_q + Mtri + e;
+  if (dir == 0) *w = *b;
+  else *b = *w;
+}
+
+__global__ void raw_kmn_kernel(const double* __restrict__ a, const double* __restrict__ gm, const double* __restrict__ gv,
+                               int J, int j, double w, const double* __restrict__ Pt, int M, long long N,
+                               double* __restrict__ out) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = blockIdx.y;
+  if (n >= N) return;
+  out[(long long)m * N + n] = a[m] * gm[n * J + j] + 2.0 * w * (gv[n * J + j] * Pt[n * M + m]);
+}
+
 __global__ void gammaln1p_kernel(const double* __restrict__ y, double* __restrict__ out, long long N) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < N) out[i] = lgamma(y[i] + 1.0);
@@ -481,7 +527,7 @@ template <int LIK>
 __global__ __launch_bounds__(256) void var_exp_kernel(int J, double param, long long N, const double* __restrict__ y,
                                                       const double* __restrict__ m, const double* __restrict__ v,
                                                       double* __restrict__ ve, double* __restrict__ dm,
-                                                      double* __restrict__ dv) {
+                                                      double* __restrict__ dv, unsigned quirks) {
   constexpr int G = lik_lanes(LIK);
   __shared__ double etab[4][HMOGP_MAXJ * 10];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -497,7 +543,7 @@ __global__ __launch_bounds__(256) void var_exp_kernel(int J, double param, long 
 #pragma unroll
   for (int j = 0; j < HMOGP_MAXJ; ++j) o.gm[j] = o.gv[j] = 0.0;
   const double yy = y[n];
-  lik_eval<LIK>(yy, (LIK == HMOGP_LIK_POISSON) ? lgamma(yy + 1.0) : 0.0, mu, vv, param, lane, etab[w], o);
+  lik_eval<LIK>(yy, (LIK == HMOGP_LIK_POISSON) ? lgamma(yy + 1.0) : 0.0, mu, vv, param, lane, etab[w], quirks, o);
   if (G == 1 || lane == 0) {
     ve[n] = o.ve;
     for (int j = 0; j < J; ++j) {
@@ -625,10 +671,10 @@ void launch_quad(const QuadArgs& a, hipStream_t s) {
 }
 
 void launch_var_exp(int lik, int J, double param, long long N, const double* y, const double* m, const double* v, double* ve,
-                    double* dm, double* dv, hipStream_t s) {
+                    double* dm, double* dv, hipStream_t s, unsigned quirks) {
   if (N <= 0) return;
   dim3 grid((unsigned)quad_blocks(lik, N));
-#define VK(L) hipLaunchKernelGGL((var_exp_kernel<L>), grid, dim3(256), 0, s, J, param, N, y, m, v, ve, dm, dv)
+#define VK(L) hipLaunchKernelGGL((var_exp_kernel<L>), grid, dim3(256), 0, s, J, param, N, y, m, v, ve, dm, dv, quirks)
   switch (lik) {
     case HMOGP_LIK_GAUSSIAN: VK(HMOGP_LIK_GAUSSIAN); break;
     case HMOGP_LIK_BERNOULLI: VK(HMOGP_LIK_BERNOULLI); break;
@@ -711,6 +757,21 @@ void launch_reduce_slabs_lower(const double* slabs, int nslabs, int M, double* d
 
 void launch_mirror_lower(double* A, int Q, int M, long long stride, hipStream_t s) {
   hipLaunchKernelGGL(mirror_lower_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, A, M, stride);
+}
+
+void launch_wire_copy(double* bundle, double* wire, long long NG, int Q, int M, long long per_q, int dir, hipStream_t s) {
+  const long long MM = (long long)M * M, Mtri = (long long)M * (M + 1) / 2, wire_per_q = Mtri + (per_q - MM);
+  hipLaunchKernelGGL(wire_tri_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, bundle + NG, wire + NG, M, per_q, wire_per_q,
+                     dir);
+  const long long rest = NG + (per_q - MM) * Q;
+  hipLaunchKernelGGL(wire_rest_kernel, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, s, bundle, wire, NG, MM, Mtri, per_q,
+                     wire_per_q, Q, dir);
+}
+
+void launch_raw_kmn(const double* a, const double* gm, const double* gv, int J, int j, double w, const double* Pt, int M,
+                    long long N, double* out, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(raw_kmn_kernel, dim3((unsigned)((N + 255) / 256), M), dim3(256), 0, s, a, gm, gv, J, j, w, Pt, M, N, out);
 }
 
 void launch_gammaln1p(const double* y, double* out, long long N, hipStream_t s) {

@@ -74,7 +74,7 @@ class Engine(object):
     """specs: list of (likelihood class name, kwargs) per task, e.g. [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {})]."""
 
     def __init__(self, specs, Q, M, P, device=0, chunk_rows=0, exact_zero_windows=False, cache_kuu=False,
-                 reuse_outputs=False):
+                 reuse_outputs=False, quirks="reference"):
         self.specs = [(n, dict(k)) for n, k in specs]
         self.T, self.Q, self.M, self.P = len(specs), int(Q), int(M), int(P)
         f_index, d_index = [], []
@@ -92,7 +92,9 @@ class Engine(object):
                           lik_id.ctypes.data_as(_lib.c_int32_p), _p(lik_par),
                           self.f_index.ctypes.data_as(_lib.c_int32_p), self.d_index.ctypes.data_as(_lib.c_int32_p),
                           int(device), int(chunk_rows),
-                          (_lib.CFG_EXACT_ZERO_WINDOWS if exact_zero_windows else 0) | (_lib.CFG_CACHE_KUU if cache_kuu else 0))
+                          (_lib.CFG_EXACT_ZERO_WINDOWS if exact_zero_windows else 0) | (_lib.CFG_CACHE_KUU if cache_kuu else 0),
+                          _lib.quirk_mask(quirks))
+        self.quirks = _lib.quirk_mask(quirks)
         self._h = C.c_void_p()
         check(lib.hmogp_create(C.byref(cfg), C.byref(self._h)), None)
         self.N = [0] * self.T
@@ -215,6 +217,28 @@ class Engine(object):
         host = _f64(host)
         check(lib.hmogp_stats_write(self._h, _p(host)), self._h)
 
+    def wire_buffer(self):
+        """(device pointer, float64 count) of the wire format of the bundle (lower triangles of H_q only)."""
+        ptr, n = C.c_void_p(), C.c_int64()
+        check(lib.hmogp_wire_buffer(self._h, C.byref(ptr), C.byref(n)), self._h)
+        return ptr.value, n.value
+
+    def wire_pack(self):
+        check(lib.hmogp_wire_pack(self._h), self._h)
+
+    def wire_unpack(self):
+        check(lib.hmogp_wire_unpack(self._h), self._h)
+
+    def wire_read(self):
+        _, n = self.wire_buffer()
+        out = np.zeros(n)
+        check(lib.hmogp_wire_read(self._h, _p(out)), self._h)
+        return out
+
+    def wire_write(self, host):
+        host = _f64(host)
+        check(lib.hmogp_wire_write(self._h, _p(host)), self._h)
+
     def step_finish(self, want_dL_dS=False):
         c, o = self._outputs(want_dL_dS)
         check(lib.hmogp_step_finish(self._h, C.byref(c)), self._h)
@@ -241,6 +265,29 @@ class Engine(object):
         check(lib.hmogp_predict_f(self._h, _p(Xnew), Xnew.shape[0], _p(m), _p(v)), self._h)
         return m, v
 
+    def debug_raw_grads(self, rows):
+        """The reference's inner-protocol gradient dict of the last evaluation (small N, one pool, GROUP_ALL):
+        rows[t] = rows of task t in that evaluation.  Returns dict(dL_dKmm [Q][M,M], dL_dKmn [Q][Df][M,N_t],
+        dL_dKdiag [Q][Df][N_t])."""
+        Q, M, Df = self.Q, self.M, self.Df
+        nd = [int(rows[self.f_index[d]]) for d in range(Df)]
+        kmm = np.zeros((Q, M, M))
+        kmn = np.zeros(Q * M * sum(nd))
+        kdg = np.zeros(Q * sum(nd))
+        check(lib.hmogp_debug_raw_grads(self._h, _p(kmm), _p(kmn), _p(kdg)), self._h)
+        out = dict(dL_dKmm=[kmm[q] for q in range(Q)], dL_dKmn=[], dL_dKdiag=[])
+        o1 = o2 = 0
+        for q in range(Q):
+            a, b = [], []
+            for d in range(Df):
+                a.append(kmn[o1:o1 + M * nd[d]].reshape(M, nd[d]))
+                b.append(kdg[o2:o2 + nd[d]].copy())
+                o1 += M * nd[d]
+                o2 += nd[d]
+            out["dL_dKmn"].append(a)
+            out["dL_dKdiag"].append(b)
+        return out
+
     def timings(self):
         ms = np.zeros(8)
         n = np.zeros(8, dtype=np.int64)
@@ -251,13 +298,14 @@ class Engine(object):
 
 
 # ---------------------------------------------------------------------------------------------- building blocks
-def rbf_cross_cov(X, Z, variance, lengthscale, device=0):
+def rbf_cross_cov(X, Z, variance, lengthscale, device=0, exact=True):
+    """K = k(X, Z).  exact=True: GPy's rounding order (the K_uu variant); exact=False: the hot-path K_uf variant."""
     X, Z = _f64(X), _f64(Z)
     X = X.reshape(X.shape[0], -1)
     Z = Z.reshape(Z.shape[0], -1)
     K = np.zeros((X.shape[0], Z.shape[0]))
-    check(lib.hmogp_rbf_cross_cov(device, _p(X), X.shape[0], _p(Z), Z.shape[0], X.shape[1], float(variance),
-                                  float(lengthscale), _p(K)))
+    check(lib.hmogp_rbf_cross_cov_ex(device, _p(X), X.shape[0], _p(Z), Z.shape[0], X.shape[1], float(variance),
+                                     float(lengthscale), 1 if exact else 0, _p(K)))
     return K
 
 
@@ -289,13 +337,13 @@ def gemm(A, B, transA=False, transB=False, alpha=1.0, beta=0.0, C0=None, device=
     return Cm
 
 
-def var_exp(name, y, m, v, device=0, **kw):
+def var_exp(name, y, m, v, device=0, quirks="reference", **kw):
     y, m, v = _f64(y).reshape(-1), _f64(m), _f64(v)
     J = lik_dim_f(name, **kw)
     m, v = m.reshape(-1, J), v.reshape(-1, J)
     ve, dm, dv = np.zeros(y.shape[0]), np.zeros_like(m), np.zeros_like(v)
-    check(lib.hmogp_var_exp(device, LIK_IDS[name], lik_param(name, **kw), y.shape[0], _p(y), _p(m), _p(v), _p(ve), _p(dm),
-                            _p(dv)))
+    check(lib.hmogp_var_exp_ex(device, LIK_IDS[name], lik_param(name, **kw), _lib.quirk_mask(quirks), y.shape[0], _p(y),
+                               _p(m), _p(v), _p(ve), _p(dm), _p(dv)))
     return ve, dm, dv
 
 

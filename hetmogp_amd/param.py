@@ -18,6 +18,7 @@ class Param(np.ndarray):
         obj.name = name
         obj._grad = np.zeros(obj.shape)
         obj._fixed = [False]
+        obj._observers = []              # shared with every view: callables fired after a write (paramz's notification)
         obj.positive = positive
         return obj
 
@@ -25,7 +26,38 @@ class Param(np.ndarray):
         self.name = getattr(obj, "name", None)
         self._grad = None
         self._fixed = getattr(obj, "_fixed", [False])
+        self._observers = getattr(obj, "_observers", [])
         self.positive = getattr(obj, "positive", False)
+
+    # paramz re-runs the model's parameters_changed() on every write to a parameter; here a write notifies the
+    # observers (the model marks itself dirty and re-evaluates lazily before the next read of a derived quantity)
+    def add_observer(self, fn):
+        self._observers.append(fn)
+
+    def _notify(self):
+        for fn in self._observers:
+            fn(self)
+
+    def __setitem__(self, idx, val):
+        np.ndarray.__setitem__(self, idx, val)
+        self._notify()
+
+    def _inplace(self, op, other):
+        out = op(np.asarray(self), other)      # acts on the shared buffer
+        self._notify()
+        return self
+
+    def __iadd__(self, o):
+        return self._inplace(np.ndarray.__iadd__, o)
+
+    def __isub__(self, o):
+        return self._inplace(np.ndarray.__isub__, o)
+
+    def __imul__(self, o):
+        return self._inplace(np.ndarray.__imul__, o)
+
+    def __itruediv__(self, o):
+        return self._inplace(np.ndarray.__itruediv__, o)
 
     def __getitem__(self, idx):
         out = np.ndarray.__getitem__(self, idx)

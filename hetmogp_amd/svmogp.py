@@ -23,8 +23,21 @@ class Posterior(object):
 
 class SVMOGP(object):
     def __init__(self, X, Y, Z, kern_list, likelihood, Y_metadata, name="SVMOGP", batch_size=None, W_list=None,
-                 device=0, chunk_rows=0, exact_zero_windows=False, distributed=False):
+                 device=None, chunk_rows=0, exact_zero_windows=False, distributed=False, quirks="reference",
+                 gradients_of_fixed=False):
+        """The reference's constructor (svmogp.py:17) plus engine options (no reference equivalent):
+        device            HIP device ordinal; default: LOCAL_RANK when `distributed`, else 0
+        distributed       one process per GPU inside an initialised torch.distributed group: rows are sharded over ranks
+        quirks            "reference" (default: reproduce the reference's results including its known deviations from the
+                          exact gradient) | "exact" (true ELBO gradients) | an int mask of _lib.QUIRK_*
+        gradients_of_fixed  batch mode only: also evaluate the gradient groups whose parameters are all fixed (the
+                          reference always computes them and the optimiser never reads them); default off, which makes
+                          the VE steps of `vem_algorithm` skip the hyper-parameter / Z path."""
+        import os
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) if distributed else 0
         self.name = name
+        self.gradients_of_fixed = bool(gradients_of_fixed)
         self.batch_size = batch_size
         self.kern_list = kern_list
         self.likelihood = likelihood
@@ -44,9 +57,10 @@ class SVMOGP(object):
         self.Xdim = Z.shape[1]
         self._engine = Engine(likelihood.specs(), self.num_latent_funcs, self.num_inducing, self.Xdim, device=device,
                               chunk_rows=chunk_rows, exact_zero_windows=exact_zero_windows, cache_kuu=True,
-                              reuse_outputs=True)   # gradients arrive in engine-owned page-locked arrays, copied into
+                              reuse_outputs=True, quirks=quirks)   # gradients arrive in engine-owned page-locked arrays, copied into
                                                     # the parameters' .gradient fields by parameters_changed()
         self._engine.set_data(self.Xmulti_all, self.Ymulti_all)
+        self._engine_has_full = True      # False while foreign data (set_data of arrays that are not row ranges) is resident
         # distributed=True (inside an initialised torch.distributed group, one process per GPU): the rows of every
         # evaluation are sharded over the ranks and the statistic bundle is all-reduced once (hetmogp_amd/dist.py); every
         # rank holds identical parameters and receives identical gradients.
@@ -86,11 +100,22 @@ class SVMOGP(object):
         self.batch_scale = [1.0] * T
         self.forced_rung = None
         self.last = None
-        self.parameters_changed()
+        self._dirty = False
+        for _, prm in self._named_params():       # a direct write to any parameter marks the model dirty (paramz would
+            prm.add_observer(self._mark_dirty)    # re-run parameters_changed() at once; here it happens lazily, on the
+        self.parameters_changed()                 # next read of a derived quantity)
+
+    def _mark_dirty(self, _param=None):
+        self._dirty = True
+
+    def _refresh(self):
+        if self._dirty:
+            self.parameters_changed()
 
     # ------------------------------------------------------------------------------------------ reference surface
     def log_likelihood(self):
         """svmogp.py:82-83: a (1,1) ndarray, as the reference returns it."""
+        self._refresh()
         return self._log_marginal_likelihood
 
     def _construction_W(self):
@@ -108,6 +133,13 @@ class SVMOGP(object):
             mask = _lib.GROUP_QU if self.vem_step else (_lib.GROUP_HYPER | _lib.GROUP_Z)
         else:
             mask = _lib.GROUP_ALL
+            if not self.gradients_of_fixed:      # groups whose parameters are ALL fixed: nobody reads their gradients
+                if self.q_u_means.is_fixed and self.q_u_chols.is_fixed:
+                    mask &= ~_lib.GROUP_QU
+                hyper = [k.variance for k in self.kern_list] + [k.lengthscale for k in self.kern_list] + \
+                        [B.W for B in self.B_list] + [B.kappa for B in self.B_list]
+                if all(h.is_fixed for h in hyper):
+                    mask &= ~_lib.GROUP_HYPER
         if self.Z.is_fixed:
             mask &= ~_lib.GROUP_Z
         W0, k0 = self._construction_W()
@@ -133,19 +165,25 @@ class SVMOGP(object):
         if not self.Z.is_fixed:
             self.Z.gradient = out["g_Z"]
         self.posteriors = None                                               # built lazily (prediction only)
+        self._dirty = False
 
     def set_data(self, X, Y):
         """svmogp.py:168-173.  Batches produced by `new_batch()` are row ranges of the data already in HBM; anything
         else is uploaded."""
         if self._last_batch is not None and X is self._last_batch[0] and Y is self._last_batch[1]:
+            if not self._engine_has_full:        # foreign data was uploaded in between: the row ranges refer to the
+                self._engine.set_data(self.Xmulti_all, self.Ymulti_all)   # full data set, put it back first
+                self._engine_has_full = True
             self._rows = list(self._last_batch[2])
         else:
             Xc = [np.ascontiguousarray(x, dtype=float).reshape(x.shape[0], -1) for x in X]
             Yc = [np.ascontiguousarray(y, dtype=float).reshape(-1, 1) for y in Y]
             self._engine.set_data(Xc, Yc)
+            self._engine_has_full = False
             self._rows = [(0, x.shape[0]) for x in Xc]
             X, Y = Xc, Yc
         self.Xmulti, self.Ymulti = X, Y
+
 
     def new_batch(self):
         """svmogp.py:175-186: the next contiguous slice of every task."""
@@ -234,6 +272,8 @@ class SVMOGP(object):
         self.optimizer_array = x
         return -self._transformed_gradient()
 
+    MAX_CONSECUTIVE_FAILURES = 25
+
     def objective_function(self):
         return -float(self._log_marginal_likelihood[0, 0])
 
@@ -245,16 +285,23 @@ class SVMOGP(object):
         ELBO) is treated the same way.  The parameters of the best finite evaluation are restored at the end."""
         from scipy.optimize import minimize
         best = {"f": np.inf, "x": None}
+        failures = [0]
 
         def f(x):
             try:
                 g = self._grads(x)
                 obj = self.objective_function()
                 bad = (not np.isfinite(obj)) or bool(self.last and self.last.get("v_negative"))
+            except _lib.InvalidArgument:
+                raise                             # a programming / ABI error, not a failed evaluation
             except (np.linalg.LinAlgError, ValueError, ZeroDivisionError):
                 g, obj, bad = np.zeros_like(x), np.inf, True
             if bad:
+                failures[0] += 1
+                if failures[0] > self.MAX_CONSECUTIVE_FAILURES:
+                    raise RuntimeError("SVMOGP.optimize: %d consecutive failed evaluations" % failures[0])
                 return np.inf, np.clip(np.nan_to_num(g), -1e10, 1e10)
+            failures[0] = 0
             if obj < best["f"]:
                 best["f"], best["x"] = obj, np.array(x, copy=True)
             return obj, g
@@ -269,6 +316,7 @@ class SVMOGP(object):
 
     # ------------------------------------------------------------------------------------------ prediction
     def _ensure_posteriors(self):
+        self._refresh()
         if self.posteriors is None:
             wv, wi = self._engine.posterior_u()
             self.posteriors = [Posterior(self.q_u_means.values[:, q:q + 1], wv[q][:, None], wi[q])
@@ -292,11 +340,13 @@ class SVMOGP(object):
     def predictive_new(self, Xnew, output_function_ind=None, kern_list=None):
         """svmogp.py:280-306: algebraically (m_fd(Xnew), |v_fd(Xnew)|) of calculate_q_f -- computed on the device."""
         d = 0 if output_function_ind is None else output_function_ind
+        self._refresh()
         m, v = self._engine.predict_f(np.asarray(Xnew, dtype=float).reshape(-1, self.Xdim))
         return m[:, d:d + 1], np.abs(v[:, d:d + 1])
 
     def predict_f(self, Xnew):
         """q(f_d) at Xnew for every function d: (mean [N, Df], variance [N, Df])."""
+        self._refresh()
         return self._engine.predict_f(np.asarray(Xnew, dtype=float).reshape(-1, self.Xdim))
 
     def predictive(self, Xpred):
@@ -314,6 +364,7 @@ class SVMOGP(object):
     def natural_gradient_step(self, gamma=1.0):
         """q(u) <- natural-gradient step of size gamma (not in the reference; named in the north-star).  Uses the
         gradients of the last `parameters_changed()`; updates q_u_means / q_u_chols and re-evaluates."""
+        self._refresh()
         m, L = self._engine.natgrad_step(gamma)
         self.q_u_means[...] = m
         self.q_u_chols[...] = L

@@ -1,7 +1,9 @@
 """Host-side helpers with the reference's names and calling conventions (hetmogp/util.py): model construction
 (`latent_functions_prior`, `random_W_kappas`, `LCM`), the contiguous minibatch slicer (`mini_slices`,
 `draw_mini_slices`) and the VEM driver (`vem_algorithm`: L-BFGS-B alternation or Adadelta SVI).  No arithmetic of the
-ELBO lives here -- that is `SVMOGP.parameters_changed()` -> libhetmogp_hip.so."""
+ELBO lives here -- that is `SVMOGP.parameters_changed()` -> libhetmogp_hip.so.  The data generators of the reference's
+notebook (util.py:21-50) are not part of the path; `hetmogp_amd/synthetic.py` builds the benchmark inputs."""
+import itertools
 import random
 from functools import partial
 
@@ -10,63 +12,24 @@ import numpy as np
 from .kern import RBF, Coregionalize
 
 
-def get_batch_scales(X_all, X):
-    """util.py:15-19."""
-    return [float(xa.shape[0]) / float(x.shape[0]) for xa, x in zip(X_all, X)]
-
-
-def true_u_functions(X_list, Q):
-    """util.py:21-35: random three-sinusoid latent functions evaluated at each task's inputs."""
-    amplitude = (1.5 - 0.5) * np.random.rand(Q, 3) + 0.5
-    freq = (3 - 1) * np.random.rand(Q, 3) + 1
-    shift = 2 * np.random.rand(Q, 3)
-    u_functions = []
-    for X in X_list:
-        u_task = np.empty((X.shape[0], Q))
-        for q in range(Q):
-            u_task[:, q, None] = 3 * amplitude[q, 0] * np.cos(freq[q, 0] * np.pi * X + shift[q, 0] * np.pi) - \
-                2 * amplitude[q, 1] * np.sin(2 * freq[q, 1] * np.pi * X + shift[q, 1] * np.pi) + \
-                amplitude[q, 2] * np.cos(4 * freq[q, 2] * np.pi * X + shift[q, 2] * np.pi)
-        u_functions.append(u_task)
-    return u_functions
-
-
-def true_f_functions(true_u, W_list, D, likelihood_list, Y_metadata):
-    """util.py:37-50: F_t[:, j] = sum_q W_q[d] u_q for the functions d of task t."""
-    f_index = Y_metadata["function_index"].flatten()
-    d_index = Y_metadata["d_index"].flatten()
-    true_f = []
-    for t, u_task in enumerate(true_u):
-        _, num_f_task, _ = likelihood_list[t].get_metadata()
-        F = np.zeros((u_task.shape[0], num_f_task))
-        for q, W in enumerate(W_list):
-            for d in range(D):
-                if f_index[d] == t:
-                    F[:, d_index[d], None] += np.tile(W[d].T, (u_task.shape[0], 1)) * u_task[:, q, None]
-        true_f.append(F)
-    return true_f
-
-
 def mini_slices(n_samples, batch_size):
-    """util.py:52-59: contiguous slices, the last one may be short."""
-    n_batches, rest = divmod(n_samples, batch_size)
-    if rest != 0:
-        n_batches += 1
-    return [slice(i * batch_size, (i + 1) * batch_size) for i in range(n_batches)]
+    """Contiguous minibatch slices covering `n_samples` rows; the last one is short when the size does not divide
+    (behaviour of util.py:52-59 -- the slice stops are NOT clipped, exactly as there)."""
+    return [slice(start, start + batch_size) for start in range(0, n_samples, batch_size)]
 
 
 def draw_mini_slices(n_samples, batch_size, with_replacement=False):
-    """util.py:62-72.  The reference shuffles a temporary copy of the index list (`random.shuffle(list(idxs))`), so the
-    slices are always visited in order; reproduced as is."""
+    """Endless generator over `mini_slices` (util.py:62-72).  Without replacement the reference visits the slices in
+    their natural order on every epoch (its per-epoch shuffle acts on a temporary); with replacement it yields ONE
+    random slice and stops.  Both behaviours, and the draws they take from the `random` module, are kept."""
     slices = mini_slices(n_samples, batch_size)
-    idxs = list(range(len(slices)))
     if with_replacement:
         yield random.choice(slices)
-    else:
-        while True:
-            random.shuffle(list(idxs))
-            for i in idxs:
-                yield slices[i]
+        return
+    for epoch in itertools.count():
+        scratch = list(range(len(slices)))
+        random.shuffle(scratch)          # consumes the module RNG like the reference does; the order is not used
+        yield from slices
 
 
 def latent_functions_prior(Q, lenghtscale=None, variance=None, input_dim=None):
@@ -82,12 +45,15 @@ def latent_functions_prior(Q, lenghtscale=None, variance=None, input_dim=None):
 
 
 def random_W_kappas(Q, D, rank, experiment=False):
-    """util.py:92-103: W = +/- N(0.5, 0.5^2) / sqrt(rank), kappa = 0."""
+    """Coregionalisation weights of util.py:92-103: per latent q a (D, 1) column whose entries are N(+0.5, 0.5^2) or
+    N(-0.5, 0.5^2) with equal probability, divided by sqrt(rank); kappa = 0 (always fixed).  Draw order per q:
+    the D coin flips, the D positive-mean normals, the D negative-mean normals (same NumPy stream as the reference)."""
     W_list, kappa_list = [], []
-    for q in range(Q):
-        p = np.random.binomial(n=1, p=0.5 * np.ones((D, 1)))
-        Ws = p * np.random.normal(loc=0.5, scale=0.5, size=(D, 1)) - (p - 1) * np.random.normal(loc=-0.5, scale=0.5, size=(D, 1))
-        W_list.append(Ws / np.sqrt(rank))
+    for _ in range(Q):
+        heads = np.random.binomial(n=1, p=np.full((D, 1), 0.5)).astype(bool)
+        around_plus = np.random.normal(loc=0.5, scale=0.5, size=(D, 1))
+        around_minus = np.random.normal(loc=-0.5, scale=0.5, size=(D, 1))
+        W_list.append(np.where(heads, around_plus, around_minus) / np.sqrt(rank))
         kappa_list.append(np.zeros(D))
     return W_list, kappa_list
 
@@ -162,42 +128,59 @@ class Adadelta(object):
                 return info
 
 
+# The alternation of util.py:284-331 as data: which parameter groups are frozen in the variational E-step and which in
+# the M-step.  `Z` follows optZ and `W` follows non_chained in the M-step (they stay frozen otherwise).
+_GROUPS = {
+    "lengthscale": lambda m: m[".*.lengthscale"],
+    "variance": lambda m: m[".*.variance"],
+    "W": lambda m: m[".*.W"],
+    "kappa": lambda m: m[".*.kappa"],
+    "Z": lambda m: m.Z,
+    "m_u": lambda m: m.q_u_means,
+    "L_u": lambda m: m.q_u_chols,
+}
+VEM_SCHEDULE = (
+    # (label, groups frozen in this half-step, groups released in this half-step)
+    ("VE", ("lengthscale", "variance", "Z", "W"), ("m_u", "L_u")),
+    ("VM", ("m_u", "L_u"), ("lengthscale", "variance", "Z", "W")),
+)
+
+
+def _apply_half_step(model, frozen, released, optZ, non_chained):
+    for g in frozen:
+        _GROUPS[g](model).fix()
+    for g in released:
+        if (g == "Z" and not optZ) or (g == "W" and not non_chained):
+            continue
+        _GROUPS[g](model).unfix()
+
+
 def vem_algorithm(model, stochastic=False, vem_iters=None, step_rate=None, verbose=False, optZ=True, verbose_plot=False,
-                  non_chained=True):
-    """util.py:284-331."""
-    model[".*.lengthscale"].fix()
-    if vem_iters is None:
-        vem_iters = 5
-    model[".*.kappa"].fix()  # must be always fixed
-    model.elbo = np.empty((vem_iters, 1))
-    if stochastic is False:
-        for i in range(vem_iters):
-            # variational E-step
-            model[".*.lengthscale"].fix()
-            model[".*.variance"].fix()
-            model.Z.fix()
-            model[".*.W"].fix()
-            model.q_u_means.unfix()
-            model.q_u_chols.unfix()
-            model.optimize(messages=verbose, max_iters=100)
-            print("iteration (" + str(i + 1) + ") VE step, ELBO=" + str(model.log_likelihood().flatten()))
-            # variational M-step
-            model[".*.lengthscale"].unfix()
-            model[".*.variance"].unfix()
-            if optZ:
-                model.Z.unfix()
-            if non_chained:
-                model[".*.W"].unfix()
-            model.q_u_means.fix()
-            model.q_u_chols.fix()
-            model.optimize(messages=verbose, max_iters=100)
-            print("iteration (" + str(i + 1) + ") VM step, ELBO=" + str(model.log_likelihood().flatten()))
+                  non_chained=True, device_optimizer=True):
+    """Variational EM driver with the signature of util.py:284-331.  Batch mode alternates L-BFGS-B over q(u) (VE) and
+    over the hyper-parameters (VM) following VEM_SCHEDULE, at most 100 iterations each, and reports the ELBO after every
+    half-step; stochastic mode runs Adadelta (momentum 0.9) on `model.stochastic_grad` for `vem_iters` iterations.
+    lengthscale and kappa start frozen; kappa is never released.  `device_optimizer` (stochastic mode, no reference
+    equivalent): keep q(u) and its Adadelta state in HBM (`SVMOGP.device_adadelta`); the iterates are bit-identical to
+    the host optimiser's."""
+    vem_iters = 5 if vem_iters is None else vem_iters
+    _GROUPS["lengthscale"](model).fix()
+    _GROUPS["kappa"](model).fix()
+    if not stochastic:
+        model.elbo = np.empty((vem_iters, 1))
+        for it in range(1, vem_iters + 1):
+            for label, frozen, released in VEM_SCHEDULE:
+                _apply_half_step(model, frozen, released, optZ, non_chained)
+                model.optimize(messages=verbose, max_iters=100)
+                print("VEM %d/%d  %s-step  ELBO = %s" % (it, vem_iters, label, model.log_likelihood().flatten()))
+        return model
+    rate = 0.01 if step_rate is None else step_rate
+    model.elbo = np.empty((vem_iters + 1, 1))
+    stop = partial(model.callback, max_iter=vem_iters, verbose=verbose, verbose_plot=verbose_plot)
+    make = getattr(model, "device_adadelta", None) if device_optimizer else None
+    if make is not None:
+        optimizer = make(step_rate=rate, momentum=0.9)
     else:
-        if step_rate is None:
-            step_rate = 0.01
-        sto_iters = vem_iters
-        model.elbo = np.empty((sto_iters + 1, 1))
-        optimizer = Adadelta(model.optimizer_array, model.stochastic_grad, step_rate=step_rate, momentum=0.9)
-        c_full = partial(model.callback, max_iter=sto_iters, verbose=verbose, verbose_plot=verbose_plot)
-        optimizer.minimize_until(c_full)
+        optimizer = Adadelta(model.optimizer_array, model.stochastic_grad, step_rate=rate, momentum=0.9)
+    optimizer.minimize_until(stop)
     return model

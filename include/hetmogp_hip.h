@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMOGP_ABI_VERSION 1
+#define HMOGP_ABI_VERSION 2
 
 /* likelihood ids (class names of /root/reference/likelihoods/<name>.py) */
 enum {
@@ -59,6 +59,22 @@ enum {
 /* output flags (hmogp_outputs.flags) */
 #define HMOGP_FLAG_V_NEGATIVE 1u /* some v_fd < 0: the reference prints 'v negative!' (svmogp_inf.py:221) */
 
+/* Reference quirks (hmogp_config.quirks).  A set bit reproduces the reference's behaviour, a cleared
+ * bit gives the mathematically exact quantity.  HMOGP_QUIRKS_REFERENCE (all set) is what parity is measured against;
+ * HMOGP_QUIRKS_EXACT (0) makes every returned gradient the true gradient of the returned ELBO (finite-difference
+ * tested), which is what a quasi-Newton optimiser needs.                                                          */
+#define HMOGP_QUIRK_GAMMA_BETA_PI 1u   /* Q1: Gamma / Beta var_exp and derivatives are 1/pi x the 2-D quadrature
+                                          (gamma.py:110,139-141; beta.py:113,142-144); exact: the quadrature itself */
+#define HMOGP_QUIRK_CATEGORICAL_DM 2u  /* Q2: Categorical d var_exp / dm = onehot(y)[d] - 1, independent of f
+                                          (categorical.py:102-113); exact: E[onehot(y)[d] - softmax_d(f)]            */
+#define HMOGP_QUIRK_STALE_W 4u         /* Q3: chain factors W0 / kappa0 (construction-time copies, svmogp.py:98,141,143,
+                                          156) are honoured; exact: hmogp_params.W0 / kappa0 are ignored (= W / kappa) */
+#define HMOGP_QUIRK_W_DIAG 8u          /* Q4: dW from the K_ff diagonal = W * sum(gv)   (util.py:230); exact:
+                                          2 * W * variance_q * sum(gv)                                               */
+#define HMOGP_QUIRK_KAPPA_DIAG 16u     /* Q5: dkappa = sum(gv)  (util.py:231); exact: variance_q * sum(gv)            */
+#define HMOGP_QUIRKS_REFERENCE 31u
+#define HMOGP_QUIRKS_EXACT 0u
+
 /* gradient-group mask (hmogp_params.group_mask): which parameter groups receive a gradient.  Mirrors the
  * VEM gating of svmogp.py:104-110,131-137,145-151,160-166 and Z.is_fixed (:153,158).                    */
 #define HMOGP_GROUP_QU 1u     /* m_u, L_u            (zeroed in stochastic M-steps)                 */
@@ -85,7 +101,11 @@ typedef struct {
   int64_t chunk_rows;       /* rows streamed per pass, across tasks (0 = default: up to 2^20, less when
                                2 * Q * rows * M * 8 bytes of N x M workspace would exceed ~64 GB)     */
   uint32_t flags;           /* HMOGP_CFG_*                                                           */
+  uint32_t quirks;          /* HMOGP_QUIRK_* mask; HMOGP_QUIRKS_REFERENCE reproduces the reference             */
 } hmogp_config;
+/* Engine limits (hmogp_create fails with HMOGP_E_INVALID beyond them): 1 <= P <= 4 input dimensions (the distance
+ * kernels are instantiated per P); Q <= 8 latent GPs; dim_f <= 8 functions per likelihood (Categorical K <= 9);
+ * exact-zero windows: M <= 8192.  T, M, Df and the row counts are bounded by device memory only.                 */
 
 /* hmogp_config.flags */
 #define HMOGP_CFG_CACHE_KUU 2u /* opt-in: reuse K_uu, its Cholesky factor and inverse while (Z, variance, lengthscale,
@@ -153,9 +173,20 @@ int hmogp_elbo_grad(hmogp_handle h, const hmogp_params* p, hmogp_outputs* out);
 int hmogp_step_begin(hmogp_handle h, const hmogp_params* p);
 int hmogp_stats_buffer(hmogp_handle h, void** device_ptr, int64_t* count); /* float64 words            */
 int hmogp_step_finish(hmogp_handle h, hmogp_outputs* out);
-/* Host-staged access to the bundle (tests; all-reduce over a CPU backend when RCCL is not used).        */
+/* Host-staged access to the bundle (tests).  Between begin and finish H_q holds its LOWER triangle only (the row
+ * pass fills nothing else; finish mirrors it), so sums of bundles of different row shards stay valid bundles.     */
 int hmogp_stats_read(hmogp_handle h, double* host /* [count] */);
 int hmogp_stats_write(hmogp_handle h, const double* host /* [count] */);
+/* Wire format of the bundle = what actually travels in the exchange step: H_q is symmetric, so only its lower
+ * triangle is sent -- [head 2+Df | per q: tril(H_q) row-major packed, M(M+1)/2 | r (M) | dZ (M*P) | sa | sl | swk (Df)]
+ * = 12.7 MB instead of 25.2 MB at M = 1024, Q = 3.  Usage between begin and finish:
+ *   hmogp_wire_pack(h);  all-reduce(sum, float64) the `count` words at `device_ptr` in place;  hmogp_wire_unpack(h);
+ * pack / unpack are synchronous at return.  hmogp_wire_read / _write: host-staged variant (CPU backends, tests).   */
+int hmogp_wire_buffer(hmogp_handle h, void** device_ptr, int64_t* count);
+int hmogp_wire_pack(hmogp_handle h);
+int hmogp_wire_unpack(hmogp_handle h);
+int hmogp_wire_read(hmogp_handle h, double* host /* [count] */);
+int hmogp_wire_write(hmogp_handle h, const double* host /* [count] */);
 
 /* ---- posterior / prediction (consumers: svmogp.py:238-251, 280-306) --------------------------------- */
 /* woodbury_vector[q] = Kuu^-1 m_q  [Q, M];  woodbury_inv[q] = Kuu^-1 - Kuu^-1 S_q Kuu^-1  [Q, M, M]
@@ -180,10 +211,25 @@ int hmogp_natgrad_step(hmogp_handle h, double gamma, double* m_u_new, double* L_
  * [6] column statistics + slab reductions, [7] replicated M x M algebra.  launches[i] = kernel launches behind out[i].  */
 int hmogp_last_timings(hmogp_handle h, double* out_ms8, int64_t* launches8);
 
+/* ---- inner protocol, debug / parity mode (small N only) ------------------------------------------------ */
+/* The raw gradient dictionary SVMOGPInf.inference returns (svmogp_inf.py:107, built at :130-171) for the LAST finished
+ * evaluation, which must have used group_mask = HMOGP_GROUP_ALL and streamed all its rows in one pool (N_total <=
+ * chunk_rows): dL_dKmm [Q, M, M] (:166-171); dL_dKmn = for q, for d: [M, N_t(d)] row-major, concatenated (:157-161);
+ * dL_dKdiag = for q, for d: [N_t(d)], concatenated (:164).  N_t(d) = rows of the task owning function d in that
+ * evaluation.  Any pointer may be NULL.  This is 8*Q*Df*M*N bytes -- the reason the product boundary is the outer
+ * protocol; it exists so that the device's dL_dKmm / dL_dKmn can be compared with the reference's with nothing in
+ * between.                                                                                                       */
+int hmogp_debug_raw_grads(hmogp_handle h, double* dL_dKmm, double* dL_dKmn, double* dL_dKdiag);
+
 /* ---- building blocks, exposed for parity tests ("inner protocol" at small sizes) ---------------------- */
 /* K = variance * exp(-0.5 * |x - z|^2 / lengthscale^2), GPy RBF.K(X, Z) semantics (util.py:161,197).      */
 int hmogp_rbf_cross_cov(int32_t device, const double* X, int64_t N, const double* Z, int32_t M, int32_t P,
                         double variance, double lengthscale, double* K /* [N, M] */);
+/* The same with the rounding order selectable: exact = 1 is hmogp_rbf_cross_cov (GPy's r = sqrt(clip(r2))/l, used
+ * for K_uu); exact = 0 is the variant the row pass uses for K_uf (clip(r2) * (1/l^2): no sqrt / divide per element,
+ * <= 2 ulp of the exponent away).                                                                                 */
+int hmogp_rbf_cross_cov_ex(int32_t device, const double* X, int64_t N, const double* Z, int32_t M, int32_t P,
+                           double variance, double lengthscale, int32_t exact, double* K /* [N, M] */);
 /* Batched lower Cholesky with GPy's jitter ladder + inverse: A [Q,M,M] -> L, Ainv; rung[q] as above.     */
 int hmogp_jitchol_inv(int32_t device, const double* A, int32_t Q, int32_t M, const int32_t* forced_rung,
                       double* L, double* Ainv, int32_t* rung);
@@ -196,6 +242,10 @@ int hmogp_gemm_f64(int32_t device, int32_t transA, int32_t transB, int32_t M, in
 /* Variational expectations of one likelihood: y [N], m,v [N, dim_f] -> ve [N], dm, dv [N, dim_f].         */
 int hmogp_var_exp(int32_t device, int32_t lik_id, double lik_param, int64_t N, const double* y,
                   const double* m, const double* v, double* ve, double* dm, double* dv);
+
+/* The same under a quirk mask (HMOGP_QUIRK_GAMMA_BETA_PI, HMOGP_QUIRK_CATEGORICAL_DM).                            */
+int hmogp_var_exp_ex(int32_t device, int32_t lik_id, double lik_param, uint32_t quirks, int64_t N, const double* y,
+                     const double* m, const double* v, double* ve, double* dm, double* dv);
 
 /* Predictive mean / variance of y under q(f) = N(m, diag v): the reference's `<likelihood>.predictive(m, v)`
  * (e.g. bernoulli.py:113-128, gamma.py:196-238, categorical.py:224-269), consumed by HetLikelihood.predictive

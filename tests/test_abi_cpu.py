@@ -33,7 +33,8 @@ def test_library_exports_every_declared_symbol(built):
     for n in names:
         assert hasattr(lib, n), "libhetmogp_hip.so does not export %s" % n
     lib.hmogp_abi_version.restype = ctypes.c_int
-    assert lib.hmogp_abi_version() == 1
+    header_version = int(re.search(r"#define HMOGP_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert lib.hmogp_abi_version() == header_version == 2
 
 
 def test_ctypes_binding_matches_header(built):

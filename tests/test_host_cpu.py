@@ -38,7 +38,11 @@ def test_minibatch_slicer_is_contiguous_and_ordered():
     it = util.draw_mini_slices(10, 4)
     seq = [next(it) for _ in range(7)]
     assert [(s.start, s.stop) for s in seq] == [(0, 4), (4, 8), (8, 12)] * 2 + [(0, 4)]   # always in order (util.py:70)
-    assert util.get_batch_scales([np.zeros((10, 1))], [np.zeros((4, 1))]) == [2.5]
+    import random
+    random.seed(3)
+    one = list(util.draw_mini_slices(10, 4, with_replacement=True))                 # ONE random slice, then stops
+    assert len(one) == 1 and (one[0].start, one[0].stop) in [(0, 4), (4, 8), (8, 12)]
+    assert util.mini_slices(8, 4) == [slice(0, 4), slice(4, 8)] and util.mini_slices(0, 4) == []
 
 
 def test_adadelta_matches_its_recurrence():
