@@ -45,6 +45,26 @@ class _StdoutToStderr(object):
         os.close(self._saved)
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _self_launch(ngpus):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: re-execute under torch.distributed.run,
+    one rank per GPU (the driver may also launch the ranks itself, in which case RANK is set and this is skipped)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,10 +73,14 @@ def main():
     ap.add_argument("--rows", type=int, default=200000, help="rows per task (headline: 200000)")
     ap.add_argument("--inducing", type=int, default=1024, help="M (headline: 1024)")
     ap.add_argument("--latents", type=int, default=3, help="Q (headline: 3)")
-    ap.add_argument("--cpu-sample-rows", type=int, default=4000, help="rows per task of the CPU-baseline sample")
+    ap.add_argument("--cpu-sample-rows", type=int, default=3000, help="rows per task of the larger CPU-baseline sample")
+    ap.add_argument("--cpu-literal-budget", type=float, default=45.0, help="seconds the literal-reference baseline may use")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-zero-pass", action="store_true", help="skip the extra (untimed-for-value) opt-in mode pass")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(_self_launch(args.gpus))
 
     import numpy as np
     import torch
@@ -66,15 +90,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but only %d device(s) visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     guard = _StdoutToStderr()
     guard.__enter__()
+    rccl_ranks = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        ones = torch.ones(1, dtype=torch.float64, device="cuda")
+        dist.all_reduce(ones)                                   # proof that RCCL connected every rank
+        rccl_ranks = int(round(float(ones.item())))
+        if rccl_ranks != world:
+            raise SystemExit("bench.py: RCCL all-reduce saw %d ranks, expected %d" % (rccl_ranks, world))
 
     from hetmogp_amd.engine import Engine
     from hetmogp_amd.synthetic import make_case
@@ -83,19 +115,21 @@ def main():
     N, M, Q, P, T = args.rows, args.inducing, args.latents, 1, len(SPECS)
     prm, X, Y = make_case(SPECS, [N] * T, M=M, Q=Q, P=P, seed=20260929)
     eng = Engine(SPECS, Q, M, P, device=local_rank, reuse_outputs=True)   # gradients land in page-locked arrays
-    eng.set_data(X, Y)                      # every rank holds the (tiny) raw data; it only touches its own rows
+    # strong scaling: the rows of every task are split into one contiguous range per rank; a rank uploads ONLY its rows
+    rb, re = hdist.shard_ranges([0] * T, [N] * T, rank, world)
+    eng.set_data([x[b:e] for x, b, e in zip(X, rb, re)], [y[b:e] for y, b, e in zip(Y, rb, re)])
+    rows_rank = sum(e - b for b, e in zip(rb, re))              # rows this rank streams per step (all tasks)
     from hetmogp_amd.engine import pinned_empty
     for k in ("Z", "m_u", "L_flat"):        # the optimiser's parameter vectors live in page-locked host memory: H2D by DMA
         a = pinned_empty(np.shape(prm[k]))
         a[...] = prm[k]
         prm[k] = a
     reducer = hdist.StatsReducer(eng, device=local_rank) if world > 1 else None
-    rb, re = hdist.shard_ranges([0] * T, [N] * T, rank, world)
 
     def step():
         if world == 1:
             return eng.elbo_grad(**prm)
-        eng.step_begin(row_begin=rb, row_end=re, **prm)
+        eng.step_begin(**prm)
         reducer()
         return eng.step_finish()
 
@@ -108,28 +142,33 @@ def main():
         out = step()
     fence()
     guard.__exit__()
+    if reducer is not None:
+        reducer.total_ms, reducer.n_calls = 0.0, 0
     t0 = time.perf_counter()
     cat_ms, cat_n = {}, {}
     for _ in range(args.steps):
         out = step()
-        ms, nl = eng.timings()              # HIP-event spans on the engine's stream, per kernel family
+        ms, nl = eng.timings()              # HIP-event spans on the engine's streams, per kernel family
         for k in ms:
             cat_ms[k] = cat_ms.get(k, 0.0) + ms[k]
             cat_n[k] = cat_n.get(k, 0) + nl[k]
     fence()
     elapsed = time.perf_counter() - t0
+    rows_all = [rows_rank]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        gathered = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([float(rows_rank)], dtype=torch.float64, device="cuda"))
+        rows_all = [int(g.item()) for g in gathered]
     if not np.isfinite(out["elbo"]):
         raise SystemExit("bench.py: non-finite ELBO")
 
     if rank == 0:
-        rows_rank = sum(e - b for b, e in zip(rb, re))          # rows this rank streamed per step (all tasks)
-        pairs_rows = rows_rank * Q                               # (row, latent) pairs per step
-        # dominant kernel: forward contraction; one launch = all Q latents of one task chunk = 2*n*M*M*Q algorithmic
-        # flops; the category holds exactly that kernel, so cat_ms / launches = its average duration
+        pairs_rows = rows_rank * Q                               # (row, latent) pairs per step on this rank
+        # dominant kernel: forward contraction; one launch = all Q latents of one pool = 2*n*M*M*Q algorithmic flops
+        # (DESIGN.md 5); the category holds exactly that kernel, so cat_ms / launches = its average duration
         fwd_flops = 2.0 * pairs_rows * M * M * args.steps
         fwd_s = cat_ms["forward_gemm"] / 1e3
         achieved = fwd_flops / fwd_s / 1e12 if fwd_s > 0 else 0.0
@@ -137,10 +176,12 @@ def main():
         kuf_s = cat_ms["rbf_cross_cov"] / 1e3
         kuf_gbs = kuf_bytes / kuf_s / 1e9 if kuf_s > 0 else 0.0
         gram_flops = 1.0 * pairs_rows * M * M * args.steps       # lower-triangular weighted Gram: n*M*M
-        traffic = None
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_forward_gemm.json")
         if os.path.exists(pmc) and (N, M, Q) == (200000, 1024, 3) and world == 1:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            rec = json.load(open(pmc))
+            traffic, traffic_src = rec.get("hbm_bytes_per_launch"), rec.get("source")
+        exec_flops = 3.0 * rows_rank * Q * M * M                # executed by the two contractions (forward 2nM^2 + Gram nM^2)
         line = {
             "metric": "ELBO-steps/sec (one step = ELBO + all parameter gradients)",
             "value": args.steps / elapsed,
@@ -159,23 +200,34 @@ def main():
                        "rows_per_task": N, "M": M, "Q": Q, "T": T, "sharding": "rows/%d" % world},
             "roofline": {"kernel": "gemm_f64_kernel<false, true, 1> (forward P~ = K^ C_q + fused row statistics)", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": cat_n["forward_gemm"], "avg_launch_ms": cat_ms["forward_gemm"] / max(cat_n["forward_gemm"], 1)},
             "roofline_kuf": {"kernel": "rbf_kernel<1, false> (K_uf construction)", "bound": "hbm", "achieved": kuf_gbs,
                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": kuf_gbs / PEAK_HBM_GBS, "traffic": None,
                              "launches": cat_n["rbf_cross_cov"],
                              "avg_launch_ms": cat_ms["rbf_cross_cov"] / max(cat_n["rbf_cross_cov"], 1)},
+            # the whole step against the FP64-MFMA peak on EXECUTED contraction flops (3 n M^2 per (row, latent) pair: the
+            # Gram only forms lower tiles), this rank's share
+            "step_tflops_executed": exec_flops / (elapsed / args.steps) / 1e12,
+            "step_frac_of_peak_executed": exec_flops / (elapsed / args.steps) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
             "kernel_ms_per_step": {k: v / args.steps for k, v in cat_ms.items()},
             # the weighted Gram shares the device with the HBM-bound column statistics (second stream): its span is longer
             # than when it runs alone, and gram_gemm + colstats_reduce overlap (they do not add up to the wall time)
             "gram_tflops": gram_flops / (cat_ms["gram_gemm"] / 1e3) / 1e12 if cat_ms["gram_gemm"] > 0 else 0.0,
+            "replicated_ms": cat_ms["mxm_algebra"] / args.steps,  # M x M algebra every rank repeats (the Amdahl term)
+            "rccl_ranks": rccl_ranks,
+            "rows_per_rank": rows_all,
             "elbo": out["elbo"],
         }
+        if reducer is not None:
+            line["allreduce_ms_per_step"] = reducer.total_ms / max(reducer.n_calls, 1)
+            line["allreduce_bytes"] = 8 * int(reducer.tensor.numel())
         if world == 1 and not args.no_exact_zero_pass:
             line["exact_zero_windows"] = exact_zero_pass(args, prm, X, Y, N, M, Q, P, out)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args, prm, X, Y, N, M, Q, P)
+            line.update(cpu_baselines(args, eng, prm, X, Y, N, M, Q, P))
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -211,27 +263,134 @@ def exact_zero_pass(args, prm, X, Y, N, M, Q, P, dense_out):
             "note": "opt-in mode; bit-for-bit the same terms minus products with exact 0.0; not used for `value`"}
 
 
-def cpu_baseline(args, prm, X, Y, N, M, Q, P):
-    """The oracle's fused restatement (same algebra and flop count as the GPU path: NumPy + multithreaded BLAS, fp64) on
-    the first `cpu_sample_rows` rows of every task; steps/s is scaled linearly to the full row count (the M^3 part,
-    which does not shrink with the sample, is charged in full -- conservative in the CPU's favour for value)."""
+def _blas_info():
+    try:
+        from threadpoolctl import threadpool_info
+        info = [i for i in threadpool_info() if i.get("user_api") == "blas"]
+        if info:
+            return info[0].get("internal_api", "?") + " " + str(info[0].get("version", "")), int(info[0].get("num_threads", 0))
+    except Exception:
+        pass
+    return "unknown", 0
+
+
+def _median_time(fn, reps):
+    import statistics
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return statistics.median(ts), ts
+
+
+def cpu_baselines(args, eng, prm, X, Y, N, M, Q, P):
+    """CPU legs, on this host's cores, same inputs (oracle/ is the checker and the baseline, never the product):
+
+    cpu_baseline          baseline B of BASELINE.md 4 ("port"): the oracle's fused restatement -- the same algebra and flop
+        count as the GPU path, NumPy + multithreaded BLAS -- timed at TWO row samples (median of 5 steps each).  The cost
+        splits into a part that does not depend on the rows (M x M algebra: fixed_s) and a part linear in them
+        (per_row_s); only the latter is extrapolated to the full row count.
+    parity_at_headline_M  max relative error (ELBO and the 7 gradient arrays) between the oracle on the larger sample and
+        the engine on the same rows, at the headline M / Q / likelihood mix; the bench fails above 1e-5.
+    cpu_baseline_literal  baseline A ("the reference CPU path"): the literal restatement with the N x N terms
+        (oracle.inference_literal(full_cov=True) + assemble_literal) at C1 in full and at the largest N_t <= 8192 of the
+        headline mix that fits the time budget."""
     import numpy as np
     from oracle import svmogp_oracle as so
-    ns = min(args.cpu_sample_rows, N)
+    T = len(SPECS)
+    blas, threads = _blas_info()
     prob = so.make_problem(SPECS, Q, M, P)
-    Xs, Ys = [x[:ns] for x in X], [y[:ns] for y in Y]
-    so.elbo_grad_fused(prm, prob, Xs, Ys)                       # warm-up (BLAS thread pool, page faults)
-    times = []
-    for _ in range(2):
+    ns2 = min(args.cpu_sample_rows, N)
+    ns1 = max(1, ns2 // 3)
+
+    # NumPy's element-wise passes over the N x M blocks are single-threaded; to give the CPU all of its cores the rows are
+    # cut into shards evaluated by a thread pool (NumPy and BLAS release the GIL; the statistic bundle is additive over
+    # row shards -- the same property the multi-GPU path uses), each worker with its share of the BLAS threads.
+    from concurrent.futures import ThreadPoolExecutor
+    from threadpoolctl import threadpool_limits
+    ncpu = os.cpu_count() or 1
+    workers = max(1, min(64, ncpu // 2))
+    blas_per_worker = max(1, ncpu // workers)
+    pool = ThreadPoolExecutor(max_workers=workers)
+
+    def run_b(ns):
+        u = so.u_algebra(prm, prob)                               # replicated M x M algebra: all BLAS threads
+        nsh = max(1, min(workers, ns // 64))
+        cuts = [(ns * i) // nsh for i in range(nsh + 1)]
+
+        def shard(i):
+            return so.local_stats(prm, prob, u, [x[cuts[i]:cuts[i + 1]] for x in X], [y[cuts[i]:cuts[i + 1]] for y in Y])[0]
+        with threadpool_limits(limits=blas_per_worker, user_api="blas"):
+            parts = list(pool.map(shard, range(nsh)))
+        total = parts[0]
+        for part in parts[1:]:
+            total = total + part
+        return so.finish(prm, prob, u, total)
+
+    run_b(ns1)                                                    # warm-up (BLAS thread pool, page faults)
+    t1, _ = _median_time(lambda: run_b(ns1), 5)
+    t2, ts2 = _median_time(lambda: run_b(ns2), 5)
+    per_row = max((t2 - t1) / (T * (ns2 - ns1)), 0.0) if ns2 > ns1 else t2 / (T * ns2)
+    fixed = max(t1 - per_row * T * ns1, 0.0)
+    full = fixed + per_row * T * N
+    flops_sample = 3.0 * T * ns2 * Q * M * M + 20.0 * Q * M ** 3
+    res = {"cpu_baseline": {
+        "value": 1.0 / full, "unit": "steps/s", "cores": min(ncpu, workers * blas_per_worker), "host_cores": ncpu, "kind": "port",
+        "blas": blas, "threads": threads, "row_shard_workers": workers, "blas_threads_per_worker": blas_per_worker,
+        "gflops": flops_sample / t2 / 1e9, "fixed_s": fixed, "per_row_s": per_row, "reps": 5,
+        "sample": "baseline B: oracle.svmogp_oracle u_algebra + local_stats + finish (NumPy + %s, fp64; rows sharded over %d "
+                  "worker threads x %d BLAS threads) on the first %d and %d of %d rows of each of the %d tasks, M=%d, Q=%d: "
+                  "median of 5 steps = %.2f s and %.2f s -> %.3f s independent of the rows + %.3e s per row; full step = "
+                  "fixed + per_row * %d rows" % (blas, workers, blas_per_worker, ns1, ns2, N, T, M, Q, t1, t2, fixed, per_row,
+                                                 T * N),
+        "sample_seconds_per_step": t2}}
+    # ---- parity at the headline M: the engine on exactly the sampled rows vs the oracle ------------------------------
+    # (the engine of a 1-GPU run holds all rows; row_end restricts the evaluation to the sample)
+    want = run_b(ns2)
+    got = eng.elbo_grad(row_end=[ns2] * T, **prm)
+    worst, worst_key = 0.0, None
+    for k in ("elbo", "g_m_u", "g_L_u", "g_variance", "g_lengthscale", "g_W", "g_kappa", "g_Z"):
+        a, b = np.asarray(got[k], float), np.asarray(want[k], float)
+        err = float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300))
+        if err > worst:
+            worst, worst_key = err, k
+    res["parity_at_headline_M"] = {"max_rel_err": worst, "worst": worst_key, "rows_per_task": ns2, "M": M, "Q": Q,
+                                   "tolerance": 1e-5}
+    if not (worst <= 1e-5):
+        raise SystemExit("bench.py: engine and oracle disagree at the headline M: %s rel err %.3e" % (worst_key, worst))
+    # ---- baseline A: the literal reference algorithm (N x N terms included) -------------------------------------------
+    lit = {"kind": "port-literal", "cores": os.cpu_count(), "blas": blas, "threads": threads, "runs": []}
+
+    def run_a(specs, prmA, Xa, Ya, Ma, Qa):
+        pa = so.make_problem(specs, Qa, Ma, 1)
+        r = so.inference_literal(prmA, pa, Xa, Ya, full_cov=True)
+        so.assemble_literal(prmA, pa, Xa, r["grads"])
+
+    from hetmogp_amd.synthetic import make_case
+    c1 = [("HetGaussian", {}), ("Bernoulli", {}), ("Categorical", {"K": 3})]
+    p1, X1, Y1 = make_case(c1, [1000] * 3, M=50, Q=2, P=1, seed=20260930)
+    run_a(c1, p1, X1, Y1, 50, 2)
+    tA, _ = _median_time(lambda: run_a(c1, p1, X1, Y1, 50, 2), 3)
+    lit["runs"].append({"config": "C1: T=3 [HetGaussian,Bernoulli,Categorical(3)], N_t=1000, M=50, Q=2", "seconds_per_step": tA,
+                        "reps": 3})
+    budget, spent, nt = float(args.cpu_literal_budget), 0.0, 512
+    while nt <= 8192 and N >= nt:
+        Xa, Ya = [x[:nt] for x in X], [y[:nt] for y in Y]
         t0 = time.perf_counter()
-        so.elbo_grad_fused(prm, prob, Xs, Ys)
-        times.append(time.perf_counter() - t0)
-    t = min(times)
-    return {"value": 1.0 / (t * (float(N) / ns)), "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "oracle.svmogp_oracle.elbo_grad_fused (NumPy+BLAS fp64, all host cores) on the first %d of %d rows of "
-                      "each of the 4 tasks, M=%d, Q=%d: %.2f s per sampled step, scaled by %d/%d to the full step"
-                      % (ns, N, M, Q, t, N, ns),
-            "sample_seconds_per_step": t}
+        run_a(SPECS, prm, Xa, Ya, M, Q)
+        dt = time.perf_counter() - t0
+        spent += dt
+        lit["runs"].append({"config": "headline mix, N_t=%d, M=%d, Q=%d" % (nt, M, Q), "seconds_per_step": dt, "reps": 1})
+        if spent + 4.2 * dt > budget:                      # the next size costs ~4x (O(N^2) terms)
+            break
+        nt *= 2
+    last = lit["runs"][-1]
+    lit["value"] = 1.0 / last["seconds_per_step"]
+    lit["unit"] = "steps/s at the size of the last run (O(N^2): not runnable at the full batch)"
+    res["cpu_baseline_literal"] = lit
+    pool.shutdown()
+    return res
 
 
 if __name__ == "__main__":

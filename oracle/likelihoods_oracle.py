@@ -160,7 +160,7 @@ def beta(y, m, v):
 
 
 # ------------------------------------------------------------------ (K-1)-D quadrature (L8)
-def categorical(y, m, v, K, T=10, chunk=256):
+def categorical(y, m, v, K, T=10, chunk=256, exact_dm=False):
     """categorical.py:37-46,77-82,102-222.  Labels are 1..K (quirk Q7); class K is the reference class."""
     N, D = m.shape
     assert D == K - 1
@@ -196,19 +196,28 @@ def categorical(y, m, v, K, T=10, chunk=256):
             pd = enum.sum(-1) / safe_square(den[..., 0])
             d2 = -valid[s:e, None] * pd
             dv[s:e, d] = 0.5 * (d2 @ Wf)
+            if exact_dm:    # true derivative E[onehot_d - softmax_d] (quirks = "exact"; not the reference)
+                dm[s:e, d] = (valid[s:e, None] * (onehot[s:e, None, d] - eF[:, :, d] / den[..., 0])) @ Wf
+    if exact_dm:
+        return ve, dm, dv
     # quirk Q2: p/p == 1 -> dlogp = onehot_d - sum_k onehot_k, integrated against weights summing to ~1
     dm[:, :] = (onehot[:, :D] - valid[:, None]) * (wsum ** D)
     return ve, dm, dv
 
 
-def var_exp_all(name, y, m, v, **kw):
-    """Dispatch on the reference's class name (het_likelihood.py:101-131 loops these per task)."""
+def var_exp_all(name, y, m, v, exact=False, **kw):
+    """Dispatch on the reference's class name (het_likelihood.py:101-131 loops these per task).  exact=True is NOT the
+    reference: it removes quirk Q1 (the extra 1/pi of Gamma / Beta) and quirk Q2 (Categorical's constant d/dm) so that
+    (dm, dv) are the true derivatives of ve -- the yardstick of the engine's quirks = "exact" mode."""
     if name == "Gaussian":
         return gaussian(y, m, v, kw.get("sigma", 0.5) if kw.get("sigma", None) is not None else 0.5)
     if name == "Categorical":
-        return categorical(y, m, v, kw["K"])
-    return dict(Bernoulli=bernoulli, HetGaussian=hetgaussian, Poisson=poisson, Exponential=exponential, Gamma=gamma,
-                Beta=beta)[name](y, m, v)
+        return categorical(y, m, v, kw["K"], exact_dm=exact)
+    out = dict(Bernoulli=bernoulli, HetGaussian=hetgaussian, Poisson=poisson, Exponential=exponential, Gamma=gamma,
+               Beta=beta)[name](y, m, v)
+    if exact and name in ("Gamma", "Beta"):
+        out = tuple(np.pi * o for o in out)
+    return out
 
 
 # ============================================================================ predictive (SURVEY.md 8f, row f2)

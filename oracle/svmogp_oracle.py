@@ -317,7 +317,8 @@ def local_stats(prm, prob, u, X, Y, batch_scale=None):
     Q, M, P, T, Df = prob["Q"], prob["M"], prob["P"], prob["T"], prob["Df"]
     lay = stats_layout(prob)
     batch_scale = [1.0] * T if batch_scale is None else list(batch_scale)
-    W0 = prm.get("W0", prm["W"])
+    exact = prob.get("quirks", "reference") == "exact"      # not the reference: true gradients (see finish)
+    W0 = prm["W"] if exact else prm.get("W0", prm["W"])
     stats = np.zeros(lay["size"])
     v_neg = False
     for t in range(T):
@@ -345,7 +346,7 @@ def local_stats(prm, prob, u, X, Y, batch_scale=None):
                 vv[:, j] += (w * w + prm["kappa"][q, d]) * prm["variance"][q] + w * w * c[q]
         v_neg |= bool((vv < 0).any())
         name, kw = prob["specs"][t]
-        ve, gm, gv = lo.var_exp_all(name, Y[t], mu, vv, **kw)
+        ve, gm, gv = lo.var_exp_all(name, Y[t], mu, vv, exact=exact, **kw)
         ve, gm, gv = ve * batch_scale[t], gm * batch_scale[t], gv * batch_scale[t]
         stats[0] += ve.sum()
         stats[1] += float((vv < 0).sum())
@@ -375,8 +376,12 @@ def finish(prm, prob, u, stats, stochastic=False, vem_step=True, z_fixed=False):
     """Replicated M x M post-processing of the (all-reduced) statistic bundle -> ELBO + parameter gradients."""
     Q, M, P, Df = prob["Q"], prob["M"], prob["P"], prob["Df"]
     lay = stats_layout(prob)
-    W0 = prm.get("W0", prm["W"])
-    kappa0 = prm.get("kappa0", prm["kappa"])
+    # prob["quirks"] = "exact" (default "reference"): W0 := W (Q3), dW diag term 2 W variance sum(gv) (Q4), dkappa =
+    # variance sum(gv) (Q5), and exact likelihood derivatives in local_stats (Q1, Q2): every gradient is then the true
+    # gradient of the returned ELBO.  The reference mode is what the golden fixtures pin.
+    exact = prob.get("quirks", "reference") == "exact"
+    W0 = prm["W"] if exact else prm.get("W0", prm["W"])
+    kappa0 = prm["kappa"] if exact else prm.get("kappa0", prm["kappa"])
     e_gate = 0.0 if (stochastic and not vem_step) else 1.0
     m_gate = 0.0 if (stochastic and vem_step) else 1.0
     out = dict(g_m_u=np.zeros((M, Q)), g_L_u=np.zeros((M * (M + 1) // 2, Q)), g_variance=np.zeros(Q),
@@ -423,8 +428,12 @@ def finish(prm, prob, u, stats, stochastic=False, vem_step=True, z_fixed=False):
             gZ[:, pp] += np.sum(T2 * (Zq[:, pp][None, :] - Zq[:, pp][:, None]), 1) / ell ** 2
         out["g_variance"][q] = m_gate * gvar
         out["g_lengthscale"][q] = m_gate * gell
-        out["g_W"][q] = m_gate * (prm["W"][q] * sgv + swk)
-        out["g_kappa"][q] = m_gate * sgv
+        if exact:
+            out["g_W"][q] = m_gate * (2.0 * prm["W"][q] * var * sgv + swk)
+            out["g_kappa"][q] = m_gate * var * sgv
+        else:
+            out["g_W"][q] = m_gate * (prm["W"][q] * sgv + swk)          # util.py:230 (quirk Q4) + :252
+            out["g_kappa"][q] = m_gate * sgv                             # util.py:231 (quirk Q5)
         if not z_fixed:
             out["g_Z"][:, q * P:(q + 1) * P] = m_gate * gZ
     out["KL"] = KL

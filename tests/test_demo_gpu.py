@@ -17,6 +17,6 @@ def test_notebook_demo_vem_improves_elbo(capsys):
     assert e1 > e0 + 500.0 and -1500.0 < e1 < -900.0
     assert acc > 0.75
     out = capsys.readouterr().out
-    assert "VE step" in out and "VM step" in out            # util.vem_algorithm prints, like the reference
-    trace = [float(l.split("ELBO=[")[1].rstrip("]\n")) for l in out.splitlines() if "ELBO=[" in l]
+    assert "VE-step" in out and "VM-step" in out            # util.vem_algorithm reports every half-step, like the reference
+    trace = [float(l.split("ELBO = [")[1].rstrip("]\n")) for l in out.splitlines() if "ELBO = [" in l]
     assert len(trace) == 10 and all(b >= a - 1e-6 * abs(a) for a, b in zip(trace, trace[1:]))   # monotone VEM

@@ -42,11 +42,13 @@ def test_bundle_aliases_as_torch_tensor_and_rccl_allreduce():
         red = hd.StatsReducer(e, device=0)
         assert red.mode == "device" and red.tensor.is_cuda and red.tensor.dtype == torch.float64
         e.step_begin(**prm)
-        host = e.stats_read()
+        e.wire_pack()                                                    # lower triangles of H_q -> wire buffer
+        host = e.wire_read()
+        assert red.tensor.numel() == host.size < e.stats_read().size
         assert np.array_equal(red.tensor.cpu().numpy(), host)            # same memory, no copy
         dist.all_reduce(red.tensor)                                      # RCCL on engine-owned HBM (sum over 1 rank)
         torch.cuda.synchronize()
-        assert np.array_equal(e.stats_read(), host)
+        assert np.array_equal(e.wire_read(), host)
         out = hd.sharded_elbo_grad(e, red, 0, 1, **prm)
         for k in ("elbo", "g_m_u", "g_L_u", "g_Z", "g_W"):
             assert np.array_equal(np.asarray(out[k]), np.asarray(full[k])), k   # deterministic reductions: bit-identical
@@ -142,3 +144,81 @@ def test_facade_distributed_rows_match_reference_fixture():
         assert abs(elbo - float(g["elbo"])) < 1e-8 * abs(float(g["elbo"]))
         assert np.max(np.abs(gZ - g["g_Z"])) < 1e-8 * np.max(np.abs(g["g_Z"]))
         assert np.max(np.abs(gL - g["g_L_u"])) < 1e-8 * np.max(np.abs(g["g_L_u"]))
+
+
+# ------------------------------------------------------------------------------------------------ >= 2 GPUs: real RCCL
+def _nccl_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from hetmogp_amd.engine import Engine
+    from hetmogp_amd import dist as hd
+    from test_dist_gpu import _case
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    specs, prm, X, Y = _case()
+    rb, re = hd.shard_ranges([0] * len(X), [x.shape[0] for x in X], rank, world)
+    e = Engine(specs, 3, 64, 1, device=rank)                                  # one GPU per rank
+    e.set_data([x[b:e_] for x, b, e_ in zip(X, rb, re)], [y[b:e_] for y, b, e_ in zip(Y, rb, re)])   # only its rows
+    red = hd.StatsReducer(e, device=rank)
+    assert red.mode == "device" and red.tensor.device.index == rank
+    e.step_begin(**prm)
+    red()
+    out = e.step_finish()
+    ones = torch.ones(1, dtype=torch.float64, device="cuda")
+    dist.all_reduce(ones)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, out["elbo"], out["g_Z"], out["g_L_u"], float(ones.item()), red.last_ms))
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_two_gpus_rccl_match_single_rank():
+    """BASELINE config C4's mechanism on real hardware: one process per GPU, rows sharded, the wire bundle all-reduced by
+    RCCL in place on engine-owned HBM (device-mode StatsReducer).  Skipped on boxes with a single GPU."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (the nccl backend refuses two ranks on one device)")
+    import torch.multiprocessing as mp
+    from hetmogp_amd.engine import Engine
+    specs, prm, X, Y = _case()
+    e = Engine(specs, 3, 64, 1)
+    e.set_data(X, Y)
+    full = e.elbo_grad(**prm)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, elbo, gZ, gL, nranks, ms in res:
+        assert nranks == 2.0
+        assert abs(elbo - full["elbo"]) < 1e-10 * abs(full["elbo"])
+        assert np.max(np.abs(gZ - full["g_Z"])) < 1e-9 * np.max(np.abs(full["g_Z"]))
+        assert np.max(np.abs(gL - full["g_L_u"])) < 1e-9 * np.max(np.abs(full["g_L_u"]))
+    assert res[0][1] == res[1][1]
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` without a rendezvous in the environment re-executes itself under torch.distributed.run
+    and prints one JSON line whose rccl_ranks == 2.  Skipped on boxes with a single GPU."""
+    import json
+    import subprocess
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows",
+                        "20000", "--inducing", "256"], env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and sum(line["rows_per_rank"]) == 4 * 20000
+    assert line["allreduce_ms_per_step"] > 0.0
