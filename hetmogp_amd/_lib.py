@@ -81,6 +81,9 @@ EXPORTS = {
                                       C.c_double, c_double_p]),
     "hmogp_rbf_cross_cov_ex": (C.c_int, [C.c_int32, c_double_p, C.c_int64, c_double_p, C.c_int32, C.c_int32, C.c_double,
                                          C.c_double, C.c_int32, c_double_p]),
+    "hmogp_qu_load": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "hmogp_qu_read": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "hmogp_qu_adadelta": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
     "hmogp_debug_raw_grads": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "hmogp_var_exp_ex": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_uint32, C.c_int64, c_double_p, c_double_p,
                                    c_double_p, c_double_p, c_double_p, c_double_p]),
@@ -93,6 +96,7 @@ EXPORTS = {
                                    c_double_p]),
     "hmogp_log_predictive": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_int64, C.c_int32, C.c_uint64, c_double_p,
                                        c_double_p, c_double_p, c_double_p]),
+    "hmogp_sample": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_int64, C.c_uint64, c_double_p, c_double_p]),
     "hmogp_bench_contraction": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, c_double_p]),
     "hmogp_host_alloc": (C.c_void_p, [C.c_uint64]),
     "hmogp_host_free": (None, [C.c_void_p]),

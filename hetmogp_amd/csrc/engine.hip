@@ -175,6 +175,9 @@ struct hmogp_engine {
   double* hstage = nullptr;  // page-locked landing buffer of the small per-evaluation results
   size_t hstage_cap = 0;
   bool began = false, evaluated = false;
+  // device-resident q(u) for the SVI loop (hmogp_qu_*): dmu / dLflat ARE the parameters; Adadelta state beside them
+  bool qu_resident = false;
+  DevBuf ad_gms_m, ad_sms_m, ad_step_m, ad_gms_L, ad_sms_L, ad_step_L;
 
   // timing
   struct Span {
@@ -356,8 +359,12 @@ struct hmogp_engine {
 
   // ------------------------------------------------------------------------------------------ parameters
   void upload_params(const hmogp_params* p) {
-    if (!p || !p->Z || !p->m_u || !p->L_flat || !p->variance || !p->lengthscale || !p->W || !p->kappa)
+    if (!p || !p->Z || !p->variance || !p->lengthscale || !p->W || !p->kappa)
       throw EngineError{HMOGP_E_INVALID, "missing parameter array"};
+    const bool resident = !p->m_u && !p->L_flat;     // q(u) stays where hmogp_qu_load / hmogp_qu_adadelta left it
+    if (resident ? !qu_resident : (!p->m_u || !p->L_flat))
+      throw EngineError{HMOGP_E_INVALID, resident ? "m_u / L_flat are NULL but no q(u) is resident (hmogp_qu_load)" : "missing parameter array"};
+    if (!resident) qu_resident = false;              // host arrays overwrite the resident copy
     const long long Mtri = (long long)M * (M + 1) / 2;
     h_var.assign(p->variance, p->variance + Q);
     h_ell.assign(p->lengthscale, p->lengthscale + Q);
@@ -386,10 +393,10 @@ struct hmogp_engine {
     }
     group_mask = p->group_mask;
     HIP_TRY(hipMemcpyAsync(dZ.p, p->Z, sizeof(double) * M * Q * P, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dmu.p, p->m_u, sizeof(double) * M * Q, hipMemcpyHostToDevice, st));
+    if (!resident) HIP_TRY(hipMemcpyAsync(dmu.p, p->m_u, sizeof(double) * M * Q, hipMemcpyHostToDevice, st));
     // the one large parameter (12.6 MB at M = 1024, Q = 3) goes up on the second stream, whose chain is its only consumer
     // (u_algebra): the K_uu chain on the main stream starts without waiting for it
-    HIP_TRY(hipMemcpyAsync(dLflat.p, p->L_flat, sizeof(double) * Mtri * Q, hipMemcpyHostToDevice, st2));
+    if (!resident) HIP_TRY(hipMemcpyAsync(dLflat.p, p->L_flat, sizeof(double) * Mtri * Q, hipMemcpyHostToDevice, st2));
     HIP_TRY(hipMemcpyAsync(dvar.p, h_var.data(), sizeof(double) * Q, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dell.p, h_ell.data(), sizeof(double) * Q, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dW.p, h_W.data(), sizeof(double) * Q * Df, hipMemcpyHostToDevice, st));
@@ -807,6 +814,44 @@ struct hmogp_engine {
     HIP_TRY(hipStreamSynchronize(st));
   }
 
+  // ---- device-resident q(u) + Adadelta (SVI loop; util.py:321-329, svmogp.py:188-199) ------------
+  void qu_load(const double* m_u, const double* L_flat) {
+    if (!m_u || !L_flat) throw EngineError{HMOGP_E_INVALID, "null q(u) arrays"};
+    HIP_TRY(hipSetDevice(device));
+    const size_t nm = sizeof(double) * M * Q, nl = sizeof(double) * ((long long)M * (M + 1) / 2) * Q;
+    HIP_TRY(hipMemcpyAsync(dmu.p, m_u, nm, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dLflat.p, L_flat, nl, hipMemcpyHostToDevice, st));
+    for (DevBuf* b : {&ad_gms_m, &ad_sms_m, &ad_step_m}) {
+      b->ensure(nm);
+      HIP_TRY(hipMemsetAsync(b->p, 0, nm, st));
+    }
+    for (DevBuf* b : {&ad_gms_L, &ad_sms_L, &ad_step_L}) {
+      b->ensure(nl);
+      HIP_TRY(hipMemsetAsync(b->p, 0, nl, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    qu_resident = true;
+  }
+  void qu_read(double* m_u, double* L_flat) {
+    if (!qu_resident) throw EngineError{HMOGP_E_STATE, "no resident q(u)"};
+    HIP_TRY(hipSetDevice(device));
+    if (m_u) HIP_TRY(hipMemcpyAsync(m_u, dmu.p, sizeof(double) * M * Q, hipMemcpyDeviceToHost, st));
+    if (L_flat) HIP_TRY(hipMemcpyAsync(L_flat, dLflat.p, sizeof(double) * ((long long)M * (M + 1) / 2) * Q, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  // phase 0: momentum move before the gradient evaluation; phase 1: update from the gradients the last evaluation left in
+  // gmu / gL (objective = -ELBO: sign -1), or from a zero gradient when that evaluation did not include the q(u) group
+  void qu_adadelta(int phase, double rate, double m, double d, double omd, double o) {
+    if (!qu_resident) throw EngineError{HMOGP_E_STATE, "no resident q(u)"};
+    if (phase == 1 && !evaluated) throw EngineError{HMOGP_E_STATE, "Adadelta update without a finished evaluation"};
+    HIP_TRY(hipSetDevice(device));
+    const long long nm = (long long)M * Q, nl = ((long long)M * (M + 1) / 2) * Q;
+    const bool has = phase == 1 && (group_mask & HMOGP_GROUP_QU) != 0;
+    launch_adadelta(dmu.d(), ad_gms_m.d(), ad_sms_m.d(), ad_step_m.d(), has ? gmu.d() : nullptr, -1.0, nm, phase, rate, m, d, omd, o, st);
+    launch_adadelta(dLflat.d(), ad_gms_L.d(), ad_sms_L.d(), ad_step_L.d(), has ? gL.d() : nullptr, -1.0, nl, phase, rate, m, d, omd, o, st);
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+
   // Inner-protocol debug export (include/hetmogp_hip.h: hmogp_debug_raw_grads): the gradient dictionary of
   // SVMOGPInf.inference (svmogp_inf.py:107) rebuilt from what the last evaluation left in HBM -- dKmm, a, P~ of the one
   // pool, p / c row statistics -- plus one more quadrature pass that writes the per-function d ve/dm, d ve/dv rows.
@@ -1114,6 +1159,22 @@ int hmogp_posterior_u(hmogp_handle h, double* woodbury_vector, double* woodbury_
   return guarded(h, [&] { h->posterior_u(woodbury_vector, woodbury_inv); });
 }
 
+int hmogp_qu_load(hmogp_handle h, const double* m_u, const double* L_flat) {
+  if (!h) return HMOGP_E_INVALID;
+  return guarded(h, [&] { h->qu_load(m_u, L_flat); });
+}
+
+int hmogp_qu_read(hmogp_handle h, double* m_u, double* L_flat) {
+  if (!h) return HMOGP_E_INVALID;
+  return guarded(h, [&] { h->qu_read(m_u, L_flat); });
+}
+
+int hmogp_qu_adadelta(hmogp_handle h, int32_t phase, double step_rate, double momentum, double decay, double one_minus_decay,
+                      double offset) {
+  if (!h || (phase != 0 && phase != 1)) return HMOGP_E_INVALID;
+  return guarded(h, [&] { h->qu_adadelta(phase, step_rate, momentum, decay, one_minus_decay, offset); });
+}
+
 int hmogp_debug_raw_grads(hmogp_handle h, double* dL_dKmm, double* dL_dKmn, double* dL_dKdiag) {
   if (!h) return HMOGP_E_INVALID;
   return guarded(h, [&] { h->debug_raw(dL_dKmm, dL_dKmn, dL_dKdiag); });
@@ -1295,6 +1356,21 @@ int hmogp_log_predictive(int32_t device, int32_t lik_id, double lik_param, int64
     launch_log_predictive(lik_id, J, lik_param, N, num_samples, seed, dy.d(), dm.d(), dv.d(), dout.d(), nullptr);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(log_pred, dout.p, sizeof(double) * N, hipMemcpyDeviceToHost));
+  });
+}
+
+int hmogp_sample(int32_t device, int32_t lik_id, double lik_param, int64_t N, uint64_t seed, const double* F, double* Y) {
+  return guarded(nullptr, [&] {
+    need_device(device);
+    if (lik_id == HMOGP_LIK_GAUSSIAN && !(lik_param > 0.0)) lik_param = 0.5;
+    const int J = lik_dimf(lik_id, lik_param);
+    if (J < 1 || J > HMOGP_MAXJ || N <= 0 || !F || !Y) throw EngineError{HMOGP_E_INVALID, "bad arguments"};
+    DevBuf dF, dY;
+    dF.ensure(sizeof(double) * N * J), dY.ensure(sizeof(double) * N);
+    HIP_TRY(hipMemcpy(dF.p, F, sizeof(double) * N * J, hipMemcpyHostToDevice));
+    launch_sample(lik_id, J, lik_param, N, seed, dF.d(), dY.d(), nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(Y, dY.p, sizeof(double) * N, hipMemcpyDeviceToHost));
   });
 }
 

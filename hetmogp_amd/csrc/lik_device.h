@@ -145,20 +145,42 @@ __device__ __forceinline__ void lik_gamma(double y, const double* m, const doubl
   o.gv[1] = 0.5 * (-y * S0 * B1);
 }
 
+// Per-wave LDS scratch of the tensor-rule likelihoods (doubles): Categorical [0,80) exp(f_k(node i)), [80,160) f_k(node i),
+// [160,170) normalised GH weights; Beta [0,80) a_i, psi(a_i), zeta(2,a_i), lgamma(a_i) and the same four for b_j.
+#define HMOGP_ETAB 176
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------- Beta, 10 x 10
-// beta.py:29-36,76-197.  betaln / psi / zeta of (a+b) couple the two dimensions: 100 nodes over the 64 lanes.
-__device__ __forceinline__ void lik_beta_wave(double y, const double* m, const double* v, int lane, LikOut& o) {
-  const double s1 = sqrt(2.0 * v[0]), s2 = sqrt(2.0 * v[1]);
+// beta.py:29-36,76-197.  betaln / psi / zeta of (a+b) couple the two dimensions: 100 nodes over the 64 lanes.  Everything
+// that depends on ONE dimension only -- a_i, psi(a_i), zeta(2, a_i), lgamma(a_i) and the same for b_j -- is evaluated once
+// per row by 20 lanes into the wave's LDS table: 3 special functions per node (of a+b) instead of 9.
+__device__ __forceinline__ void lik_beta_wave(double y, const double* m, const double* v, int lane, double* tab, LikOut& o) {
+  if (lane < 20) {
+    const int dim = lane / 10, i = lane - 10 * dim;
+    const double x = clip(safe_exp(GH10_X[i] * sqrt(2.0 * v[dim]) + m[dim]), 1e-9, 1e9);
+    double* t = tab + dim * 40 + i;
+    t[0] = x, t[10] = digamma_pos(x), t[20] = trigamma_pos(x), t[30] = lgamma(x);
+  }
+  __builtin_amdgcn_wave_barrier();  // written and read by this wave only (LDS operations of a wave are in order)
   const double ly = log(y), l1y = log(1.0 - y);
   double ve = 0.0, g0 = 0.0, g1 = 0.0, h0 = 0.0, h1 = 0.0;
   for (int n = lane; n < 100; n += 64) {
     const int i = n / 10, j = n - 10 * i;
     const double w = (GH10_WN[i] * INV_SQRT_PI) * (GH10_WN[j] * INV_SQRT_PI);
-    const double a = clip(safe_exp(GH10_X[i] * s1 + m[0]), 1e-9, 1e9);
-    const double b = clip(safe_exp(GH10_X[j] * s2 + m[1]), 1e-9, 1e9);
-    const double pab = digamma_pos(a + b), pa = digamma_pos(a), pb = digamma_pos(b);
-    const double zab = trigamma_pos(a + b), za = trigamma_pos(a), zb = trigamma_pos(b);
-    const double lbeta = lgamma(a) + lgamma(b) - lgamma(a + b);
+    const double a = tab[i], pa = tab[10 + i], za = tab[20 + i], lga = tab[30 + i];
+    const double b = tab[40 + j], pb = tab[50 + j], zb = tab[60 + j], lgb = tab[70 + j];
+    const double pab = digamma_pos(a + b), zab = trigamma_pos(a + b);
+    const double lbeta = lga + lgb - lgamma(a + b);
     ve += w * ((a - 1.0) * ly + (b - 1.0) * l1y - lbeta);
     g0 += w * ((pab - pa + ly) * a);
     g1 += w * ((pab - pb + l1y) * b);
@@ -174,85 +196,145 @@ __device__ __forceinline__ void lik_beta_wave(double y, const double* m, const d
 
 // ------------------------------------------------------------------------------------------- Categorical
 // categorical.py:37-46,77-82,102-222.  K classes, D = K-1 functions, labels 1..K (class K = reference class),
-// 10^D tensor nodes strided over the wave.  `etab` is a per-wave LDS table [D][10] of exp(f_k(node i)).
-__device__ __forceinline__ void lik_categorical_wave(double y, const double* m, const double* v, int K, int lane,
-                                                     double* etab, unsigned quirks, LikOut& o) {
-  const int D = K - 1;
-  for (int e = lane; e < D * 10; e += 64) {
-    const int k = e / 10, i = e - 10 * k;
-    etab[e] = safe_exp(GH10_X[i] * sqrt(2.0 * v[k]) + m[k]);
+// 10^D tensor nodes.  The node dependence factorises through exp(f_k) per dimension: a per-wave LDS
+// table holds exp(f_k(node i)) and f_k(node i), [D][10] each.  The LAST min(D,3) dimensions are strided over the lanes
+// (their digits, table entries and weight product are formed once per lane and chunk); the remaining leading dimensions
+// are a uniform outer loop.  A node whose probabilities are not touched by the reference's clip to [1e-9, 1-1e-9] takes
+//   log p_y = f_y - log(den),  d2 = -p_d (den - e_d)/den      (one reciprocal, one log per node)
+// which equals the reference's clipped / renormalised expressions to rounding; any other node (clip active, overflow)
+// takes the literal formulas.
+template <int D>
+__device__ __forceinline__ void cat_node_literal(const double (&e)[D], double w, int label, bool exact_dm, double& ve,
+                                                 double (&hv)[D], double (&gx)[D]) {
+  constexpr int K = D + 1;
+  double esum = 0.0;
+#pragma unroll
+  for (int k = D - 1; k >= 0; --k) esum += e[k];
+  const double den = 1.0 + esum;
+  double psum = 0.0, py = 0.0;  // class probabilities, clipped then renormalised (:41-44)
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const double pk = clip(e[k] / den, 1e-9, 1.0 - 1e-9);
+    psum += pk;
+    if (label == k + 1) py = pk;
   }
-  __builtin_amdgcn_wave_barrier();  // the table is written and read by this wave only (LDS ops are in order)
-  int total = 1;
-  for (int k = 0; k < D; ++k) total *= 10;
+  const double pK = clip(1.0 / den, 1e-9, 1.0 - 1e-9);
+  psum += pK;
+  if (label == K) py = pK;
+  ve += w * log(py / psum);
+  // second derivative of log p wrt f_d (:115-128): -(e_d + sum_{j != d} e^{f_j + f_d}) / den^2, independent of y
+  const double den2 = safe_square(den);
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    double num = e[d];
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+      if (j != d) num += fmin(e[j] * e[d], 1.79769313486231570815e308);
+    hv[d] += w * (num / den2);
+    if (exact_dm) gx[d] += w * ((label == d + 1 ? 1.0 : 0.0) - e[d] / den);  // E[d log p_y / d f_d], softmax
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void lik_categorical_t(double y, const double* m, const double* v, int lane, double* tab,
+                                                  unsigned quirks, LikOut& o) {
+  constexpr int K = D + 1;
+  constexpr int DI = D < 3 ? D : 3, DO = D - DI;            // lane-strided inner / uniform outer dimensions
+  constexpr int NIN = DI == 1 ? 10 : (DI == 2 ? 100 : 1000);
+  int NOUT = 1;
+#pragma unroll
+  for (int k = 0; k < DO; ++k) NOUT *= 10;
+  double* etab = tab;
+  double* ftab = tab + 80;
+  double* wtab = tab + 160;
+  double mine = INFINITY, maxe = 0.0;
+  for (int t = lane; t < D * 10; t += 64) {
+    const int k = t / 10, i = t - 10 * k;
+    const double f = GH10_X[i] * sqrt(2.0 * v[k]) + m[k], ef = safe_exp(f);
+    etab[t] = ef, ftab[t] = f;
+    mine = fmin(mine, ef), maxe = fmax(maxe, ef);
+  }
+  if (lane < 10) wtab[lane] = GH10_WN[lane];
+  __builtin_amdgcn_wave_barrier();  // the tables are written and read by this wave only (LDS ops are in order)
+  // row-level bounds for the "clip inactive" test of a node: every p = t / den with lo_row <= t <= hi_row
+  const double lo_row = fmin(wave_min(mine), 1.0), hi_row = fmax(wave_max(maxe), 1.0);
   const int label = (int)y;  // 1..K
   const bool valid = (y == (double)label) && label >= 1 && label <= K;
-  double ve = 0.0;
-  double hv[HMOGP_MAXJ], gx[HMOGP_MAXJ];
   const bool exact_dm = (quirks & HMOGP_QUIRK_CATEGORICAL_DM) == 0;
+  double ve = 0.0, hv[D], gx[D];
 #pragma unroll
-  for (int k = 0; k < HMOGP_MAXJ; ++k) hv[k] = gx[k] = 0.0;
-  for (int n = lane; n < total; n += 64) {
-    double e[HMOGP_MAXJ];
-    double w = 1.0, esum = 0.0;
-    int rem = n;
-    // C-order grid (categorical.py:153-162): function 0 is the slowest index
+  for (int k = 0; k < D; ++k) hv[k] = gx[k] = 0.0;
+  for (int base = 0; base < NIN; base += 64) {
+    const int idx = base + lane;
+    if (idx >= NIN) continue;
+    // C-order grid (categorical.py:153-162): function 0 is the slowest index, function D-1 the fastest
+    double e[D], fy = 0.0, win = 1.0;
+    int rem = idx;
 #pragma unroll
-    for (int k = HMOGP_MAXJ - 1; k >= 0; --k) {
-      if (k < D) {
-        const int i = rem % 10;
-        rem /= 10;
+    for (int t = DI - 1; t >= 0; --t) {
+      const int i = rem % 10;
+      rem /= 10;
+      e[DO + t] = etab[(DO + t) * 10 + i];
+      if (label == DO + t + 1) fy = ftab[(DO + t) * 10 + i];
+      win *= wtab[i];
+    }
+    for (int oc = 0; oc < NOUT; ++oc) {
+      double w = win, fyo = fy;
+      int r2 = oc;
+#pragma unroll
+      for (int k = DO - 1; k >= 0; --k) {  // uniform digits
+        const int i = r2 % 10;
+        r2 /= 10;
         e[k] = etab[k * 10 + i];
-        w *= GH10_WN[i];
-        esum += e[k];
+        if (label == k + 1) fyo = ftab[k * 10 + i];
+        w *= wtab[i];
+      }
+      double esum = 0.0;
+#pragma unroll
+      for (int k = D - 1; k >= 0; --k) esum += e[k];
+      const double den = 1.0 + esum;
+      if (den < 1e300 && den * 1e-9 <= lo_row && den * (1.0 - 1e-9) >= hi_row) {
+        const double rden = 1.0 / den;
+        ve += w * (fyo - log(den));
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          const double pd = e[d] * rden;
+          hv[d] += w * (pd * ((den - e[d]) * rden));
+          if (exact_dm) gx[d] += w * ((label == d + 1 ? 1.0 : 0.0) - pd);
+        }
       } else {
-        e[k] = 0.0;
-      }
-    }
-    const double den = 1.0 + esum;
-    // class probabilities, clipped then renormalised (:41-44)
-    double psum = 0.0, py = 0.0;
-#pragma unroll
-    for (int k = 0; k < HMOGP_MAXJ; ++k) {
-      if (k < D) {
-        const double pk = clip(e[k] / den, 1e-9, 1.0 - 1e-9);
-        psum += pk;
-        if (label == k + 1) py = pk;
-      }
-    }
-    const double pK = clip(1.0 / den, 1e-9, 1.0 - 1e-9);
-    psum += pK;
-    if (label == K) py = pK;
-    ve += w * log(py / psum);
-    // second derivative of log p wrt f_d (:115-128): -(e_d + sum_{j != d} e^{f_j + f_d}) / den^2, independent of y
-    const double den2 = safe_square(den);
-#pragma unroll
-    for (int d = 0; d < HMOGP_MAXJ; ++d) {
-      if (d < D) {
-        double num = e[d];
-#pragma unroll
-        for (int j = 0; j < HMOGP_MAXJ; ++j)
-          if (j < D && j != d) num += fmin(e[j] * e[d], 1.79769313486231570815e308);
-        hv[d] += w * (num / den2);
-        if (exact_dm) gx[d] += w * ((label == d + 1 ? 1.0 : 0.0) - e[d] / den);  // E[d log p_y / d f_d], softmax
+        cat_node_literal<D>(e, w, label, exact_dm, ve, hv, gx);
       }
     }
   }
   o.ve = valid ? wave_sum(ve) : nan("");
   double wpow = 1.0;
+#pragma unroll
   for (int k = 0; k < D; ++k) wpow *= GH10_WSUM_OVER_SQRTPI;
 #pragma unroll
-  for (int d = 0; d < HMOGP_MAXJ; ++d) {
-    if (d < D) {
-      const double s = wave_sum(hv[d]);
-      o.gv[d] = valid ? -0.5 * s : 0.0;
-      if (exact_dm) {
-        const double g = wave_sum(gx[d]);
-        o.gm[d] = valid ? g : 0.0;
-      } else {
-        o.gm[d] = ((label == d + 1 ? 1.0 : 0.0) - (valid ? 1.0 : 0.0)) * wpow;  // quirk Q2
-      }
+  for (int d = 0; d < D; ++d) {
+    const double s = wave_sum(hv[d]);
+    o.gv[d] = valid ? -0.5 * s : 0.0;
+    if (exact_dm) {
+      const double g = wave_sum(gx[d]);
+      o.gm[d] = valid ? g : 0.0;
+    } else {
+      o.gm[d] = ((label == d + 1 ? 1.0 : 0.0) - (valid ? 1.0 : 0.0)) * wpow;  // quirk Q2
     }
+  }
+}
+
+__device__ __forceinline__ void lik_categorical_wave(double y, const double* m, const double* v, int K, int lane,
+                                                     double* tab, unsigned quirks, LikOut& o) {
+  switch (K - 1) {
+    case 1: lik_categorical_t<1>(y, m, v, lane, tab, quirks, o); break;
+    case 2: lik_categorical_t<2>(y, m, v, lane, tab, quirks, o); break;
+    case 3: lik_categorical_t<3>(y, m, v, lane, tab, quirks, o); break;
+    case 4: lik_categorical_t<4>(y, m, v, lane, tab, quirks, o); break;
+    case 5: lik_categorical_t<5>(y, m, v, lane, tab, quirks, o); break;
+    case 6: lik_categorical_t<6>(y, m, v, lane, tab, quirks, o); break;
+    case 7: lik_categorical_t<7>(y, m, v, lane, tab, quirks, o); break;
+    default: lik_categorical_t<8>(y, m, v, lane, tab, quirks, o); break;
   }
 }
 
@@ -437,6 +519,112 @@ __device__ __forceinline__ void normal_pair(unsigned long long seed, long long n
   z1 = r * sin(2.0 * M_PI * u2);
 }
 
+// ============================================================================ data generation (`samples`)
+// One draw y ~ p(y | f) per row with the link functions and clips of the reference's `<likelihood>.samples`
+// (gaussian.py:36-39, bernoulli.py:59-64, hetgaussian.py:41-44, poisson.py:51-54, exponential.py:52-56, gamma.py:43-50,
+// beta.py:38-45, categorical.py:65-75).  Counter-based generator (reproducible per (seed, row); a different stream than
+// NumPy's, so only the DISTRIBUTION is comparable with the reference): uniforms from splitmix64, normals by Box-Muller,
+// Poisson by multiplication (lambda < 10) / Hoermann's PTRS transformed rejection, Gamma by Marsaglia-Tsang.
+struct RowRng {
+  unsigned long long key, ctr;
+  __device__ RowRng(unsigned long long seed, long long row) : key(splitmix64(seed ^ (unsigned long long)row * 0xD1342543DE82EF95ULL)), ctr(0) {}
+  __device__ double uniform() {  // (0, 1)
+    const unsigned long long h = splitmix64(key ^ (++ctr * 0x9E3779B97F4A7C15ULL));
+    return ((double)(h >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+  }
+  __device__ double normal() {
+    const double u1 = uniform(), u2 = uniform();
+    return sqrt(-2.0 * log(u1)) * cos(2.0 * M_PI * u2);
+  }
+  __device__ double gamma(double a) {  // shape a > 0, scale 1
+    double boost = 1.0;
+    if (a < 1.0) {
+      boost = pow(uniform(), 1.0 / a);
+      a += 1.0;
+    }
+    const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (int it = 0; it < 1000; ++it) {
+      const double x = normal(), t = 1.0 + c * x;
+      if (t <= 0.0) continue;
+      const double vv = t * t * t, u = uniform();
+      if (u < 1.0 - 0.0331 * (x * x) * (x * x) || log(u) < 0.5 * x * x + d * (1.0 - vv + log(vv))) return boost * d * vv;
+    }
+    return boost * d;
+  }
+  __device__ double poisson(double lam) {
+    if (!(lam > 0.0)) return 0.0;
+    if (lam < 10.0) {
+      const double L = exp(-lam);
+      double k = 0.0, p = uniform();
+      while (p > L) {
+        k += 1.0;
+        p *= uniform();
+      }
+      return k;
+    }
+    if (lam > 1e15) return lam;  // beyond float64 integer resolution the distribution is its mean
+    const double slam = sqrt(lam), loglam = log(lam), b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
+    const double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2.0);
+    for (int it = 0; it < 1000; ++it) {
+      const double U = uniform() - 0.5, V = uniform(), us = 0.5 - fabs(U);
+      const double k = floor((2.0 * a / us + b) * U + lam + 0.43);
+      if (us >= 0.07 && V <= vr) return k;
+      if (k < 0.0 || (us < 0.013 && V > us)) continue;
+      if (log(V) + log(invalpha) - log(a / (us * us) + b) <= -lam + k * loglam - lgamma(k + 1.0)) return k;
+    }
+    return floor(lam);
+  }
+};
+
+template <int LIK>
+__device__ __forceinline__ double lik_sample(RowRng& g, const double* f, double param) {
+  if (LIK == HMOGP_LIK_GAUSSIAN) {
+    return f[0] + param * g.normal();
+  } else if (LIK == HMOGP_LIK_BERNOULLI) {
+    const double ef = safe_exp(f[0]);
+    return g.uniform() < clip(ef / (1.0 + ef), 1e-9, 1.0 - 1e-9) ? 1.0 : 0.0;
+  } else if (LIK == HMOGP_LIK_HETGAUSSIAN) {
+    return f[0] + sqrt(safe_exp(f[1])) * g.normal();
+  } else if (LIK == HMOGP_LIK_POISSON) {
+    return g.poisson(safe_exp(f[0]));
+  } else if (LIK == HMOGP_LIK_EXPONENTIAL) {
+    return -clip(safe_exp(-f[0]), 1e-9, 1e9) * log(g.uniform());
+  } else if (LIK == HMOGP_LIK_GAMMA) {
+    const double a = clip(safe_exp(f[0]), 1e-9, 1e9), b = clip(safe_exp(f[1]), 1e-9, 1e9);
+    return g.gamma(a) / b;
+  } else if (LIK == HMOGP_LIK_BETA) {
+    const double a = clip(safe_exp(f[0]), 1e-9, 1e9), b = clip(safe_exp(f[1]), 1e-9, 1e9);
+    const double x = g.gamma(a), yv = g.gamma(b);
+    return x / (x + yv);
+  } else {  // Categorical: labels 1..K, probabilities clipped then renormalised (categorical.py:66-71)
+    const int K = (int)param, D = K - 1;
+    double e[HMOGP_MAXJ], esum = 0.0;
+#pragma unroll
+    for (int k = 0; k < HMOGP_MAXJ; ++k) {
+      e[k] = (k < D) ? safe_exp(f[k]) : 0.0;
+      esum += e[k];
+    }
+    const double den = 1.0 + esum;
+    double psum = clip(1.0 / den, 1e-9, 1.0 - 1e-9);
+#pragma unroll
+    for (int k = 0; k < HMOGP_MAXJ; ++k)
+      if (k < D) {
+        e[k] = clip(e[k] / den, 1e-9, 1.0 - 1e-9);
+        psum += e[k];
+      }
+    const double u = g.uniform() * psum;
+    double cum = 0.0, label = (double)K;
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < HMOGP_MAXJ; ++k)
+      if (k < D && !found) {
+        cum += e[k];
+        if (u < cum) label = (double)(k + 1), found = true;
+      }
+    return label;
+  }
+}
+
 // lanes per row of a likelihood's predictive rule
 __host__ __device__ constexpr int lik_pred_lanes(int lik) {
   return (lik == HMOGP_LIK_BETA || lik == HMOGP_LIK_GAMMA || lik == HMOGP_LIK_CATEGORICAL) ? 64 : 1;
@@ -461,7 +649,7 @@ __device__ __forceinline__ void lik_eval(double y, double yaux, const double* m,
   else if (LIK == HMOGP_LIK_GAMMA)
     lik_gamma(y, m, v, o);
   else if (LIK == HMOGP_LIK_BETA)
-    lik_beta_wave(y, m, v, lane, o);
+    lik_beta_wave(y, m, v, lane, etab, o);
   else
     lik_categorical_wave(y, m, v, (int)param, lane, etab, quirks, o);
   if ((LIK == HMOGP_LIK_GAMMA || LIK == HMOGP_LIK_BETA) && !(quirks & HMOGP_QUIRK_GAMMA_BETA_PI)) {

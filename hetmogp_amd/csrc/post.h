@@ -26,3 +26,7 @@ void launch_natgrad_theta1(const double* t1, const double* t2, const double* gm,
                            hipStream_t s);
 void launch_pack_tril(const double* T, double* out, int Q, int M, double scale, hipStream_t s);
 void launch_scatter_mq(const double* v, double* out, int Q, int M, hipStream_t s);
+// device-resident Adadelta (climin recurrence, util.py:327) on one parameter block; phase 0 = momentum move before the
+// gradient, phase 1 = update from grad (nullptr = zero gradient); omd = 1 - d as the host computes it
+void launch_adadelta(double* x, double* gms, double* sms, double* step, const double* grad, double sign, long long n, int phase,
+                     double rate, double m, double d, double omd, double o, hipStream_t s);

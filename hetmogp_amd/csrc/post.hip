@@ -1,6 +1,8 @@
 // post.hip -- element-wise / reduction kernels of the replicated M x M algebra (gfx950): the pieces of
 // SVMOGPInf.calculate_KL (svmogp_inf.py:227-250), calculate_gradients (:111-183) and of the K_uu half of
 // SVMOGP.parameters_changed (svmogp.py:116,154) that are not GEMMs.
+#include <algorithm>
+
 #include "post.h"
 #include "rbf_device.h"
 
@@ -247,3 +249,53 @@ void launch_qf_combine(const double* p, const double* c, long long ldn, long lon
   hipLaunchKernelGGL(qf_combine_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, p, c, ldn, N, Q, Df, W, kappa,
                      var, m, v);
 }
+
+// ---- device-resident Adadelta for q(u) (SVI loop; the recurrence of climin.Adadelta as the reference calls it, util.py:327)
+// phase 0 (before the gradient):  step1 = m * step;  x -= step1
+// phase 1 (after it):             gms = d gms + (1-d) g^2;  step2 = sqrt(sms+o)/sqrt(gms+o) * g * rate;  x -= step2;
+//                                 step = step1 + step2;  sms = d sms + (1-d) step^2        with g = sign * grad (or 0)
+// Every operation is a separately rounded IEEE operation in the order of hetmogp_amd/util.py:Adadelta (no FMA contraction),
+// so the iterates are bit-identical to the host optimiser's.
+namespace {
+__global__ void adadelta_kernel(double* __restrict__ x, double* __restrict__ gms, double* __restrict__ sms,
+                                double* __restrict__ step, const double* __restrict__ grad, double sign, long long n, int phase,
+                                double rate, double m, double d, double omd, double o) {
+#pragma clang fp contract(off)
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const double step1 = step[i] * m;
+    if (phase == 0) {
+      x[i] = x[i] - step1;
+      continue;
+    }
+    const double g = grad ? sign * grad[i] : 0.0;
+    double t1 = g * g;
+    t1 = t1 * omd;
+    double gm = gms[i] * d;
+    gm = gm + t1;
+    gms[i] = gm;
+    double a = sqrt(sms[i] + o);
+    const double b = sqrt(gm + o);
+    a = a / b;
+    a = a * g;
+    a = a * rate;
+    x[i] = x[i] - a;
+    const double st = step1 + a;
+    step[i] = st;
+    double t2 = st * st;
+    t2 = t2 * omd;
+    double sm = sms[i] * d;
+    sm = sm + t2;
+    sms[i] = sm;
+  }
+}
+}  // namespace
+
+void launch_adadelta(double* x, double* gms, double* sms, double* step, const double* grad, double sign, long long n, int phase,
+                     double rate, double m, double d, double omd, double o, hipStream_t s) {
+  if (n <= 0) return;
+  const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(adadelta_kernel, dim3(blocks), dim3(256), 0, s, x, gms, sms, step, grad, sign, n, phase, rate, m, d, omd, o);
+}
+

@@ -59,6 +59,9 @@ void launch_predictive(int lik, int J, int Jp, double param, int T, long long N,
 // out[n] = -log S + logsumexp_s log p(y_n | f_s), f_s ~ N(m_n, diag v_n): Monte-Carlo log predictive density per row
 void launch_log_predictive(int lik, int J, double param, long long N, int S, unsigned long long seed, const double* y,
                            const double* m, const double* v, double* out, hipStream_t s);
+// Y[n] ~ p(y | F[n]): the reference's `<likelihood>.samples`, one draw per row, counter-based generator
+void launch_sample(int lik, int J, double param, long long N, unsigned long long seed, const double* F, double* Y,
+                   hipStream_t s);
 void launch_rbf(const double* X, int ldx, long long N, int P, const double* Z, int ldz, int M, double var, double ell,
                 double* K, bool same, hipStream_t s, const int* rowwin = nullptr, bool exact = true,
                 const RbfBatch* batch = nullptr);

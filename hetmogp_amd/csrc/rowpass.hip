@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void window_fix_kernel(int* __restrict__ rowwi
 template <int LIK>
 __global__ __launch_bounds__(256) void quad_kernel(QuadArgs a) {
   constexpr int G = lik_lanes(LIK);
-  __shared__ double etab[4][HMOGP_MAXJ * 10];
+  __shared__ double etab[4][HMOGP_ETAB];
   __shared__ double red[4][HMOGP_MAXSCAL];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const long long n = ((long long)blockIdx.x * 256 + t) / G;
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void var_exp_kernel(int J, double param, long 
                                                       double* __restrict__ ve, double* __restrict__ dm,
                                                       double* __restrict__ dv, unsigned quirks) {
   constexpr int G = lik_lanes(LIK);
-  __shared__ double etab[4][HMOGP_MAXJ * 10];
+  __shared__ double etab[4][HMOGP_ETAB];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const long long n = ((long long)blockIdx.x * 256 + t) / G;
   if (n >= N) return;
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void predictive_kernel(int J, int Jp, double p
                                                          const double* __restrict__ m, const double* __restrict__ v,
                                                          double* __restrict__ mean, double* __restrict__ var) {
   constexpr int G = lik_pred_lanes(LIK);
-  __shared__ double etab[4][HMOGP_MAXJ * 10];
+  __shared__ double etab[4][HMOGP_ETAB];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const long long n = ((long long)blockIdx.x * 256 + t) / G;
   if (n >= N) return;
@@ -622,9 +622,41 @@ __global__ __launch_bounds__(256) void log_predictive_kernel(int J, double param
   if (lane == 0) out[n] = -log((double)S) + mx + log(se);
 }
 
+// ---- data generation: one lane per row -------------------------------------------------------------------------------
+template <int LIK>
+__global__ __launch_bounds__(256) void sample_kernel(int J, double param, long long N, unsigned long long seed,
+                                                     const double* __restrict__ F, double* __restrict__ Y) {
+  const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  double f[HMOGP_MAXJ];
+#pragma unroll
+  for (int j = 0; j < HMOGP_MAXJ; ++j) f[j] = (j < J) ? F[n * J + j] : 0.0;
+  RowRng g(seed, n);
+  Y[n] = lik_sample<LIK>(g, f, param);
+}
+
 }  // namespace
 
 // =============================================================================================== launchers
+void launch_sample(int lik, int J, double param, long long N, unsigned long long seed, const double* F, double* Y,
+                   hipStream_t s) {
+  if (N <= 0) return;
+  dim3 grid((unsigned)((N + 255) / 256));
+#define SK(L) hipLaunchKernelGGL((sample_kernel<L>), grid, dim3(256), 0, s, J, param, N, seed, F, Y)
+  switch (lik) {
+    case HMOGP_LIK_GAUSSIAN: SK(HMOGP_LIK_GAUSSIAN); break;
+    case HMOGP_LIK_BERNOULLI: SK(HMOGP_LIK_BERNOULLI); break;
+    case HMOGP_LIK_HETGAUSSIAN: SK(HMOGP_LIK_HETGAUSSIAN); break;
+    case HMOGP_LIK_CATEGORICAL: SK(HMOGP_LIK_CATEGORICAL); break;
+    case HMOGP_LIK_POISSON: SK(HMOGP_LIK_POISSON); break;
+    case HMOGP_LIK_EXPONENTIAL: SK(HMOGP_LIK_EXPONENTIAL); break;
+    case HMOGP_LIK_GAMMA: SK(HMOGP_LIK_GAMMA); break;
+    case HMOGP_LIK_BETA: SK(HMOGP_LIK_BETA); break;
+    default: throw HipError{hipErrorInvalidValue, "unknown likelihood id", __FILE__, __LINE__};
+  }
+#undef SK
+}
+
 void launch_windows(const double* X, long long N, int P, const double* Z, int ldz, int M, double ell, int* rowwin, int* colwin,
                     unsigned char* hit, hipStream_t s) {
   if (N <= 0) return;

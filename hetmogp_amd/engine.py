@@ -155,7 +155,7 @@ class Engine(object):
         p.group_mask = int(group_mask)
         return p, keep
 
-    def _outputs(self, want_dL_dS=False):
+    def _outputs(self, want_dL_dS=False, skip_qu=False):
         Q, M, P, Df = self.Q, self.M, self.P, self.Df
         if self.reuse_outputs:      # page-locked arrays owned by the engine, overwritten by the next evaluation
             if self._pinned_out is None:
@@ -175,6 +175,10 @@ class Engine(object):
             setattr(c, k, _p(v))
         if not want_dL_dS:
             c.dL_dS = None
+        if skip_qu:                  # q(u) is device-resident: its gradient stays in HBM for hmogp_qu_adadelta
+            c.g_m_u = None
+            c.g_L_u = None
+            o["g_m_u"] = o["g_L_u"] = None
         c.rung = rung.ctypes.data_as(_lib.c_int32_p)
         c.flags = flags.ctypes.data_as(_lib.c_uint32_p)
         o["rung"], o["flags"] = rung, flags
@@ -193,7 +197,7 @@ class Engine(object):
         """One ``parameters_changed()``: returns dict(elbo, g_m_u, g_L_u, g_variance, g_lengthscale, g_W, g_kappa,
         g_Z, rungs, v_negative[, dL_dS])."""
         p, keep = self._params(**params)
-        c, o = self._outputs(want_dL_dS)
+        c, o = self._outputs(want_dL_dS, skip_qu=params.get("m_u") is None)
         check(lib.hmogp_elbo_grad(self._h, C.byref(p), C.byref(c)), self._h)
         return self._wrap(o)
 
@@ -264,6 +268,20 @@ class Engine(object):
         v = np.zeros((Xnew.shape[0], self.Df))
         check(lib.hmogp_predict_f(self._h, _p(Xnew), Xnew.shape[0], _p(m), _p(v)), self._h)
         return m, v
+
+    # ------------------------------------------------------------------------------------------ resident q(u)
+    def qu_load(self, m_u, L_flat):
+        m_u, L_flat = _f64(m_u).reshape(self.M, self.Q), _f64(L_flat).reshape(self.Mtri, self.Q)
+        check(lib.hmogp_qu_load(self._h, _p(m_u), _p(L_flat)), self._h)
+
+    def qu_read(self):
+        m, L = np.zeros((self.M, self.Q)), np.zeros((self.Mtri, self.Q))
+        check(lib.hmogp_qu_read(self._h, _p(m), _p(L)), self._h)
+        return m, L
+
+    def qu_adadelta(self, phase, step_rate, momentum, decay, offset):
+        check(lib.hmogp_qu_adadelta(self._h, int(phase), float(step_rate), float(momentum), float(decay), float(1 - decay),
+                                    float(offset)), self._h)
 
     def debug_raw_grads(self, rows):
         """The reference's inner-protocol gradient dict of the last evaluation (small N, one pool, GROUP_ALL):
@@ -368,3 +386,12 @@ def log_predictive_rows(name, y, m, v, num_samples=1000, seed=0, device=0, **kw)
     check(lib.hmogp_log_predictive(device, LIK_IDS[name], lik_param(name, **kw), y.shape[0], int(num_samples), int(seed),
                                    _p(y), _p(m), _p(v), _p(out)))
     return out
+
+
+def sample(name, F, seed=0, device=0, **kw):
+    """One draw y ~ p(y | F[n]) per row on the device (the reference's `<likelihood>.samples`): returns (N, 1)."""
+    J = lik_dim_f(name, **kw)
+    F = _f64(F).reshape(-1, J)
+    Y = np.zeros(F.shape[0])
+    check(lib.hmogp_sample(device, LIK_IDS[name], lik_param(name, **kw), F.shape[0], int(seed) & (2 ** 64 - 1), _p(F), _p(Y)))
+    return Y[:, None]

@@ -41,9 +41,16 @@ class _Lik(object):
         from .engine import predictive
         return predictive(self.name, m, v, **self.kwargs())
 
-
-def _safe_exp(f):
-    return np.exp(np.minimum(f, np.log(np.finfo(np.float64).max)))
+    def samples(self, F, num_samples=1, Y_metadata=None, seed=None):
+        """One draw y ~ p(y | F[n]) per row, (N, 1) -- the reference's `samples` (e.g. gaussian.py:36-39, gamma.py:43-50,
+        categorical.py:65-75: same link functions and clips, labels 1..K), generated on the device (`hmogp_sample`).
+        The reference draws from NumPy's global generator; here the device generator is keyed by `seed`, which is itself
+        drawn from NumPy's global generator when not given -- so `np.random.seed(k)` still makes a run reproducible, but
+        the stream differs from the reference's (only the distribution is the same)."""
+        from .engine import sample
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 31 - 1))
+        return sample(self.name, F, seed=seed, **self.kwargs())
 
 
 class Gaussian(_Lik):
@@ -55,19 +62,12 @@ class Gaussian(_Lik):
     def kwargs(self):
         return {"sigma": self.sigma}
 
-    def samples(self, f, num_samples=1, Y_metadata=None):
-        return np.random.normal(loc=f, scale=self.sigma)   # gaussian.py:36-39
-
 
 class Bernoulli(_Lik):
     name = "Bernoulli"
 
     def __init__(self, gp_link=None):
         pass
-
-    def samples(self, f, num_samples=1, Y_metadata=None):
-        ef = _safe_exp(f)                                   # bernoulli.py:59-64
-        return np.random.binomial(n=1, p=np.clip(ef / (1 + ef), 1e-9, 1.0 - 1e-9))
 
 
 class HetGaussian(_Lik):
@@ -77,9 +77,6 @@ class HetGaussian(_Lik):
     def __init__(self, gp_link=None):
         pass
 
-    def samples(self, F, num_samples=1, Y_metadata=None):
-        return np.random.normal(loc=F[:, 0], scale=np.sqrt(_safe_exp(F[:, 1])))[:, None]   # hetgaussian.py:41-44
-
 
 class Poisson(_Lik):
     name = "Poisson"
@@ -87,18 +84,12 @@ class Poisson(_Lik):
     def __init__(self, gp_link=None):
         pass
 
-    def samples(self, f, num_samples=1, Y_metadata=None):
-        return np.random.poisson(lam=_safe_exp(f))         # poisson.py:51-54
-
 
 class Exponential(_Lik):
     name = "Exponential"
 
     def __init__(self, gp_link=None):
         pass
-
-    def samples(self, f, num_samples=1, Y_metadata=None):
-        return np.random.exponential(scale=np.clip(_safe_exp(-f), 1e-9, 1e9))   # exponential.py:52-56
 
 
 class Gamma(_Lik):
@@ -108,10 +99,6 @@ class Gamma(_Lik):
     def __init__(self, gp_link=None):
         pass
 
-    def samples(self, F, num_samples=1, Y_metadata=None):
-        eF = np.clip(_safe_exp(F), 1e-9, 1e9)              # gamma.py:43-50
-        return np.random.gamma(shape=eF[:, 0, None], scale=1.0 / eF[:, 1, None])
-
 
 class Beta(_Lik):
     name = "Beta"
@@ -119,10 +106,6 @@ class Beta(_Lik):
 
     def __init__(self, gp_link=None):
         pass
-
-    def samples(self, F, num_samples=1, Y_metadata=None):
-        eF = np.clip(_safe_exp(F), 1e-9, 1e9)              # beta.py:38-45
-        return np.random.beta(a=eF[:, 0, None], b=eF[:, 1, None])
 
 
 class Categorical(_Lik):
@@ -136,14 +119,6 @@ class Categorical(_Lik):
 
     def get_metadata(self):
         return 1, self.K - 1, self.K - 1                   # categorical.py:287-291
-
-    def samples(self, F, num_samples=1, Y_metadata=None):
-        eF = _safe_exp(F)                                   # categorical.py:65-75: labels 1..K
-        den = 1 + eF.sum(1)[:, None]
-        p = np.clip(np.hstack((eF / den, 1 / den)), 1e-9, 1 - 1e-9)
-        p = p / p.sum(1)[:, None]
-        u = np.random.rand(F.shape[0], 1)
-        return (1 + (u > np.cumsum(p, 1)).sum(1)).clip(1, self.K).astype(float)[:, None]
 
 
 class HetLikelihood(object):
@@ -175,7 +150,7 @@ class HetLikelihood(object):
         return [(l.name, l.kwargs()) for l in self.likelihoods_list]
 
     def samples(self, F, Y_metadata):
-        """het_likelihood.py:72-83: one draw per task from its likelihood (host-side data generation)."""
+        """het_likelihood.py:72-83: one draw per task from its likelihood, generated on the device."""
         return [l.samples(F[t], num_samples=1) for t, l in enumerate(self.likelihoods_list)]
 
     def var_exp(self, Y, mu_F, v_F, Y_metadata):

@@ -21,6 +21,102 @@ class Posterior(object):
         self.mean, self.woodbury_vector, self.woodbury_inv = mean, woodbury_vector, woodbury_inv
 
 
+class DeviceAdadelta(object):
+    """climin.Adadelta as `util.vem_algorithm` drives it (util.py:321-329: iteration protocol, `minimize_until`, info dict
+    with 1-based `n_iter`), with q(u) -- 98 % of the optimiser vector -- and its accumulators resident in HBM
+    (`hmogp_qu_load` / `hmogp_qu_adadelta`).  The few remaining free parameters (Z, variance, W, ...) follow the same
+    recurrence here on the host, in the optimiser's (Logexp) coordinates.  One iteration = the reference's
+    `stochastic_grad` (next contiguous minibatch, 4 E-steps then 1 M-step gating, svmogp.py:188-199) wrapped in the two
+    halves of the Adadelta update.  Iterates are bit-identical to `util.Adadelta(model.optimizer_array,
+    model.stochastic_grad, ...)`; `model.q_u_means` / `q_u_chols` are refreshed from the device when the loop ends
+    (`finish()`), not after every iteration."""
+
+    def __init__(self, model, step_rate=1.0, decay=0.9, momentum=0.0, offset=1e-4):
+        self.model = model
+        self.step_rate, self.decay, self.momentum, self.offset = step_rate, decay, momentum, offset
+        self.small = [p for _, p in model._named_params()
+                      if not p.is_fixed and p is not model.q_u_means and p is not model.q_u_chols]
+        parts = [logexp_finv(p.values.ravel()) if p.positive else p.values.ravel().copy() for p in self.small]
+        self.wrt = np.concatenate(parts) if parts else np.zeros(0)
+        self.gms, self.sms, self.step = (np.zeros_like(self.wrt) for _ in range(3))
+        self.n_iter = 0
+        model._engine.qu_load(model.q_u_means.values, model.q_u_chols.values)
+        model._qu_on_device = True
+
+    def _set_small(self):
+        i = 0
+        for p in self.small:
+            v = self.wrt[i:i + p.size].reshape(p.shape)
+            p[...] = logexp_f(v) if p.positive else v
+            i += p.size
+
+    def _small_gradient(self):
+        parts = []
+        for p in self.small:
+            g = np.asarray(p.gradient, dtype=float).ravel()
+            parts.append(g * logexp_gradfactor(p.values.ravel()) if p.positive else g)
+        return -np.concatenate(parts) if parts else np.zeros(0)
+
+    def __iter__(self):
+        m, eng = self.model, self.model._engine
+        try:
+            while True:
+                d, o, mom, rate = self.decay, self.offset, self.momentum, self.step_rate
+                step1 = self.step * mom                            # the operations of util.Adadelta, in its order
+                self.wrt -= step1
+                eng.qu_adadelta(0, rate, mom, d, o)
+                m.set_data(*m.new_batch())                         # stochastic_grad, svmogp.py:188-199
+                self._set_small()
+                m.parameters_changed()
+                g = self._small_gradient()
+                if m.vem_step:
+                    if m.ve_count > 2:
+                        m.ve_count, m.vem_step = 0, False
+                    else:
+                        m.ve_count += 1
+                else:
+                    m.vem_step = True
+                t1 = g * g
+                t1 *= (1 - d)
+                self.gms *= d
+                self.gms += t1
+                t1 = np.sqrt(self.sms + o)
+                t1 /= np.sqrt(self.gms + o)
+                t1 *= g
+                t1 *= rate
+                self.wrt -= t1
+                self.step = step1 + t1
+                t2 = self.step * self.step
+                t2 *= (1 - d)
+                self.sms *= d
+                self.sms += t2
+                eng.qu_adadelta(1, rate, mom, d, o)
+                self.n_iter += 1
+                yield dict(n_iter=self.n_iter, gradient=g, step=self.step)
+        finally:
+            self.finish()
+
+    def finish(self):
+        """Bring q(u) back into the model's parameter arrays (no re-evaluation: the device state is what the last
+        evaluation... preceded; the model is marked dirty so the next read of a derived quantity re-evaluates)."""
+        m = self.model
+        if getattr(m, "_qu_on_device", False):
+            mu, L = m._engine.qu_read()
+            np.asarray(m.q_u_means)[...] = mu
+            np.asarray(m.q_u_chols)[...] = L
+            m._qu_on_device = False
+            m._dirty = True
+
+    def minimize_until(self, criterion):
+        it = iter(self)
+        try:
+            for info in it:
+                if criterion(info):
+                    return info
+        finally:
+            it.close()
+
+
 class SVMOGP(object):
     def __init__(self, X, Y, Z, kern_list, likelihood, Y_metadata, name="SVMOGP", batch_size=None, W_list=None,
                  device=None, chunk_rows=0, exact_zero_windows=False, distributed=False, quirks="reference",
@@ -101,6 +197,7 @@ class SVMOGP(object):
         self.forced_rung = None
         self.last = None
         self._dirty = False
+        self._qu_on_device = False                # True while a DeviceAdadelta loop owns q(u) (host arrays stale)
         for _, prm in self._named_params():       # a direct write to any parameter marks the model dirty (paramz would
             prm.add_observer(self._mark_dirty)    # re-run parameters_changed() at once; here it happens lazily, on the
         self.parameters_changed()                 # next read of a derived quantity)
@@ -147,8 +244,9 @@ class SVMOGP(object):
         if self._dist is not None:
             hdist, reducer, rank, world = self._dist
             evaluate = lambda **kw: hdist.sharded_elbo_grad(self._engine, reducer, rank, world, **kw)  # noqa: E731
+        on_dev = self._qu_on_device
         out = evaluate(
-            Z=self.Z.values, m_u=self.q_u_means.values, L_flat=self.q_u_chols.values,
+            Z=self.Z.values, m_u=None if on_dev else self.q_u_means.values, L_flat=None if on_dev else self.q_u_chols.values,
             variance=[float(k.variance[0]) for k in self.kern_list],
             lengthscale=[float(k.lengthscale[0]) for k in self.kern_list],
             W=np.stack([np.ravel(B.W.values) for B in self.B_list]),
@@ -157,8 +255,9 @@ class SVMOGP(object):
             forced_rung=self.forced_rung, group_mask=mask)
         self.last = out
         self._log_marginal_likelihood = np.array([[out["elbo"]]])
-        self.q_u_means.gradient = out["g_m_u"]
-        self.q_u_chols.gradient = out["g_L_u"]
+        if not on_dev:                            # (device-resident q(u): its gradient stays in HBM for the optimiser)
+            self.q_u_means.gradient = out["g_m_u"]
+            self.q_u_chols.gradient = out["g_L_u"]
         for q, (k, B) in enumerate(zip(self.kern_list, self.B_list)):
             k.gradient = [out["g_variance"][q], out["g_lengthscale"][q]]
             B.gradient = np.hstack([out["g_W"][q], out["g_kappa"][q]])
@@ -210,6 +309,14 @@ class SVMOGP(object):
         else:
             self.vem_step = True
         return g
+
+    def device_adadelta(self, step_rate=1.0, decay=0.9, momentum=0.0, offset=1e-4):
+        """An Adadelta optimiser over `stochastic_grad` with q(u) and its accumulators resident in HBM (DeviceAdadelta),
+        or None when that does not apply (batch mode, q(u) fixed, row-sharded evaluation) -- callers then fall back to
+        `util.Adadelta(model.optimizer_array, model.stochastic_grad, ...)`, which produces the same iterates."""
+        if not self.stochastic or self._dist is not None or self.q_u_means.is_fixed or self.q_u_chols.is_fixed:
+            return None
+        return DeviceAdadelta(self, step_rate=step_rate, decay=decay, momentum=momentum, offset=offset)
 
     def callback(self, i, max_iter, verbose=True, verbose_plot=False):
         """svmogp.py:201-217."""

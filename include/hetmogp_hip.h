@@ -120,8 +120,8 @@ typedef struct {
 /* All model parameters of one evaluation: the arrays paramz hands to parameters_changed().             */
 typedef struct {
   const double* Z;            /* [M, Q*P]  block q = inducing inputs of u_q (svmogp.py:52)            */
-  const double* m_u;          /* [M, Q]    q_u_means                                                  */
-  const double* L_flat;       /* [M(M+1)/2, Q] q_u_chols, GPy row-major tril packing                  */
+  const double* m_u;          /* [M, Q]    q_u_means                  } both NULL: use the device-resident q(u)  */
+  const double* L_flat;       /* [M(M+1)/2, Q] q_u_chols, GPy row-major tril packing } (hmogp_qu_load / _adadelta) */
   const double* variance;     /* [Q]  RBF variance of k_q                                             */
   const double* lengthscale;  /* [Q]  RBF lengthscale of k_q                                          */
   const double* W;            /* [Q, Df] live coregionalisation weights  B_list[q].W                  */
@@ -203,6 +203,24 @@ int hmogp_predict_f(hmogp_handle h, const double* Xnew, int64_t Nnew, double* m,
  * the step leaves the positive-definite cone.  Invalidates posterior_u / predict_f until the next evaluation.   */
 int hmogp_natgrad_step(hmogp_handle h, double gamma, double* m_u_new, double* L_flat_new);
 
+/* ---- device-resident q(u) and its Adadelta state: the SVI loop without moving 2 x 12.6 MB per iteration ------ */
+/* The reference's stochastic driver (util.py:321-329) runs climin.Adadelta over the flat optimiser vector, 98 % of which
+ * is q(u) (m_u, L_u: 1.58 M numbers at M = 1024, Q = 3); its gradient is svmogp.py:188-199 (stochastic_grad).  These
+ * entry points keep q(u), its gradient and the three Adadelta accumulators in HBM; the caller runs the same recurrence
+ * on the few remaining parameters (Z, variance, W ...) on the host.  The device recurrence performs the same IEEE
+ * operations in the same order as the host one, so the iterates are bit-identical.
+ *   hmogp_qu_load      upload q(u) (zeroes the accumulators); evaluations with params.m_u = params.L_flat = NULL use it,
+ *                      outputs.g_m_u / g_L_u may then be NULL (nothing is copied back)
+ *   hmogp_qu_adadelta  phase 0: step1 = momentum * step; q(u) -= step1                 (before the gradient evaluation)
+ *                      phase 1: gms = d gms + (1-d) g^2; step2 = sqrt(sms+o)/sqrt(gms+o) g rate; q(u) -= step2;
+ *                               step = step1 + step2; sms = d sms + (1-d) step^2       with g = -dELBO/dq(u) of the last
+ *                               evaluation, or 0 if its group_mask excluded HMOGP_GROUP_QU (the M-steps of svmogp.py:196)
+ *   hmogp_qu_read      download the current q(u)                                                                  */
+int hmogp_qu_load(hmogp_handle h, const double* m_u, const double* L_flat);
+int hmogp_qu_read(hmogp_handle h, double* m_u, double* L_flat);
+int hmogp_qu_adadelta(hmogp_handle h, int32_t phase, double step_rate, double momentum, double decay,
+                      double one_minus_decay, double offset);
+
 /* ---- timing --------------------------------------------------------------------------------------- */
 /* Milliseconds the kernels of the last evaluation spent, measured with HIP events on the engine's stream:
  * out[0] whole evaluation, [1] K_uf construction (rbf_cross_cov; + window kernels in the opt-in mode), [2] forward
@@ -262,6 +280,13 @@ int hmogp_predictive(int32_t device, int32_t lik_id, double lik_param, int32_t g
  * tasks -- done by the caller.  Defined for Gaussian, Bernoulli, HetGaussian, Poisson, Exponential, Categorical.   */
 int hmogp_log_predictive(int32_t device, int32_t lik_id, double lik_param, int64_t N, int32_t num_samples, uint64_t seed,
                          const double* y, const double* m, const double* v, double* log_pred);
+
+/* Data generation on the device: one draw Y[n] ~ p(y | F[n, :]) per row with the link functions and clips of the
+ * reference's `<likelihood>.samples` (het_likelihood.py:72-83 -> e.g. gamma.py:43-50, categorical.py:65-75; labels of
+ * Categorical are 1..K).  Counter-based generator keyed by (seed, row): reproducible, but a different stream than
+ * NumPy's -- only the distribution is comparable with the reference.                                             */
+int hmogp_sample(int32_t device, int32_t lik_id, double lik_param, int64_t N, uint64_t seed, const double* F /* [N, dim_f] */,
+                 double* Y /* [N] */);
 
 /* Micro-benchmark of the two row-pass contractions on synthetic operands resident in HBM (tools/bench_gemm.py):
  * role 1: forward  P~[n,M] = K^[n,M] C[M,M];  role 2: weighted Gram  H[M,M] (lower tiles) = K^T diag(beta) K^ incl. the

@@ -214,3 +214,80 @@ def test_vem_converges_higher_with_exact_gradients():
         else:      # compare like with like: the ELBO of the reference-mode optimum (Q2 does not change the ELBO itself)
             elbo[mode] = float(model.log_likelihood()[0, 0])
     assert np.isfinite(elbo["exact"]) and elbo["exact"] > elbo["reference"]
+
+
+# ------------------------------------------------------------------------------------------------ f4: device samples
+SAMPLE_CASES = [("Gaussian", {"sigma": 0.7}), ("Bernoulli", {}), ("HetGaussian", {}), ("Poisson", {}), ("Exponential", {}),
+                ("Gamma", {}), ("Beta", {}), ("Categorical", {"K": 4})]
+
+
+@pytest.mark.parametrize("name,kw", SAMPLE_CASES, ids=[c[0] for c in SAMPLE_CASES])
+def test_device_samples_have_the_reference_distribution(name, kw):
+    """hmogp_sample (the reference's `<likelihood>.samples`, e.g. gamma.py:43-50, categorical.py:65-75): the generator is a
+    different stream than NumPy's, so the test is statistical -- per distinct f, 40 000 draws must reproduce the mean and
+    variance the reference's link functions imply (5 sigma of the Monte-Carlo error), plus the supports."""
+    from hetmogp_amd import engine as E
+    J = E.lik_dim_f(name, **kw)
+    S = 40000
+    rng = np.random.RandomState(11)
+    fs = [rng.uniform(-1.5, 1.5, J) for _ in range(4)]
+    if name == "Poisson":
+        fs += [np.array([3.5]), np.array([6.0])]                      # lambda = 33 and 403: the PTRS branch
+    for f in fs:
+        F = np.tile(f[None, :], (S, 1))
+        y = E.sample(name, F, seed=int(rng.randint(1 << 30)), **kw)
+        assert y.shape == (S, 1) and np.all(np.isfinite(y))
+        y = y[:, 0]
+        ef = np.exp(f)
+        if name == "Gaussian":
+            mean, var = f[0], kw["sigma"] ** 2
+        elif name == "Bernoulli":
+            p = ef[0] / (1 + ef[0])
+            mean, var = p, p * (1 - p)
+            assert set(np.unique(y)) <= {0.0, 1.0}
+        elif name == "HetGaussian":
+            mean, var = f[0], ef[1]
+        elif name == "Poisson":
+            mean, var = ef[0], ef[0]
+            assert np.all(y >= 0) and np.all(y == np.floor(y))
+        elif name == "Exponential":
+            mean, var = np.exp(-f[0]), np.exp(-2 * f[0])              # scale = exp(-f) (exponential.py:52-56)
+            assert np.all(y > 0)
+        elif name == "Gamma":
+            mean, var = ef[0] / ef[1], ef[0] / ef[1] ** 2             # shape a = e^f1, rate b = e^f2 (gamma.py:43-50)
+            assert np.all(y > 0)
+        elif name == "Beta":
+            a, b = ef
+            mean, var = a / (a + b), a * b / ((a + b) ** 2 * (a + b + 1))
+            assert np.all((y > 0) & (y < 1))
+        else:
+            K = kw["K"]
+            p = np.append(ef, 1.0) / (1 + ef.sum())
+            assert set(np.unique(y)) <= set(float(k) for k in range(1, K + 1))      # labels 1..K (categorical.py:81)
+            freq = np.array([(y == k + 1).mean() for k in range(K)])
+            assert np.all(np.abs(freq - p) < 5 * np.sqrt(p * (1 - p) / S) + 1e-4)
+            continue
+        m4 = max(3.0 * var ** 2, 1e-12)                                 # crude bound on the 4th central moment
+        assert abs(y.mean() - mean) < 5 * np.sqrt(var / S) + 1e-12, (name, f, y.mean(), mean)
+        assert abs(y.var() - var) < 8 * np.sqrt(m4 / S) * (4 if name in ("Exponential", "Gamma", "Poisson") else 1), (name, f)
+
+
+def test_device_samples_are_reproducible_per_seed():
+    from hetmogp_amd import engine as E
+    F = np.linspace(-1, 1, 64)[:, None]
+    a, b, c = E.sample("Poisson", F, seed=5), E.sample("Poisson", F, seed=5), E.sample("Poisson", F, seed=6)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+def test_het_likelihood_samples_run_on_the_device():
+    import hetmogp_amd as H
+    lik = H.HetLikelihood([H.Gaussian(sigma=0.5), H.Categorical(3), H.Gamma()])
+    md = lik.generate_metadata()
+    rng = np.random.RandomState(0)
+    F = [rng.randn(50, 1), rng.randn(50, 2), 0.3 * rng.randn(50, 2)]
+    np.random.seed(4)
+    Y1 = lik.samples(F, md)
+    np.random.seed(4)
+    Y2 = lik.samples(F, md)
+    assert [y.shape for y in Y1] == [(50, 1)] * 3 and all(np.array_equal(a, b) for a, b in zip(Y1, Y2))
+    assert set(np.unique(Y1[1])) <= {1.0, 2.0, 3.0} and np.all(Y1[2] > 0)

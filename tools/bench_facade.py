@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Wall time of the reference-surface SVI loop (SVMOGP.stochastic_grad + Adadelta update) at the C3 size:
-python tools/bench_facade.py [rows_per_task] [M] [batch]"""
+"""Wall time of the SVI training loop (SVMOGP.stochastic_grad + Adadelta update) at the C3 size:
+python tools/bench_facade.py [rows_per_task] [M] [batch] [device|host]"""
 import os
 import sys
 import time
@@ -28,8 +28,11 @@ model[".*.lengthscale"].fix()      # as util.vem_algorithm does (util.py:284-331
 model[".*.kappa"].fix()
 model.Z.fix()                       # optZ=False: 1024 inducing points one lengthscale apart do not survive raw SGD moves
 model.stochastic = True
-x = model.optimizer_array
-opt = Adadelta(x, model.stochastic_grad, step_rate=0.005, momentum=0.9)
+mode = sys.argv[4] if len(sys.argv) > 4 else "device"
+if mode == "device":    # q(u) and its Adadelta accumulators resident in HBM (bit-identical iterates, tests/test_facade_gpu.py)
+    opt = model.device_adadelta(step_rate=0.005, momentum=0.9)
+else:                   # the reference-surface loop: climin-style Adadelta over model.optimizer_array on the host
+    opt = Adadelta(model.optimizer_array, model.stochastic_grad, step_rate=0.005, momentum=0.9)
 it = iter(opt)
 for _ in range(6):
     next(it)
@@ -38,7 +41,7 @@ K = 20
 for _ in range(K):
     next(it)
 dt = (time.perf_counter() - t0) / K
-print("SVI iteration (new batch + gradient + Adadelta update) N=%d M=%d batch=%d: %.2f ms  ELBO %.6g" %
-      (N, M, B, 1e3 * dt, float(model.log_likelihood()[0, 0])))
+print("SVI iteration [%s optimiser] (new batch + gradient + Adadelta update) N=%d M=%d batch=%d: %.2f ms = %.1f ELBO-steps/s of "
+      "the training loop  ELBO %.6g" % (mode, N, M, B, 1e3 * dt, 1.0 / dt, float(model._log_marginal_likelihood[0, 0])))
 ms, _ = model._engine.timings() if hasattr(model, "_engine") else ({}, {})
 print({k: round(v, 2) for k, v in ms.items()})
