@@ -109,7 +109,8 @@ void launch_gemm_f64(const GemmArgs& g, hipStream_t stream);
 // ---- linear algebra on Q x M x M batches (linalg.hip) ---------------------------------------------------
 // In-place lower Cholesky of A[q]; info[q] = 0 or the 1-based index of the first non-positive pivot (LAPACK
 // dpotrf convention; the matrix content is then undefined). Upper triangle is zeroed. dscr: Q*M*M doubles (out-of-place factor).
-void launch_potrf_batched(double* A, int Q, int M, int* d_info, double* dscr, hipStream_t stream);
+void launch_potrf_batched(double* A, int Q, int M, int* d_info, double* dscr, hipStream_t stream, int panel_begin = 0,
+                          int panel_end = -1);
 // Linv[q] = L[q]^-1 (lower triangular, upper zero). `L` is preserved; tmp: Q*M*M doubles.
 void launch_trtri_batched(const double* L, double* Linv, double* tmp, int Q, int M, hipStream_t stream);
 // Out[q] = Linv[q]^T Linv[q]  (= (L L^T)^-1), full symmetric.

@@ -102,24 +102,49 @@ int gram_ksplit(long long n, int M) {
 // Luu <- chol(Kuu + jitter I) with GPy's ladder (GPy.util.linalg.jitchol): plain factorisation first, then
 // jitter = mean(diag) * 1e-6 * 10^k, k = 0..4.  diag(K_uu) == variance for the RBF, so mean(diag) = variance.
 // rung_io[q]: in  -2 = search, -1 / k = forced;  out = rung taken.
-void jitchol_batched(const double* Kuu, double* Luu, int Q, int M, const double* diag_mean, int* rung_io, int* d_info,
-                     double* d_jit, double* dscr, hipStream_t st) {
-  std::vector<double> jit(Q, 0.0);
-  std::vector<int> forced(Q), info(Q);
-  for (int q = 0; q < Q; ++q) {
-    forced[q] = rung_io[q] != -2;
-    if (rung_io[q] >= 0) jit[q] = diag_mean[q] * 1e-6 * std::pow(10.0, rung_io[q]);
-    if (!forced[q]) rung_io[q] = -1;
+// Two halves so that the caller can enqueue other (independent) work between the asynchronous part and the one host
+// synchronisation of the path (the ladder decision).
+struct JitcholState {
+  std::vector<double> jit;
+  std::vector<int> forced, info_own;
+  bool complete = false;       // every panel has been enqueued
+  int* info = nullptr;         // where the device's info lands: PAGE-LOCKED memory when the caller provides it (a D2H copy
+                               // into pageable memory blocks the host until the stream has drained, which would serialise
+                               // everything the caller wants to enqueue behind the factorisation)
+};
+// part 0: set-up + the first `head` panels; part 1: the remaining panels + the info read-back; part -1: everything
+constexpr int JIT_HEAD_PANELS = 12;
+void jitchol_enqueue(const double* Kuu, double* Luu, int Q, int M, const double* diag_mean, int* rung_io, int* d_info,
+                     double* d_jit, double* dscr, hipStream_t st, JitcholState& js, int part = -1) {
+  if (part == 1) {
+    launch_potrf_batched(Luu, Q, M, d_info, dscr, st, JIT_HEAD_PANELS, -1);
+    HIP_TRY(hipMemcpyAsync(js.info, d_info, sizeof(int) * Q, hipMemcpyDeviceToHost, st));
+    return;
   }
-  HIP_TRY(hipMemcpyAsync(d_jit, jit.data(), sizeof(double) * Q, hipMemcpyHostToDevice, st));
+  js.jit.assign(Q, 0.0), js.forced.resize(Q);
+  if (!js.info) js.info_own.assign(Q, 0), js.info = js.info_own.data();
+  for (int q = 0; q < Q; ++q) {
+    js.forced[q] = rung_io[q] != -2;
+    if (rung_io[q] >= 0) js.jit[q] = diag_mean[q] * 1e-6 * std::pow(10.0, rung_io[q]);
+    if (!js.forced[q]) rung_io[q] = -1;
+  }
+  HIP_TRY(hipMemcpyAsync(d_jit, js.jit.data(), sizeof(double) * Q, hipMemcpyHostToDevice, st));
   launch_add_diag_copy(Kuu, Luu, Q, M, d_jit, st);
+  if (part == 0 && (M + HMOGP_POTRF_NB - 1) / HMOGP_POTRF_NB > JIT_HEAD_PANELS) {
+    launch_potrf_batched(Luu, Q, M, d_info, dscr, st, 0, JIT_HEAD_PANELS);
+    return;
+  }
   launch_potrf_batched(Luu, Q, M, d_info, dscr, st);
-  HIP_TRY(hipMemcpyAsync(info.data(), d_info, sizeof(int) * Q, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(js.info, d_info, sizeof(int) * Q, hipMemcpyDeviceToHost, st));
+  js.complete = true;
+}
+void jitchol_resolve(const double* Kuu, double* Luu, int Q, int M, const double* diag_mean, int* rung_io, int* d_info,
+                     double* d_jit, double* dscr, hipStream_t st, JitcholState& js) {
   HIP_TRY(hipStreamSynchronize(st));
   const long long MM = (long long)M * M;
   for (int q = 0; q < Q; ++q) {
-    if (info[q] == 0) continue;
-    if (forced[q]) throw EngineError{HMOGP_E_NOT_PD, "Cholesky failed at the forced jitter rung"};
+    if (js.info[q] == 0) continue;
+    if (js.forced[q]) throw EngineError{HMOGP_E_NOT_PD, "Cholesky failed at the forced jitter rung"};
     if (!(diag_mean[q] > 0.0)) throw EngineError{HMOGP_E_NOT_PD, "not pd: non-positive diagonal elements"};
     double j = diag_mean[q] * 1e-6;
     bool ok = false;
@@ -138,6 +163,12 @@ void jitchol_batched(const double* Kuu, double* Luu, int Q, int M, const double*
     }
     if (!ok) throw EngineError{HMOGP_E_NOT_PD, "not positive definite, even with jitter."};
   }
+}
+void jitchol_batched(const double* Kuu, double* Luu, int Q, int M, const double* diag_mean, int* rung_io, int* d_info,
+                     double* d_jit, double* dscr, hipStream_t st) {
+  JitcholState js;
+  jitchol_enqueue(Kuu, Luu, Q, M, diag_mean, rung_io, d_info, d_jit, dscr, st, js);
+  jitchol_resolve(Kuu, Luu, Q, M, diag_mean, rung_io, d_info, d_jit, dscr, st, js);
 }
 
 }  // namespace
@@ -172,6 +203,7 @@ struct hmogp_engine {
   DevBuf Kh, Pt, vp, vc, vpt, vct, valpha, vbeta, valpha0, vbeta0;
   DevBuf stats, wire, slabs, colpart, quadpart, fwdpart, winrow, wincol, winhit, Xws, dstage;
   long long nwire = 0;  // float64 words of the wire format (lower triangles of H_q only; rowpass.hip: wire_tri_kernel)
+  int* h_info = nullptr;     // page-locked landing buffer of the factorisation's info flags
   double* hstage = nullptr;  // page-locked landing buffer of the small per-evaluation results
   size_t hstage_cap = 0;
   bool began = false, evaluated = false;
@@ -190,8 +222,10 @@ struct hmogp_engine {
   double ms[NCAT] = {0};
   long long launches[NCAT] = {0};
   hipEvent_t ev_begin0 = nullptr, ev_begin1 = nullptr, ev_fin0 = nullptr, ev_fin1 = nullptr;
-  hipStream_t st2 = nullptr;  // second stream: the q(u)-only chain of u_algebra
-  hipEvent_t ev_fork = nullptr, ev_S = nullptr, ev_join = nullptr, ev_col = nullptr, ev_kuf = nullptr;
+  hipStream_t st2 = nullptr;  // second stream, LOW priority: bandwidth-bound work beside the main stream (K_uf prefetch, colstats)
+  hipStream_t st3 = nullptr;  // third stream, HIGH priority like the main one: the q(u)-only chains (S, S^-1; dL/dL, D2H)
+  hipEvent_t ev_fork = nullptr, ev_S = nullptr, ev_join = nullptr, ev_col = nullptr, ev_kuf = nullptr, ev_params = nullptr,
+             ev_ua = nullptr;
 
   hipEvent_t new_event() {
     if (pool_used == pool.size()) {
@@ -228,10 +262,13 @@ struct hmogp_engine {
 
   ~hmogp_engine() {
     for (auto e : pool) (void)hipEventDestroy(e);
-    for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_S, ev_join, ev_col, ev_kuf})
+    for (auto e : ev_seg) (void)hipEventDestroy(e);
+    for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_S, ev_join, ev_col, ev_kuf, ev_params, ev_ua})
       if (e) (void)hipEventDestroy(e);
     if (hstage) (void)hipHostFree(hstage);
+    if (h_info) (void)hipHostFree(h_info);
     if (st2) (void)hipStreamDestroy(st2);
+    if (st3) (void)hipStreamDestroy(st3);
     if (st) (void)hipStreamDestroy(st);
   }
 
@@ -265,8 +302,10 @@ struct hmogp_engine {
       HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
       HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
       HIP_TRY(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, lo));
+      HIP_TRY(hipStreamCreateWithPriority(&st3, hipStreamNonBlocking, hi));
     }
-    for (hipEvent_t* e : {&ev_fork, &ev_S, &ev_join, &ev_col, &ev_kuf}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t* e : {&ev_fork, &ev_S, &ev_join, &ev_col, &ev_kuf, &ev_params, &ev_ua})
+      HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (hipEvent_t* e : {&ev_begin0, &ev_begin1, &ev_fin0, &ev_fin1}) HIP_TRY(hipEventCreate(e));
     f_index.assign(c->f_index, c->f_index + Df);
     d_index.assign(c->d_index, c->d_index + Df);
@@ -396,16 +435,17 @@ struct hmogp_engine {
     if (!resident) HIP_TRY(hipMemcpyAsync(dmu.p, p->m_u, sizeof(double) * M * Q, hipMemcpyHostToDevice, st));
     // the one large parameter (12.6 MB at M = 1024, Q = 3) goes up on the second stream, whose chain is its only consumer
     // (u_algebra): the K_uu chain on the main stream starts without waiting for it
-    if (!resident) HIP_TRY(hipMemcpyAsync(dLflat.p, p->L_flat, sizeof(double) * Mtri * Q, hipMemcpyHostToDevice, st2));
+    if (!resident) HIP_TRY(hipMemcpyAsync(dLflat.p, p->L_flat, sizeof(double) * Mtri * Q, hipMemcpyHostToDevice, st3));
     HIP_TRY(hipMemcpyAsync(dvar.p, h_var.data(), sizeof(double) * Q, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dell.p, h_ell.data(), sizeof(double) * Q, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dW.p, h_W.data(), sizeof(double) * Q * Df, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dkap.p, h_kap.data(), sizeof(double) * Q * Df, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(ev_params, st));   // what the second stream has to wait for before it reads Z / the hypers
   }
 
   // batched (over q) M x M GEMM helper
   void mm(const double* A, bool a_k, const double* B, bool b_k, double* Cc, double alpha = 1.0, long long sA = -1,
-          int lda = -1, hipStream_t stream = nullptr, int a_tri = 0, int b_tri = 0) {
+          int lda = -1, hipStream_t stream = nullptr, int a_tri = 0, int b_tri = 0, bool lower_only = false) {
     GemmArgs g;
     const long long MM = (long long)M * M;
     g.A = A, g.B = B, g.C = Cc;
@@ -416,6 +456,7 @@ struct hmogp_engine {
     g.a_kmajor = a_k, g.b_kmajor = b_k;
     g.alpha = alpha;
     g.a_tri = a_tri, g.b_tri = b_tri;
+    g.lower_only = lower_only ? 1 : 0;
     launch_gemm_f64(g, stream ? stream : st);
   }
 
@@ -430,23 +471,9 @@ struct hmogp_engine {
     // them on every call (util.py:181-200); the result is the same.
     // The chain that only depends on q(u)'s factor -- L, S = L L^T, S^-1 -- runs on a second stream, concurrently with
     // the (latency-bound, few-CU) factorisation and inversion of K_uu; scratch: HK, G (unused before hmogp_step_finish).
-    HIP_TRY(hipEventRecord(ev_fork, st));
-    HIP_TRY(hipStreamWaitEvent(st2, ev_fork, 0));
-    launch_unpack_tril(dLflat.d(), L.d(), Q, M, st2);             // flat_to_triang   (svmogp_inf.py:193)
-    mm(L.d(), false, L.d(), false, S.d(), 1.0, -1, -1, st2, +1, -1);  // S = L L^T    (:194-195), L lower
-    HIP_TRY(hipEventRecord(ev_S, st2));
-    launch_trtri_batched(L.d(), HK.d(), G.d(), Q, M, st2);        // S^-1 = dpotri(L) (svmogp_inf.py:124)
-    launch_ltl_batched(HK.d(), Sqi.d(), Q, M, st2);
-    HIP_TRY(hipEventRecord(ev_join, st2));
-    // K_uf of the first pool only needs X, Z and the kernel hyper-parameters: it goes on the second (low-priority) stream
-    // behind the q(u) chain and overlaps the K_uu chain -- bandwidth-bound work filling the CUs that the latency-bound
-    // launches of the high-priority main stream leave idle.  (With equal priorities the Cholesky's 32 dependent launches
-    // starve behind a kernel that fills every CU.)
-    if (!pools.empty()) {
-      kuf_pool(pools[0], st2);
-      HIP_TRY(hipEventRecord(ev_kuf, st2));
-      kuf_prefetched = true;
-    }
+    // Launch order on the host = critical path first: the K_uu chain (covariance, 32 dependent factorisation launches) is
+    // enqueued before anything else, so that the device starts on it while the host is still enqueueing the q(u) chain and
+    // the K_uf prefetch on the second stream (enqueued the other way round, the chain used to start ~0.35 ms late).
     std::vector<double> key;
     if (cache_kuu) {
       key.assign(h_Z.begin(), h_Z.end());
@@ -454,14 +481,44 @@ struct hmogp_engine {
       key.insert(key.end(), h_ell.begin(), h_ell.end());
       for (int q = 0; q < Q; ++q) key.push_back((double)rung_request[q]);
     }
-    if (cache_kuu && kuu_key_valid && key.size() == kuu_key.size() &&
-        std::memcmp(key.data(), kuu_key.data(), sizeof(double) * key.size()) == 0) {
+    const bool kuu_hit = cache_kuu && kuu_key_valid && key.size() == kuu_key.size() &&
+                         std::memcmp(key.data(), kuu_key.data(), sizeof(double) * key.size()) == 0;
+    JitcholState js;
+    if (!h_info) HIP_TRY(hipHostMalloc((void**)&h_info, sizeof(int) * HMOGP_MAXQ, hipHostMallocDefault));
+    js.info = h_info;
+    if (kuu_hit) {
       rung = kuu_rung;
     } else {
       kuu_key_valid = false;
-      for (int q = 0; q < Q; ++q)  // K_uu: both arguments passed (util.py:197) -> no forced diagonal
-        launch_rbf(dZ.d() + q * P, ldz, M, P, dZ.d() + q * P, ldz, M, h_var[q], h_ell[q], Kuu.d() + q * MM, false, st);
-      jitchol_batched(Kuu.d(), Luu.d(), Q, M, h_var.data(), rung.data(), dinfo.as<int>(), djit.d(), dscr.d(), st);
+      RbfBatch kb;  // K_uu of all latents in one launch; both arguments passed (util.py:197) -> no forced diagonal
+      kb.nq = Q, kb.var = dvar.d(), kb.ell = dell.d(), kb.sZ = P, kb.sX = P, kb.sK = MM;
+      launch_rbf(dZ.d(), ldz, M, P, dZ.d(), ldz, M, 0.0, 1.0, Kuu.d(), false, st, nullptr, true, &kb);
+      jitchol_enqueue(Kuu.d(), Luu.d(), Q, M, h_var.data(), rung.data(), dinfo.as<int>(), djit.d(), dscr.d(), st, js, 0);
+    }
+    // (only the first panels of the factorisation are enqueued at this point -- enough device work to cover the host time
+    // of the launches below; the rest follows them)
+    // K_uf of the first pool only needs X, Z and the kernel hyper-parameters: it is built on the low-priority second
+    // stream beside the latency-bound chains.  Its exp() work and the matrix cores share the FP64 pipe (tools/probes/
+    // probe_coissue.hip), so hiding it behind the forward contraction gains nothing -- the chains, which need neither,
+    // are the one place where it is free.
+    HIP_TRY(hipStreamWaitEvent(st2, ev_params, 0));
+    if (!pools.empty()) {
+      kuf_pool(pools[0], st2);
+      HIP_TRY(hipEventRecord(ev_kuf, st2));
+      kuf_prefetched = true;
+    }
+    // The q(u) chain goes to a stream of the SAME (high) priority as the main one: on the low-priority stream it would
+    // not be dispatched before the 32 back-to-back factorisation launches of the main stream have drained.
+    launch_unpack_tril(dLflat.d(), L.d(), Q, M, st3);             // flat_to_triang   (svmogp_inf.py:193)
+    mm(L.d(), false, L.d(), false, S.d(), 1.0, -1, -1, st3, +1, -1);  // S = L L^T    (:194-195), L lower
+    HIP_TRY(hipEventRecord(ev_S, st3));
+    launch_trtri_batched(L.d(), HK.d(), G.d(), Q, M, st3);        // S^-1 = dpotri(L) (svmogp_inf.py:124)
+    launch_ltl_batched(HK.d(), Sqi.d(), Q, M, st3);
+    HIP_TRY(hipEventRecord(ev_join, st3));
+    if (!kuu_hit && !js.complete)
+      jitchol_enqueue(Kuu.d(), Luu.d(), Q, M, h_var.data(), rung.data(), dinfo.as<int>(), djit.d(), dscr.d(), st, js, 1);
+    if (!kuu_hit) {
+      jitchol_resolve(Kuu.d(), Luu.d(), Q, M, h_var.data(), rung.data(), dinfo.as<int>(), djit.d(), dscr.d(), st, js);
       launch_trtri_batched(Luu.d(), tmpA.d(), tmpB.d(), Q, M, st);
       launch_ltl_batched(tmpA.d(), Kuui.d(), Q, M, st);             // K_uu^-1          (util.py:199)
       if (cache_kuu) kuu_key.swap(key), kuu_rung = rung, kuu_key_valid = true;
@@ -473,6 +530,11 @@ struct hmogp_engine {
     launch_sub(KSK.d(), Kuui.d(), C.d(), MM * Q, st);             // C = K^-1 S K^-1 - K^-1
     launch_tri_fold(C.d(), Ctri.d(), Q, M, st);                   // x^T Ctri x == x^T C x with a triangular matrix
     HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));
+    // the KL terms (svmogp_inf.py:227-250) only need what exists now: they run on the second stream beside the row pass
+    // instead of sitting in the tail of hmogp_step_finish
+    HIP_TRY(hipEventRecord(ev_ua, st));
+    HIP_TRY(hipStreamWaitEvent(st3, ev_ua, 0));
+    launch_kl_terms(Kuui.d(), S.d(), dmu.d(), a.d(), Luu.d(), L.d(), Sqi.d(), Q, M, klout.d(), st3);
   }
 
   // ------------------------------------------------------------------------------------------ row pools
@@ -486,6 +548,16 @@ struct hmogp_engine {
   struct Seg { int t; long long r0, n, off; };
   std::vector<std::vector<Seg>> pools;
   bool kuf_prefetched = false;
+  std::vector<hipEvent_t> ev_seg;   // K_uf of segment i of the prefetched pool is complete
+  // A segment gets its own forward launch when it is large enough to fill the device by itself: the forward contraction of
+  // segment i then only waits for K_uf of segment i, and the (HBM-bound) construction of the later segments hides behind it.
+  static constexpr long long SEG_FORWARD_MIN_ROWS = 32768;
+  static constexpr long long KUF_CHUNK_ROWS = 16384;
+  bool seg_forward(const std::vector<Seg>& pl) const {
+    bool per_seg = !use_windows && pl.size() > 1;
+    for (auto& sg : pl) per_seg = per_seg && sg.n >= SEG_FORWARD_MIN_ROWS;
+    return per_seg;
+  }
   void plan_pools() {
     pools.clear();
     kuf_prefetched = false;
@@ -504,13 +576,16 @@ struct hmogp_engine {
     ensure_workspace(maxrows);
   }
   // K_uf = k_q(X, Z_q) of one pool, all latents in one launch per segment (grid.z = latent), on `stream`
-  void kuf_pool(const std::vector<Seg>& pl, hipStream_t stream) {
+  void kuf_pool(const std::vector<Seg>& pl, hipStream_t stream, size_t seg_begin = 0, size_t seg_end = (size_t)-1) {
     const int ldz = Q * P, ncb = (M + 127) / 128;
     const long long wtiles = (ws_rows + 127) / 128, sK = ws_rows * M;
     int* rw = use_windows ? winrow.as<int>() : nullptr;    // [Q][wtiles][2]
     int* cw = use_windows ? wincol.as<int>() : nullptr;    // [Q][ncb][2]
-    Scope sc(this, CAT_RBF, (int)pl.size() + (use_windows ? 3 * Q : 0), stream);
-    for (auto& sg : pl) {
+    seg_end = std::min(seg_end, pl.size());
+    if (seg_begin >= seg_end) return;
+    Scope sc(this, CAT_RBF, (int)(seg_end - seg_begin) + (use_windows ? 3 * Q : 0), stream);
+    for (size_t si = seg_begin; si < seg_end; ++si) {
+      const Seg& sg = pl[si];
       const double* Xs = tasks[sg.t].X.d() + sg.r0 * P;
       if (use_windows)
         for (int q = 0; q < Q; ++q)
@@ -518,7 +593,22 @@ struct hmogp_engine {
                          winhit.as<unsigned char>(), stream);
       RbfBatch rbt;
       rbt.nq = Q, rbt.var = dvar.d(), rbt.ell = dell.d(), rbt.sZ = P, rbt.sK = sK, rbt.sWin = 2 * wtiles;
-      launch_rbf(Xs, P, sg.n, P, dZ.d(), ldz, M, 0.0, 1.0, Kh.d() + sg.off * M, false, stream, rw, false, &rbt);
+      // On the side stream the construction is cut into launches of KUF_CHUNK_ROWS rows (~70 us each): a kernel that fills
+      // every CU for a millisecond stalls every launch of the latency-bound chains on the other streams until it has
+      // drained (stream priorities notwithstanding); between short launches they slip in.
+      const long long step = (stream != st && !use_windows) ? KUF_CHUNK_ROWS : sg.n;
+      for (long long r = 0; r < sg.n; r += step)
+        launch_rbf(Xs + r * P, P, std::min(step, sg.n - r), P, dZ.d(), ldz, M, 0.0, 1.0, Kh.d() + (sg.off + r) * M, false, stream,
+                   rw, false, &rbt);
+      if (stream != st) {            // prefetch on another stream: one completion event per segment
+        const size_t i = si;
+        while (ev_seg.size() <= i) {
+          hipEvent_t e;
+          HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+          ev_seg.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(ev_seg[i], stream));
+      }
     }
   }
 
@@ -546,35 +636,43 @@ struct hmogp_engine {
                                  hipMemcpyDeviceToDevice, st));
         X = Xws.d();
       }
-      if (&pl == &pools[0] && kuf_prefetched)
-        HIP_TRY(hipStreamWaitEvent(st, ev_kuf, 0));          // built on the second stream beside the tail of the K_uu chain
-      else
-        kuf_pool(pl, st);
-      {
-        // forward contraction for all latents (batched), row statistics fused into its epilogue; P~ itself is only
-        // stored when the Z gradient (its one remaining consumer, colstats) is requested
-        const long long sPart = 8LL * tiles * ldn;
+      const bool prefetched = &pl == &pools[0] && kuf_prefetched;
+      if (!prefetched) kuf_pool(pl, st);
+      // Forward contraction for all latents (batched), row statistics fused into its epilogue; P~ itself is only stored
+      // when the Z gradient (its one remaining consumer, colstats) is requested.  One launch per pool -- or one per
+      // segment when every segment is large (see SEG_FORWARD_MIN_ROWS).
+      const bool per_seg = seg_forward(pl);
+      const long long sPart = 8LL * tiles * ldn;
+      const size_t nlaunch = per_seg ? pl.size() : 1;
+      for (size_t li = 0; li < nlaunch; ++li) {
+        const long long off = per_seg ? pl[li].off : 0, rows = per_seg ? pl[li].n : n;
+        if (prefetched) {
+          if (!per_seg)
+            HIP_TRY(hipStreamWaitEvent(st, ev_kuf, 0));
+          else
+            HIP_TRY(hipStreamWaitEvent(st, ev_seg[li], 0));
+        }
         {
           Scope sc(this, CAT_FWD, 1);
           GemmArgs g;
-          g.A = Kh.d(), g.lda = M, g.a_kmajor = 0, g.sA = sK;
+          g.A = Kh.d() + off * M, g.lda = M, g.a_kmajor = 0, g.sA = sK;
           // only the quadratic forms are wanted when neither the hyper-parameter nor the Z gradients are (SVI / VEM
           // E-steps): the triangular fold of C gives them with half the products
           const bool tri = !want_hyper && !want_z;
           g.B = tri ? Ctri.d() : C.d(), g.ldb = M, g.b_kmajor = 1, g.sB = MM, g.b_tri = tri ? 1 : 0;
-          g.C = Pt.d(), g.ldc = M, g.sC = sK;
-          g.M = (int)n, g.N = M, g.K = M;
+          g.C = Pt.d() + off * M, g.ldc = M, g.sC = sK;
+          g.M = (int)rows, g.N = M, g.K = M;
           g.nbatch = Q;
           g.role = 1;
-          g.fs_part = fwdpart.d(), g.fs_sPart = sPart, g.fs_a = a.d(), g.fs_sA = M, g.fs_x = X;
+          g.fs_part = fwdpart.d() + 8LL * tiles * off, g.fs_sPart = sPart, g.fs_a = a.d(), g.fs_sA = M, g.fs_x = X + off * P;
           g.fs_z = dZ.d(), g.fs_sZ = P, g.fs_ldz = ldz, g.fs_P = P, g.fs_hyper = want_hyper ? 1 : 0, g.fs_ell = dell.d();
           g.store_c = want_z ? 1 : 0;
           g.win = rw, g.win_stride = 2 * wtiles;
           launch_gemm_f64(g, st);
         }
         Scope sc2(this, CAT_ROWSTATS, 1);  // sum of the per-column-tile partials of the fused row statistics
-        launch_combine_parts(fwdpart.d(), 2 * tiles, n, vp.d(), vc.d(), want_hyper ? vpt.d() : nullptr,
-                             want_hyper ? vct.d() : nullptr, st, Q, sPart, ldn);
+        launch_combine_parts(fwdpart.d() + 8LL * tiles * off, 2 * tiles, rows, vp.d() + off, vc.d() + off,
+                             want_hyper ? vpt.d() + off : nullptr, want_hyper ? vct.d() + off : nullptr, st, Q, sPart, ldn);
       }
       {
         Scope sc(this, CAT_QUAD, 2 * (int)pl.size());
@@ -657,7 +755,7 @@ struct hmogp_engine {
     HIP_TRY(hipStreamSynchronize(st));
   }
 
-  void begin(const hmogp_params* p) {
+  void begin(const hmogp_params* p, bool sync = true) {
     HIP_TRY(hipSetDevice(device));
     began = false;
     spans.clear();  // a failed evaluation may have left unmatched timing spans behind
@@ -669,7 +767,9 @@ struct hmogp_engine {
     u_algebra();
     row_pass();
     HIP_TRY(hipEventRecord(ev_begin1, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    // hmogp_step_begin returns with the bundle complete (the caller all-reduces it); the fused hmogp_elbo_grad goes straight
+    // on to enqueue the post-processing behind the row pass -- no host round trip, no launch latency in the tail
+    if (sync) HIP_TRY(hipStreamSynchronize(st));
     began = true;
   }
 
@@ -686,25 +786,25 @@ struct hmogp_engine {
       Scope sc(this, CAT_MM, 0);
       launch_mirror_lower(Hq(0), Q, M, per_q, st);                   // the row pass / the exchange fill the lower triangle
       mm(Hq(0), false, Kuui.d(), true, HK.d(), 1.0, per_q);          // H K^-1
-      mm(Kuui.d(), false, HK.d(), true, G.d());                      // G = K^-1 H K^-1  (dVE_dS, svmogp_inf.py:148)
+      mm(Kuui.d(), false, HK.d(), true, G.d(), 1.0, -1, -1, nullptr, 0, 0, true);  // G = K^-1 H K^-1 (dVE_dS, svmogp_inf.py:148):
+      launch_mirror_lower(G.d(), Q, M, MM, st);                      // symmetric -> lower tiles only, then mirrored
       launch_gemv_batched(Kuui.d(), Hq(0) + oR, Kr.d(), Q, M, per_q, 1, st);  // K^-1 r  (dVE_dmu, :144)
       // two independent tails: the K_uu-side gradients stay on the main stream, the q(u) gradients and the KL terms
       // go to the second one
       HIP_TRY(hipEventRecord(ev_fork, st));
-      HIP_TRY(hipStreamWaitEvent(st2, ev_fork, 0));
+      HIP_TRY(hipStreamWaitEvent(st3, ev_fork, 0));
       if (want_qu) {
-        launch_dlds(G.d(), Kuui.d(), Sqi.d(), dLdS.d(), MM * Q, st2);
-        mm(dLdS.d(), false, L.d(), true, tmpA.d(), 1.0, -1, -1, st2, 0, +1);  // dL_dS L (:175-177), L lower
-        launch_pack_gl(tmpA.d(), gL.d(), Q, M, st2);
-        launch_gmu(Kr.d(), a.d(), gmu.d(), Q, M, st2);
+        launch_dlds(G.d(), Kuui.d(), Sqi.d(), dLdS.d(), MM * Q, st3);
+        mm(dLdS.d(), false, L.d(), true, tmpA.d(), 1.0, -1, -1, st3, 0, +1);  // dL_dS L (:175-177), L lower
+        launch_pack_gl(tmpA.d(), gL.d(), Q, M, st3);
+        launch_gmu(Kr.d(), a.d(), gmu.d(), Q, M, st3);
         // the large gradient leaves on this stream as soon as it exists, beside the K_uu-side tail of the main stream
         if (out->g_L_u && (group_mask & HMOGP_GROUP_QU))
-          HIP_TRY(hipMemcpyAsync(out->g_L_u, gL.p, sizeof(double) * Mtri * Q, hipMemcpyDeviceToHost, st2));
+          HIP_TRY(hipMemcpyAsync(out->g_L_u, gL.p, sizeof(double) * Mtri * Q, hipMemcpyDeviceToHost, st3));
         if (out->g_m_u && (group_mask & HMOGP_GROUP_QU))
-          HIP_TRY(hipMemcpyAsync(out->g_m_u, gmu.p, sizeof(double) * M * Q, hipMemcpyDeviceToHost, st2));
+          HIP_TRY(hipMemcpyAsync(out->g_m_u, gmu.p, sizeof(double) * M * Q, hipMemcpyDeviceToHost, st3));
       }
-      launch_kl_terms(Kuui.d(), S.d(), dmu.d(), a.d(), Luu.d(), L.d(), Sqi.d(), Q, M, klout.d(), st2);
-      HIP_TRY(hipEventRecord(ev_join, st2));
+      HIP_TRY(hipEventRecord(ev_join, st3));
       if (want_hz) {
         mm(G.d(), false, KiS.d(), false, GSK.d());                   // G S K^-1        (tmp_dv, :151)
         launch_dkmm(G.d(), GSK.d(), Kuui.d(), KSK.d(), Kr.d(), a.d(), dKmm.d(), Q, M, st);
@@ -726,12 +826,8 @@ struct hmogp_engine {
     }
     {
       double* d = dstage.d();
-      HIP_TRY(hipMemcpyAsync(d, stats.p, sizeof(double) * n_hg, hipMemcpyDeviceToDevice, st));
-      HIP_TRY(hipMemcpyAsync(d + n_hg, klout.p, sizeof(double) * n_kl, hipMemcpyDeviceToDevice, st));
-      for (int q = 0; q < Q; ++q)
-        HIP_TRY(hipMemcpyAsync(d + n_hg + n_kl + (size_t)q * (per_q - oDZ), Hq(q) + oDZ, sizeof(double) * (per_q - oDZ),
-                               hipMemcpyDeviceToDevice, st));
-      if (n_row) HIP_TRY(hipMemcpyAsync(d + n_hg + n_kl + n_tail, rowout.p, sizeof(double) * n_row, hipMemcpyDeviceToDevice, st));
+      launch_gather_small(stats.d(), (long long)n_hg, klout.d(), (long long)n_kl, per_q, oDZ, per_q - oDZ, Q, rowout.d(),
+                          (long long)n_row, d, st);
       HIP_TRY(hipMemcpyAsync(hstage, d, sizeof(double) * n_all, hipMemcpyDeviceToHost, st));
     }
     const double *hg = hstage, *hkl = hstage + n_hg, *htail = hstage + n_hg + n_kl, *hrow = hstage + n_hg + n_kl + n_tail;
@@ -1149,7 +1245,7 @@ int hmogp_step_finish(hmogp_handle h, hmogp_outputs* out) {
 int hmogp_elbo_grad(hmogp_handle h, const hmogp_params* p, hmogp_outputs* out) {
   if (!h) return HMOGP_E_INVALID;
   return guarded(h, [&] {
-    h->begin(p);
+    h->begin(p, false);
     h->finish(out);
   });
 }
@@ -1377,8 +1473,39 @@ int hmogp_sample(int32_t device, int32_t lik_id, double lik_param, int64_t N, ui
 int hmogp_bench_contraction(int32_t device, int32_t role, int64_t n, int32_t M, int32_t iters, double* avg_ms) {
   return guarded(nullptr, [&] {
     need_device(device);
-    if (n <= 0 || M <= 0 || iters <= 0 || !avg_ms || role < 1 || role > 4) throw EngineError{HMOGP_E_INVALID, "bad arguments"};
+    if (n <= 0 || M <= 0 || iters <= 0 || !avg_ms || role < 1 || role > 5) throw EngineError{HMOGP_E_INVALID, "bad arguments"};
     const long long MM = (long long)M * M;
+    if (role == 5) {  // K_uf construction alone: the launch shape of the row pass (3 latents batched, P = 1, hot-path variant)
+      const int Qb = 3;
+      DevBuf X, Z, K, var, ell;
+      X.ensure(sizeof(double) * n), Z.ensure(sizeof(double) * M * Qb), K.ensure(sizeof(double) * n * M * Qb);
+      var.ensure(sizeof(double) * Qb), ell.ensure(sizeof(double) * Qb);
+      std::vector<double> hx((size_t)n), hz((size_t)M * Qb), hv(Qb, 0.5), hl(Qb);
+      for (long long i = 0; i < n; ++i) hx[(size_t)i] = (double)i / (double)n;
+      for (int m = 0; m < M; ++m)
+        for (int q = 0; q < Qb; ++q) hz[(size_t)m * Qb + q] = (double)m / (double)std::max(1, M - 1);
+      for (int q = 0; q < Qb; ++q) hl[q] = (0.8 + 0.25 * q) / (double)std::max(1, M - 1);
+      HIP_TRY(hipMemcpy(X.p, hx.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(Z.p, hz.data(), sizeof(double) * M * Qb, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(var.p, hv.data(), sizeof(double) * Qb, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(ell.p, hl.data(), sizeof(double) * Qb, hipMemcpyHostToDevice));
+      RbfBatch rbt;
+      rbt.nq = Qb, rbt.var = var.d(), rbt.ell = ell.d(), rbt.sZ = 1, rbt.sK = n * (long long)M;
+      hipEvent_t e0, e1;
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      launch_rbf(X.d(), 1, n, 1, Z.d(), Qb, M, 0.0, 1.0, K.d(), false, nullptr, nullptr, false, &rbt);
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipEventRecord(e0, nullptr));
+      for (int i = 0; i < iters; ++i) launch_rbf(X.d(), 1, n, 1, Z.d(), Qb, M, 0.0, 1.0, K.d(), false, nullptr, nullptr, false, &rbt);
+      HIP_TRY(hipEventRecord(e1, nullptr));
+      HIP_TRY(hipEventSynchronize(e1));
+      float msf = 0.f;
+      HIP_TRY(hipEventElapsedTime(&msf, e0, e1));
+      *avg_ms = msf / iters;
+      (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+      return;
+    }
     DevBuf A, B, Cc, beta, slabs;
     A.ensure(sizeof(double) * n * M), B.ensure(sizeof(double) * MM), Cc.ensure(sizeof(double) * std::max<long long>(n * M, MM));
     beta.ensure(sizeof(double) * n), slabs.ensure(sizeof(double) * MM * gram_ksplit(n, M), true);

@@ -160,6 +160,38 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+// 1/d for a positive normal double: hardware seed + two Newton steps (error ~1e-16 relative; NOT correctly rounded)
+__device__ __forceinline__ double fast_rcp_pos(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+// log(x) for a positive normal double: x = m 2^e with m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(s), s = (m-1)/(m+1),
+// |s| <= 0.1716: odd series to s^21.  Absolute error ~2e-16 (1 + |log x| eps); about half the instructions of the
+// library log (no special cases: the caller guarantees 1 <= x < 1e300).
+__device__ __forceinline__ double fast_log_pos(double x) {
+  int e = __builtin_amdgcn_frexp_exp(x);
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  const bool lowm = m < 0.70710678118654752;
+  m = lowm ? m + m : m;
+  e = lowm ? e - 1 : e;
+  const double s = (m - 1.0) * fast_rcp_pos(m + 1.0), z = s * s;
+  double p = 1.0 / 21.0;
+  p = fma(p, z, 1.0 / 19.0);
+  p = fma(p, z, 1.0 / 17.0);
+  p = fma(p, z, 1.0 / 15.0);
+  p = fma(p, z, 1.0 / 13.0);
+  p = fma(p, z, 1.0 / 11.0);
+  p = fma(p, z, 1.0 / 9.0);
+  p = fma(p, z, 1.0 / 7.0);
+  p = fma(p, z, 1.0 / 5.0);
+  p = fma(p, z, 1.0 / 3.0);
+  p = fma(p * z, s + s, s + s);               // 2 s (1 + z p)
+  const double de = (double)e;
+  return fma(de, 6.93147180369123816490e-01, fma(de, 1.90821492927058770002e-10, p));
+}
+
 // ------------------------------------------------------------------------------------------- Beta, 10 x 10
 // beta.py:29-36,76-197.  betaln / psi / zeta of (a+b) couple the two dimensions: 100 nodes over the 64 lanes.  Everything
 // that depends on ONE dimension only -- a_i, psi(a_i), zeta(2, a_i), lgamma(a_i) and the same for b_j -- is evaluated once
@@ -235,75 +267,168 @@ __device__ __forceinline__ void cat_node_literal(const double (&e)[D], double w,
   }
 }
 
+// One node whose probabilities ARE touched by the clip, denominators far from overflow (den < 1e150): the literal formulas
+// with every division replaced by a multiplication with a Newton-refined reciprocal and the library log by fast_log_pos
+// (<= 2 ulp away from the reference's IEEE divisions; a clip comparison can only flip for a value within an ulp of the bound).
+template <int D>
+__device__ __forceinline__ void cat_node_clipped(const double (&e)[D], double den, double w, int label, bool exact_dm,
+                                                 double& ve, double (&hv)[D], double (&gx)[D]) {
+  constexpr int K = D + 1;
+  const double rden = fast_rcp_pos(den);
+  double psum = 0.0, py = 0.0;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const double pk = clip(e[k] * rden, 1e-9, 1.0 - 1e-9);
+    psum += pk;
+    if (label == k + 1) py = pk;
+  }
+  const double pK = clip(rden, 1e-9, 1.0 - 1e-9);
+  psum += pK;
+  if (label == K) py = pK;
+  ve = fma(w, fast_log_pos(py) - fast_log_pos(psum), ve);
+#pragma unroll
+  for (int d = 0; d < D; ++d) {   // (e_d + sum_{j != d} e_j e_d) / den^2 = e_d (den - e_d) / den^2, no overflow below 1e150
+    const double pd = e[d] * rden;
+    hv[d] = fma(w * pd, (den - e[d]) * rden, hv[d]);
+    if (exact_dm) gx[d] = fma(w, (label == d + 1 ? 1.0 : 0.0) - pd, gx[d]);
+  }
+}
+
+// One node on the "clip inactive" path: log p_y = f_y - log(den), d2 log p / df_d^2 = -p_d (den - e_d) / den.
+template <int D>
+__device__ __forceinline__ void cat_node_fast(const double (&e)[D], double den, double w, double fy, int label, bool exact_dm,
+                                              double& ve, double (&hv)[D], double (&gx)[D]) {
+  const double rden = fast_rcp_pos(den);
+  ve = fma(w, fy - fast_log_pos(den), ve);
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const double pd = e[d] * rden;
+    hv[d] = fma(w * pd, (den - e[d]) * rden, hv[d]);
+    if (exact_dm) gx[d] = fma(w, (label == d + 1 ? 1.0 : 0.0) - pd, gx[d]);
+  }
+}
+
+// Loop structure (D functions, nodes in the reference's C order, function 0 slowest):
+//   * the LAST min(D,3) dimensions are strided over the 64 lanes in chunks; their digits, table entries, weight product
+//     and partial sum are formed once per lane and chunk;
+//   * when D > 3, dimension D-4 is the REGISTER dimension: its ten table entries (exp f, f, weight) are preloaded into
+//     registers once per row and its loop is fully unrolled -- ten independent nodes per trip, no LDS access and no index
+//     arithmetic inside, so the scheduler can interleave their reciprocal / logarithm chains;
+//   * dimensions 0 .. D-5 (D > 4) form a uniform outer loop whose table reads are amortised over those ten nodes.
+// Whether the ten nodes of a trip may all take the fast path is decided once per trip from the largest / smallest
+// denominator of the trip; otherwise each node of the trip is routed individually.
 template <int D>
 __device__ __forceinline__ void lik_categorical_t(double y, const double* m, const double* v, int lane, double* tab,
                                                   unsigned quirks, LikOut& o) {
   constexpr int K = D + 1;
-  constexpr int DI = D < 3 ? D : 3, DO = D - DI;            // lane-strided inner / uniform outer dimensions
+  constexpr int DI = D < 3 ? D : 3;                          // lane-strided inner dimensions: functions D-DI .. D-1
+  constexpr int HASR = D > 3 ? 1 : 0;                        // register dimension: function D-4
+  constexpr int DS = D - DI - HASR;                          // slow (uniform) outer dimensions: functions 0 .. DS-1
   constexpr int NIN = DI == 1 ? 10 : (DI == 2 ? 100 : 1000);
-  int NOUT = 1;
+  constexpr int RD = D - DI - 1;                             // index of the register dimension (valid when HASR)
+  int NSLOW = 1;
 #pragma unroll
-  for (int k = 0; k < DO; ++k) NOUT *= 10;
+  for (int k = 0; k < DS; ++k) NSLOW *= 10;
   double* etab = tab;
   double* ftab = tab + 80;
   double* wtab = tab + 160;
-  double mine = INFINITY, maxe = 0.0;
   for (int t = lane; t < D * 10; t += 64) {
     const int k = t / 10, i = t - 10 * k;
-    const double f = GH10_X[i] * sqrt(2.0 * v[k]) + m[k], ef = safe_exp(f);
-    etab[t] = ef, ftab[t] = f;
-    mine = fmin(mine, ef), maxe = fmax(maxe, ef);
+    const double f = GH10_X[i] * sqrt(2.0 * v[k]) + m[k];
+    etab[t] = safe_exp(f), ftab[t] = f;
   }
   if (lane < 10) wtab[lane] = GH10_WN[lane];
   __builtin_amdgcn_wave_barrier();  // the tables are written and read by this wave only (LDS ops are in order)
-  // row-level bounds for the "clip inactive" test of a node: every p = t / den with lo_row <= t <= hi_row
-  const double lo_row = fmin(wave_min(mine), 1.0), hi_row = fmax(wave_max(maxe), 1.0);
   const int label = (int)y;  // 1..K
   const bool valid = (y == (double)label) && label >= 1 && label <= K;
   const bool exact_dm = (quirks & HMOGP_QUIRK_CATEGORICAL_DM) == 0;
+  double er[HASR ? 10 : 1], wr[HASR ? 10 : 1], fr[HASR ? 10 : 1];
+  if (HASR) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      er[i] = etab[RD * 10 + i], wr[i] = wtab[i];
+      fr[i] = (label == RD + 1) ? ftab[RD * 10 + i] : 0.0;
+    }
+  }
   double ve = 0.0, hv[D], gx[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) hv[k] = gx[k] = 0.0;
   for (int base = 0; base < NIN; base += 64) {
     const int idx = base + lane;
     if (idx >= NIN) continue;
-    // C-order grid (categorical.py:153-162): function 0 is the slowest index, function D-1 the fastest
-    double e[D], fy = 0.0, win = 1.0;
+    // A node takes the fast path when the reference's clip to [1e-9, 1-1e-9] cannot touch any of its K probabilities
+    // t / den, t in {e_0 .. e_{D-1}, 1}:  min t >= 1e-9 den  and  max t <= (1 - 1e-9) den  (and den finite).  The smallest /
+    // largest t of the inner and slow dimensions are hoisted out of the register dimension's loop.
+    double e[D], fy_in = 0.0, win = 1.0, sin_ = 0.0, lo_in = 1.0, hi_in = 1.0;
     int rem = idx;
 #pragma unroll
-    for (int t = DI - 1; t >= 0; --t) {
+    for (int t = DI - 1; t >= 0; --t) {  // digits of the inner dimensions, fastest first (the reference's weight order)
       const int i = rem % 10;
       rem /= 10;
-      e[DO + t] = etab[(DO + t) * 10 + i];
-      if (label == DO + t + 1) fy = ftab[(DO + t) * 10 + i];
+      const int k = D - DI + t;
+      e[k] = etab[k * 10 + i];
+      if (label == k + 1) fy_in = ftab[k * 10 + i];
       win *= wtab[i];
+      sin_ += e[k];
+      lo_in = fmin(lo_in, e[k]), hi_in = fmax(hi_in, e[k]);
     }
-    for (int oc = 0; oc < NOUT; ++oc) {
-      double w = win, fyo = fy;
-      int r2 = oc;
+    for (int sc = 0; sc < NSLOW; ++sc) {
+      double ws = win, fys = fy_in, ss = sin_, lo = lo_in, hi = hi_in;
+      int r2 = sc;
 #pragma unroll
-      for (int k = DO - 1; k >= 0; --k) {  // uniform digits
+      for (int k = DS - 1; k >= 0; --k) {  // uniform digits of the slow outer dimensions
         const int i = r2 % 10;
         r2 /= 10;
         e[k] = etab[k * 10 + i];
-        if (label == k + 1) fyo = ftab[k * 10 + i];
-        w *= wtab[i];
+        if (label == k + 1) fys = ftab[k * 10 + i];
+        ws *= wtab[i];
+        ss += e[k];
+        lo = fmin(lo, e[k]), hi = fmax(hi, e[k]);
       }
-      double esum = 0.0;
-#pragma unroll
-      for (int k = D - 1; k >= 0; --k) esum += e[k];
-      const double den = 1.0 + esum;
-      if (den < 1e300 && den * 1e-9 <= lo_row && den * (1.0 - 1e-9) >= hi_row) {
-        const double rden = 1.0 / den;
-        ve += w * (fyo - log(den));
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          const double pd = e[d] * rden;
-          hv[d] += w * (pd * ((den - e[d]) * rden));
-          if (exact_dm) gx[d] += w * ((label == d + 1 ? 1.0 : 0.0) - pd);
-        }
+      if (!HASR) {
+        const double den = 1.0 + ss;
+        if (den < 1e300 && den * 1e-9 <= lo && den * (1.0 - 1e-9) >= hi)
+          cat_node_fast<D>(e, den, ws, fys, label, exact_dm, ve, hv, gx);
+        else if (den < 1e150)
+          cat_node_clipped<D>(e, den, ws, label, exact_dm, ve, hv, gx);
+        else
+          cat_node_literal<D>(e, ws, label, exact_dm, ve, hv, gx);
       } else {
-        cat_node_literal<D>(e, w, label, exact_dm, ve, hv, gx);
+        // NB the weight of the register dimension multiplies BEFORE the slow dimensions' in the reference's order; the
+        // product of ten normalised weights is formed here as (inner * register) * slow -- same factors, and the fast
+        // path only promises 1e-15 anyway; the literal path below restores the reference's order exactly.
+        bool all_fast = true;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+          const double den = 1.0 + (ss + er[i]);
+          all_fast = all_fast && den < 1e300 && den * 1e-9 <= fmin(lo, er[i]) && den * (1.0 - 1e-9) >= fmax(hi, er[i]);
+        }
+        if (all_fast) {
+#pragma unroll
+          for (int i = 0; i < 10; ++i) {
+            e[RD] = er[i];
+            cat_node_fast<D>(e, 1.0 + (ss + er[i]), ws * wr[i], fys + fr[i], label, exact_dm, ve, hv, gx);
+          }
+        } else {
+#pragma unroll 1
+          for (int i = 0; i < 10; ++i) {
+            e[RD] = etab[RD * 10 + i];
+            double w = win * wtab[i];  // reference order: inner dims (fastest first), then RD, then the slow dims
+            int r3 = sc;
+#pragma unroll
+            for (int k = DS - 1; k >= 0; --k) {
+              w *= wtab[r3 % 10];
+              r3 /= 10;
+            }
+            const double den = 1.0 + (ss + e[RD]);
+            if (den < 1e300 && den * 1e-9 <= fmin(lo, e[RD]) && den * (1.0 - 1e-9) >= fmax(hi, e[RD]))
+              cat_node_fast<D>(e, den, w, fys + ((label == RD + 1) ? ftab[RD * 10 + i] : 0.0), label, exact_dm, ve, hv, gx);
+            else if (den < 1e150)
+              cat_node_clipped<D>(e, den, w, label, exact_dm, ve, hv, gx);
+            else
+              cat_node_literal<D>(e, w, label, exact_dm, ve, hv, gx);
+          }
+        }
       }
     }
   }
@@ -321,20 +446,6 @@ __device__ __forceinline__ void lik_categorical_t(double y, const double* m, con
     } else {
       o.gm[d] = ((label == d + 1 ? 1.0 : 0.0) - (valid ? 1.0 : 0.0)) * wpow;  // quirk Q2
     }
-  }
-}
-
-__device__ __forceinline__ void lik_categorical_wave(double y, const double* m, const double* v, int K, int lane,
-                                                     double* tab, unsigned quirks, LikOut& o) {
-  switch (K - 1) {
-    case 1: lik_categorical_t<1>(y, m, v, lane, tab, quirks, o); break;
-    case 2: lik_categorical_t<2>(y, m, v, lane, tab, quirks, o); break;
-    case 3: lik_categorical_t<3>(y, m, v, lane, tab, quirks, o); break;
-    case 4: lik_categorical_t<4>(y, m, v, lane, tab, quirks, o); break;
-    case 5: lik_categorical_t<5>(y, m, v, lane, tab, quirks, o); break;
-    case 6: lik_categorical_t<6>(y, m, v, lane, tab, quirks, o); break;
-    case 7: lik_categorical_t<7>(y, m, v, lane, tab, quirks, o); break;
-    default: lik_categorical_t<8>(y, m, v, lane, tab, quirks, o); break;
   }
 }
 
@@ -637,7 +748,9 @@ __host__ __device__ constexpr int lik_lanes(int lik) {
 
 // Dispatch.  For 64-lane likelihoods every lane of the wave must call with the same row; the result is valid in
 // every lane.  `etab` (per-wave LDS, HMOGP_MAXJ*10 doubles) is only used by Categorical.
-template <int LIK>
+// CATD: number of functions (K-1) of a Categorical likelihood -- a template parameter so that each K gets its own register
+// allocation (0 for every other likelihood).
+template <int LIK, int CATD = 0>
 __device__ __forceinline__ void lik_eval(double y, double yaux, const double* m, const double* v, double param, int lane,
                                          double* etab, unsigned quirks, LikOut& o) {
   if (LIK == HMOGP_LIK_GAUSSIAN)
@@ -651,7 +764,7 @@ __device__ __forceinline__ void lik_eval(double y, double yaux, const double* m,
   else if (LIK == HMOGP_LIK_BETA)
     lik_beta_wave(y, m, v, lane, etab, o);
   else
-    lik_categorical_wave(y, m, v, (int)param, lane, etab, quirks, o);
+    lik_categorical_t<(CATD > 0 ? CATD : 1)>(y, m, v, lane, etab, quirks, o);
   if ((LIK == HMOGP_LIK_GAMMA || LIK == HMOGP_LIK_BETA) && !(quirks & HMOGP_QUIRK_GAMMA_BETA_PI)) {
     o.ve *= M_PI;  // exact mode: undo the second division of each dimension's weights by sqrt(pi) (quirk Q1)
 #pragma unroll

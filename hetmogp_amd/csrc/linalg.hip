@@ -290,14 +290,19 @@ void launch_gemv_batched(const double* A, const double* x, double* y, int Q, int
 }
 
 // A (Q x M x M, in place) <- its lower Cholesky factor; `scr` is a Q x M x M scratch (the out-of-place factor).
-void launch_potrf_batched(double* A, int Q, int M, int* d_info, double* scr, hipStream_t stream) {
-  HIP_TRY(hipMemsetAsync(d_info, 0, sizeof(int) * Q, stream));
-  for (int j = 0; j < M; j += NB) {
+// panel_begin / panel_end (in panels of NB columns; -1 = to the end) let a caller enqueue the chain in two parts with other
+// launches in between (the host needs ~10 us per launch, the device ~25 us per panel: see engine.hip u_algebra).
+void launch_potrf_batched(double* A, int Q, int M, int* d_info, double* scr, hipStream_t stream, int panel_begin, int panel_end) {
+  const int npanels = (M + NB - 1) / NB;
+  if (panel_end < 0 || panel_end > npanels) panel_end = npanels;
+  if (panel_begin == 0) HIP_TRY(hipMemsetAsync(d_info, 0, sizeof(int) * Q, stream));
+  for (int pnl = panel_begin; pnl < panel_end; ++pnl) {
+    const int j = pnl * NB;
     const int rem = M - j - std::min(NB, M - j);
     const int T = (rem + 127) / 128;
     hipLaunchKernelGGL(potrf_step_kernel, dim3(std::max(1, T * (T + 1) / 2), Q), dim3(320), 0, stream, A, scr, M, j, d_info, j == 0 ? g_potrf_stamps : nullptr);
   }
-  hipLaunchKernelGGL(potrf_finalize_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, stream, A, M, scr);
+  if (panel_end == npanels) hipLaunchKernelGGL(potrf_finalize_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, stream, A, M, scr);
 }
 
 // Linv = L^-1.  `tmp` is a Q x M x M scratch.

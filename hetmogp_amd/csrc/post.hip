@@ -292,6 +292,39 @@ __global__ void adadelta_kernel(double* __restrict__ x, double* __restrict__ gms
 }
 }  // namespace
 
+namespace {
+// dst = [ head (n_hg) | kl (n_kl) | per-latent tails (Q x n_tail, from bundle + NG + q*per_q + oDZ) | rowout (n_row) ]
+__global__ void gather_small_kernel(const double* __restrict__ stats, long long n_hg, const double* __restrict__ kl,
+                                    long long n_kl, long long per_q, long long oDZ, long long n_tail, int Q,
+                                    const double* __restrict__ rowout, long long n_row, double* __restrict__ dst) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_hg) {
+    dst[i] = stats[i];
+    return;
+  }
+  long long k = i - n_hg;
+  if (k < n_kl) {
+    dst[i] = kl[k];
+    return;
+  }
+  k -= n_kl;
+  if (k < n_tail * Q) {
+    const long long q = k / n_tail, e = k - q * n_tail;
+    dst[i] = stats[n_hg + q * per_q + oDZ + e];
+    return;
+  }
+  k -= n_tail * Q;
+  if (k < n_row) dst[i] = rowout[k];
+}
+}  // namespace
+
+void launch_gather_small(const double* stats, long long n_hg, const double* kl, long long n_kl, long long per_q, long long oDZ,
+                         long long n_tail, int Q, const double* rowout, long long n_row, double* dst, hipStream_t s) {
+  const long long n = n_hg + n_kl + n_tail * Q + n_row;
+  hipLaunchKernelGGL(gather_small_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, stats, n_hg, kl, n_kl, per_q, oDZ,
+                     n_tail, Q, rowout, n_row, dst);
+}
+
 void launch_adadelta(double* x, double* gms, double* sms, double* step, const double* grad, double sign, long long n, int phase,
                      double rate, double m, double d, double omd, double o, hipStream_t s) {
   if (n <= 0) return;

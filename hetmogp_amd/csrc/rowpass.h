@@ -42,6 +42,7 @@ struct RbfBatch {
   const double* var = nullptr;  // [nq] device
   const double* ell = nullptr;  // [nq] device
   long long sZ = 0, sK = 0, sWin = 0;
+  long long sX = 0;             // per-latent offset of the row inputs (K_uu: the rows are the latent's own inducing inputs)
 };
 struct ColBatch {
   int nq = 1;

@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void rbf_kernel(const double* __restrict__ X, 
                                                   RbfBatch bt) {
   if (bt.var) {  // batched over the latents (grid.z): per-latent inducing block, hyper-parameters, output and windows
     const int q = blockIdx.z;
+    X += (long long)q * bt.sX;
     Z += (long long)q * bt.sZ;
     K += (long long)q * bt.sK;
     var = bt.var[q], ell = bt.ell[q];
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void window_fix_kernel(int* __restrict__ rowwi
 }
 
 // ---- quad -----------------------------------------------------------------------------------------------
-template <int LIK>
+template <int LIK, int CATD = 0>
 __global__ __launch_bounds__(256) void quad_kernel(QuadArgs a) {
   constexpr int G = lik_lanes(LIK);
   __shared__ double etab[4][HMOGP_ETAB];
@@ -261,7 +262,15 @@ __global__ __launch_bounds__(256) void quad_kernel(QuadArgs a) {
   o.ve = 0.0;
 #pragma unroll
   for (int j = 0; j < HMOGP_MAXJ; ++j) o.gm[j] = o.gv[j] = 0.0;
-  if (valid) lik_eval<LIK>(a.y[n], a.yaux ? a.yaux[n] : 0.0, mu, vv, a.lik_param, lane, etab[w], a.quirks, o);
+  if (valid) lik_eval<LIK, CATD>(a.y[n], a.yaux ? a.yaux[n] : 0.0, mu, vv, a.lik_param, lane, etab[w], a.quirks, o);
+  if (G == 64) {  // wave-per-row likelihoods: p / c were only needed for q(f); re-read them instead of keeping 2 x MAXQ
+                  // doubles alive across the node loop (register pressure = occupancy of the quadrature)
+#pragma unroll
+    for (int q = 0; q < HMOGP_MAXQ; ++q) {
+      pq[q] = (valid && q < Q) ? a.p[q * a.ldn + n] : 0.0;
+      cq[q] = (valid && q < Q) ? a.c[q * a.ldn + n] : 0.0;
+    }
+  }
   if (a.out_mu && lead) {
     for (int j = 0; j < J; ++j) {
       a.out_mu[n * J + j] = mu[j];
@@ -523,7 +532,7 @@ __global__ void gammaln1p_kernel(const double* __restrict__ y, double* __restric
 }
 
 // ---- stand-alone variational expectations (hmogp_var_exp; also the predictive building block) -------------------
-template <int LIK>
+template <int LIK, int CATD = 0>
 __global__ __launch_bounds__(256) void var_exp_kernel(int J, double param, long long N, const double* __restrict__ y,
                                                       const double* __restrict__ m, const double* __restrict__ v,
                                                       double* __restrict__ ve, double* __restrict__ dm,
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(256) void var_exp_kernel(int J, double param, long 
 #pragma unroll
   for (int j = 0; j < HMOGP_MAXJ; ++j) o.gm[j] = o.gv[j] = 0.0;
   const double yy = y[n];
-  lik_eval<LIK>(yy, (LIK == HMOGP_LIK_POISSON) ? lgamma(yy + 1.0) : 0.0, mu, vv, param, lane, etab[w], quirks, o);
+  lik_eval<LIK, CATD>(yy, (LIK == HMOGP_LIK_POISSON) ? lgamma(yy + 1.0) : 0.0, mu, vv, param, lane, etab[w], quirks, o);
   if (G == 1 || lane == 0) {
     ve[n] = o.ve;
     for (int j = 0; j < J; ++j) {
@@ -688,11 +697,24 @@ void launch_quad(const QuadArgs& a, hipStream_t s) {
   if (a.N <= 0) return;
   dim3 grid((unsigned)quad_blocks(a.lik, a.N));
 #define QK(L) hipLaunchKernelGGL((quad_kernel<L>), grid, dim3(256), 0, s, a)
+#define QKC(D) hipLaunchKernelGGL((quad_kernel<HMOGP_LIK_CATEGORICAL, D>), grid, dim3(256), 0, s, a)
   switch (a.lik) {
     case HMOGP_LIK_GAUSSIAN: QK(HMOGP_LIK_GAUSSIAN); break;
     case HMOGP_LIK_BERNOULLI: QK(HMOGP_LIK_BERNOULLI); break;
     case HMOGP_LIK_HETGAUSSIAN: QK(HMOGP_LIK_HETGAUSSIAN); break;
-    case HMOGP_LIK_CATEGORICAL: QK(HMOGP_LIK_CATEGORICAL); break;
+    case HMOGP_LIK_CATEGORICAL:
+      switch (a.dimf) {
+        case 1: QKC(1); break;
+        case 2: QKC(2); break;
+        case 3: QKC(3); break;
+        case 4: QKC(4); break;
+        case 5: QKC(5); break;
+        case 6: QKC(6); break;
+        case 7: QKC(7); break;
+        case 8: QKC(8); break;
+        default: throw HipError{hipErrorInvalidValue, "Categorical needs 2 <= K <= 9", __FILE__, __LINE__};
+      }
+      break;
     case HMOGP_LIK_POISSON: QK(HMOGP_LIK_POISSON); break;
     case HMOGP_LIK_EXPONENTIAL: QK(HMOGP_LIK_EXPONENTIAL); break;
     case HMOGP_LIK_GAMMA: QK(HMOGP_LIK_GAMMA); break;
@@ -700,6 +722,7 @@ void launch_quad(const QuadArgs& a, hipStream_t s) {
     default: throw HipError{hipErrorInvalidValue, "unknown likelihood id", __FILE__, __LINE__};
   }
 #undef QK
+#undef QKC
 }
 
 void launch_var_exp(int lik, int J, double param, long long N, const double* y, const double* m, const double* v, double* ve,
@@ -707,11 +730,24 @@ void launch_var_exp(int lik, int J, double param, long long N, const double* y, 
   if (N <= 0) return;
   dim3 grid((unsigned)quad_blocks(lik, N));
 #define VK(L) hipLaunchKernelGGL((var_exp_kernel<L>), grid, dim3(256), 0, s, J, param, N, y, m, v, ve, dm, dv, quirks)
+#define VKC(D) hipLaunchKernelGGL((var_exp_kernel<HMOGP_LIK_CATEGORICAL, D>), grid, dim3(256), 0, s, J, param, N, y, m, v, ve, dm, dv, quirks)
   switch (lik) {
     case HMOGP_LIK_GAUSSIAN: VK(HMOGP_LIK_GAUSSIAN); break;
     case HMOGP_LIK_BERNOULLI: VK(HMOGP_LIK_BERNOULLI); break;
     case HMOGP_LIK_HETGAUSSIAN: VK(HMOGP_LIK_HETGAUSSIAN); break;
-    case HMOGP_LIK_CATEGORICAL: VK(HMOGP_LIK_CATEGORICAL); break;
+    case HMOGP_LIK_CATEGORICAL:
+      switch (J) {
+        case 1: VKC(1); break;
+        case 2: VKC(2); break;
+        case 3: VKC(3); break;
+        case 4: VKC(4); break;
+        case 5: VKC(5); break;
+        case 6: VKC(6); break;
+        case 7: VKC(7); break;
+        case 8: VKC(8); break;
+        default: throw HipError{hipErrorInvalidValue, "Categorical needs 2 <= K <= 9", __FILE__, __LINE__};
+      }
+      break;
     case HMOGP_LIK_POISSON: VK(HMOGP_LIK_POISSON); break;
     case HMOGP_LIK_EXPONENTIAL: VK(HMOGP_LIK_EXPONENTIAL); break;
     case HMOGP_LIK_GAMMA: VK(HMOGP_LIK_GAMMA); break;
@@ -719,6 +755,7 @@ void launch_var_exp(int lik, int J, double param, long long N, const double* y, 
     default: throw HipError{hipErrorInvalidValue, "unknown likelihood id", __FILE__, __LINE__};
   }
 #undef VK
+#undef VKC
 }
 
 void launch_predictive(int lik, int J, int Jp, double param, int T, long long N, const double* m, const double* v,

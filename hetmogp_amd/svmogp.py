@@ -94,7 +94,10 @@ class DeviceAdadelta(object):
                 self.n_iter += 1
                 yield dict(n_iter=self.n_iter, gradient=g, step=self.step)
         finally:
-            self.finish()
+            try:
+                self.finish()
+            except Exception:      # interpreter shutdown with the generator still alive: nothing left to sync into
+                pass
 
     def finish(self):
         """Bring q(u) back into the model's parameter arrays (no re-evaluation: the device state is what the last

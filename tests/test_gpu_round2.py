@@ -259,7 +259,7 @@ def test_device_samples_have_the_reference_distribution(name, kw):
         elif name == "Beta":
             a, b = ef
             mean, var = a / (a + b), a * b / ((a + b) ** 2 * (a + b + 1))
-            assert np.all((y > 0) & (y < 1))
+            assert np.all((y >= 0) & (y <= 1))                      # (x/(x+y) rounds to the end points for tiny shapes)
         else:
             K = kw["K"]
             p = np.append(ef, 1.0) / (1 + ef.sum())

@@ -23,7 +23,10 @@ CASES = {
         ([("Categorical", {"K": 4}), ("Gaussian", {"sigma": 0.5})], 50000, 2048, 2, 2),
 }
 
+ONLY = sys.argv[1] if len(sys.argv) > 1 else ""        # e.g. `python tools/bench_configs.py C4`
 for name, (specs, N, M, Q, P) in CASES.items():
+    if not name.startswith(ONLY):
+        continue
     prm, X, Y = make_case(specs, [N] * len(specs), M=M, Q=Q, P=P, seed=1)
     e = Engine(specs, Q, M, P)
     e.set_data(X, Y)
