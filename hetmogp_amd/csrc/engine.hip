@@ -60,6 +60,8 @@ struct DevBuf {
   T* as() const { return static_cast<T*>(p); }
 };
 
+constexpr int FWD_PARTS = 2;  // partials of the fused row statistics per 128-column tile = wave columns of the role-1 GEMM
+
 enum { CAT_TOTAL = 0, CAT_RBF, CAT_FWD, CAT_ROWSTATS, CAT_QUAD, CAT_GRAM, CAT_COLSTATS, CAT_MM, NCAT };
 
 struct Task {
@@ -388,7 +390,7 @@ struct hmogp_engine {
     for (DevBuf* b : {&vp, &vc, &vpt, &vct, &valpha, &vbeta, &valpha0, &vbeta0}) b->ensure(nv, true);
     colpart.ensure(sizeof(double) * ((rows + 255) / 256) * M * (1 + P) * Q);
     quadpart.ensure(sizeof(double) * (rows * 64 / 256 + 1) * HMOGP_MAXSCAL);
-    fwdpart.ensure(sizeof(double) * 8 * ((M + 127) / 128) * rows * Q);  // 4 statistics x 2 column halves per tile
+    fwdpart.ensure(sizeof(double) * 4 * FWD_PARTS * ((M + 127) / 128) * rows * Q);  // 4 statistics x FWD_PARTS wave columns per tile
     if (use_windows) {
       const size_t tiles = (rows + 127) / 128, ncb = (M + 127) / 128;
       winrow.ensure(sizeof(int) * 2 * tiles * Q), wincol.ensure(sizeof(int) * 2 * ncb * Q), winhit.ensure(tiles * ncb);
@@ -642,8 +644,50 @@ struct hmogp_engine {
       // when the Z gradient (its one remaining consumer, colstats) is requested.  One launch per pool -- or one per
       // segment when every segment is large (see SEG_FORWARD_MIN_ROWS).
       const bool per_seg = seg_forward(pl);
-      const long long sPart = 8LL * tiles * ldn;
+      const long long sPart = 4LL * FWD_PARTS * tiles * ldn;
       const size_t nlaunch = per_seg ? pl.size() : 1;
+      const long long clen = (long long)M * (1 + P);          // one column-statistics slab: [ r (M) | dZ (M*P) ]
+      // slabs of the column statistics: 256-row splits, per segment when the segments are launched separately
+      const long long nsp = (n + 255) / 256;                  // 256-row slabs of the column statistics
+
+      auto quad_segment = [&](const Seg& sg) {
+        Task& k = tasks[sg.t];
+        QuadArgs qa;
+        qa.lik = k.lik, qa.lik_param = k.param, qa.dimf = k.dimf, qa.Q = Q, qa.N = sg.n;
+        qa.y = k.Y.d() + sg.r0;
+        qa.yaux = k.Yaux.p ? k.Yaux.d() + sg.r0 : nullptr;
+        qa.p = vp.d() + sg.off, qa.c = vc.d() + sg.off;
+        qa.pt = want_hyper ? vpt.d() + sg.off : nullptr, qa.ct = want_hyper ? vct.d() + sg.off : nullptr;
+        qa.ldn = ldn;
+        std::memset(qa.w, 0, sizeof(qa.w)), std::memset(qa.w0, 0, sizeof(qa.w0)), std::memset(qa.kap, 0, sizeof(qa.kap));
+        std::memset(qa.var, 0, sizeof(qa.var));
+        for (int q = 0; q < Q; ++q) {
+          qa.var[q] = h_var[q];
+          for (int j = 0; j < k.dimf; ++j) {
+            qa.w[q][j] = h_W[q * Df + k.d0 + j];
+            qa.w0[q][j] = h_W0[q * Df + k.d0 + j];
+            qa.kap[q][j] = h_kap[q * Df + k.d0 + j];
+          }
+        }
+        qa.scale = h_bs[sg.t];
+        qa.quirks = quirks;
+        qa.alpha = valpha.d() + sg.off, qa.beta = vbeta.d() + sg.off;
+        qa.alpha0 = valpha0.d() + sg.off, qa.beta0 = vbeta0.d() + sg.off;
+        qa.partials = quadpart.d();
+        launch_quad(qa, st);
+        launch_reduce_rows(quadpart.d(), quad_blocks(k.lik, sg.n), k.nscal, k.offsets.as<long long>(), stats.d(), true, st);
+      };
+      // column statistics of rows [off, off + rows) on the second stream, after the quadrature of those rows (ev_fork)
+      auto colstats_rows = [&](long long off, long long rows, long long slab_first) {
+        HIP_TRY(hipEventRecord(ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(st2, ev_fork, 0));
+        Scope sc(this, CAT_COLSTATS, 1, st2);
+        ColBatch cb;
+        cb.nq = Q, cb.sK = sK, cb.sA = M, cb.sV = ldn, cb.sZ = P, cb.sPart = nsp * clen, cb.sWin = 2 * ncb;
+        launch_colstats(Kh.d() + off * M, Pt.d() + off * M, a.d(), valpha.d() + off, valpha0.d() + off, vbeta0.d() + off,
+                        X + off * P, P, dZ.d(), ldz, rows, M, 256, want_z, colpart.d() + slab_first * clen, st2, cw, &cb);
+      };
+
       for (size_t li = 0; li < nlaunch; ++li) {
         const long long off = per_seg ? pl[li].off : 0, rows = per_seg ? pl[li].n : n;
         if (prefetched) {
@@ -653,6 +697,8 @@ struct hmogp_engine {
             HIP_TRY(hipStreamWaitEvent(st, ev_seg[li], 0));
         }
         {
+          // forward contraction for all latents (batched), row statistics fused into its epilogue; P~ itself is only
+          // stored when the Z gradient (its one remaining consumer, colstats) is requested
           Scope sc(this, CAT_FWD, 1);
           GemmArgs g;
           g.A = Kh.d() + off * M, g.lda = M, g.a_kmajor = 0, g.sA = sK;
@@ -664,50 +710,28 @@ struct hmogp_engine {
           g.M = (int)rows, g.N = M, g.K = M;
           g.nbatch = Q;
           g.role = 1;
-          g.fs_part = fwdpart.d() + 8LL * tiles * off, g.fs_sPart = sPart, g.fs_a = a.d(), g.fs_sA = M, g.fs_x = X + off * P;
+          g.fs_part = fwdpart.d() + 4LL * FWD_PARTS * tiles * off, g.fs_sPart = sPart, g.fs_a = a.d(), g.fs_sA = M, g.fs_x = X + off * P;
           g.fs_z = dZ.d(), g.fs_sZ = P, g.fs_ldz = ldz, g.fs_P = P, g.fs_hyper = want_hyper ? 1 : 0, g.fs_ell = dell.d();
           g.store_c = want_z ? 1 : 0;
           g.win = rw, g.win_stride = 2 * wtiles;
           launch_gemm_f64(g, st);
         }
-        Scope sc2(this, CAT_ROWSTATS, 1);  // sum of the per-column-tile partials of the fused row statistics
-        launch_combine_parts(fwdpart.d() + 8LL * tiles * off, 2 * tiles, rows, vp.d() + off, vc.d() + off,
-                             want_hyper ? vpt.d() + off : nullptr, want_hyper ? vct.d() + off : nullptr, st, Q, sPart, ldn);
+        {
+          Scope sc2(this, CAT_ROWSTATS, 1);  // sum of the per-column-tile partials of the fused row statistics
+          launch_combine_parts(fwdpart.d() + 4LL * FWD_PARTS * tiles * off, FWD_PARTS * tiles, rows, vp.d() + off, vc.d() + off,
+                               want_hyper ? vpt.d() + off : nullptr, want_hyper ? vct.d() + off : nullptr, st, Q, sPart, ldn);
+        }
       }
       {
         Scope sc(this, CAT_QUAD, 2 * (int)pl.size());
-        for (auto& sg : pl) {
-          Task& k = tasks[sg.t];
-          QuadArgs qa;
-          qa.lik = k.lik, qa.lik_param = k.param, qa.dimf = k.dimf, qa.Q = Q, qa.N = sg.n;
-          qa.y = k.Y.d() + sg.r0;
-          qa.yaux = k.Yaux.p ? k.Yaux.d() + sg.r0 : nullptr;
-          qa.p = vp.d() + sg.off, qa.c = vc.d() + sg.off;
-          qa.pt = want_hyper ? vpt.d() + sg.off : nullptr, qa.ct = want_hyper ? vct.d() + sg.off : nullptr;
-          qa.ldn = ldn;
-          std::memset(qa.w, 0, sizeof(qa.w)), std::memset(qa.w0, 0, sizeof(qa.w0)), std::memset(qa.kap, 0, sizeof(qa.kap));
-          std::memset(qa.var, 0, sizeof(qa.var));
-          for (int q = 0; q < Q; ++q) {
-            qa.var[q] = h_var[q];
-            for (int j = 0; j < k.dimf; ++j) {
-              qa.w[q][j] = h_W[q * Df + k.d0 + j];
-              qa.w0[q][j] = h_W0[q * Df + k.d0 + j];
-              qa.kap[q][j] = h_kap[q * Df + k.d0 + j];
-            }
-          }
-          qa.scale = h_bs[sg.t];
-          qa.quirks = quirks;
-          qa.alpha = valpha.d() + sg.off, qa.beta = vbeta.d() + sg.off;
-          qa.alpha0 = valpha0.d() + sg.off, qa.beta0 = vbeta0.d() + sg.off;
-          qa.partials = quadpart.d();
-          launch_quad(qa, st);
-          launch_reduce_rows(quadpart.d(), quad_blocks(k.lik, sg.n), k.nscal, k.offsets.as<long long>(), stats.d(), true, st);
-        }
+        for (auto& sg : pl) quad_segment(sg);
       }
-      // The column statistics (HBM-bound: K^ and P~ streamed once) run on the second stream BESIDE the weighted Gram
-      // (MFMA-bound): both only need the row weights of the quadrature and write disjoint parts of the bundle.
-      HIP_TRY(hipEventRecord(ev_fork, st));
-      HIP_TRY(hipStreamWaitEvent(st2, ev_fork, 0));
+      // The column statistics (HBM-bound: K^ and P~ streamed once) run on the second stream BESIDE the weighted Gram: both
+      // only need the row weights of the quadrature and write disjoint parts of the bundle.  (Measured alternative: the
+      // column statistics of segment i beside the forward contraction of segment i + 1 -- the Gram gains 4.0 ms, the
+      // forward contractions lose 5.7 ms: an HBM-saturating kernel costs an FP64-MFMA GEMM beside it about its own
+      // stand-alone time either way.)
+      colstats_rows(0, n, 0);
       {
         // H_q += K^T diag(beta) K^ for all latents (svmogp_inf.py:145-147 summed over d)
         const int ksplit = use_windows ? std::min(8, gram_ksplit(n, M)) : gram_ksplit(n, M);
@@ -728,13 +752,8 @@ struct hmogp_engine {
           launch_gemm_f64(g, st);
         }
         {
-          Scope sc(this, CAT_COLSTATS, 2, st2);
-          const long long len = (long long)M * (1 + P), nsp = (n + 255) / 256;
-          ColBatch cb;
-          cb.nq = Q, cb.sK = sK, cb.sA = M, cb.sV = ldn, cb.sZ = P, cb.sPart = nsp * len, cb.sWin = 2 * ncb;
-          launch_colstats(Kh.d(), Pt.d(), a.d(), valpha.d(), valpha0.d(), vbeta0.d(), X, P, dZ.d(), ldz, n, M, 256, want_z,
-                          colpart.d(), st2, cw, &cb);
-          launch_reduce_slabs(colpart.d(), (int)nsp, len, len, Hq(0) + oR, true, st2, Q, nsp * len, per_q);
+          Scope sc(this, CAT_COLSTATS, 1, st2);   // all 256-row slabs of the pool -> bundle
+          launch_reduce_slabs(colpart.d(), (int)nsp, clen, clen, Hq(0) + oR, true, st2, Q, nsp * clen, per_q);
         }
         HIP_TRY(hipEventRecord(ev_col, st2));
         Scope sc2(this, CAT_COLSTATS, 1);  // row-range slabs -> bundle (accounted with the column statistics)
@@ -1086,7 +1105,7 @@ struct hmogp_engine {
         g.fs_ldz = ldz, g.fs_P = P, g.fs_hyper = 0, g.fs_ell = dell.d() + q;
         g.store_c = 0;
         launch_gemm_f64(g, st);
-        launch_combine_parts(fwdpart.d(), 2 * ((M + 127) / 128), n, vp.d() + q * ldn, vc.d() + q * ldn, nullptr, nullptr, st);
+        launch_combine_parts(fwdpart.d(), FWD_PARTS * ((M + 127) / 128), n, vp.d() + q * ldn, vc.d() + q * ldn, nullptr, nullptr, st);
       }
       launch_qf_combine(vp.d(), vc.d(), ldn, n, Q, Df, dW.d(), dkap.d(), dvar.d(), dm.d(), dv.d(), st);
       HIP_TRY(hipMemcpyAsync(m + r0 * Df, dm.p, sizeof(double) * n * Df, hipMemcpyDeviceToHost, st));
@@ -1510,7 +1529,7 @@ int hmogp_bench_contraction(int32_t device, int32_t role, int64_t n, int32_t M, 
     A.ensure(sizeof(double) * n * M), B.ensure(sizeof(double) * MM), Cc.ensure(sizeof(double) * std::max<long long>(n * M, MM));
     beta.ensure(sizeof(double) * n), slabs.ensure(sizeof(double) * MM * gram_ksplit(n, M), true);
     DevBuf part, ell;   // roles 3 / 4: forward contraction with the fused row-statistics epilogue (with / without P~ store)
-    part.ensure(sizeof(double) * 8 * ((M + 127) / 128) * n, true), ell.ensure(sizeof(double), true);
+    part.ensure(sizeof(double) * 4 * FWD_PARTS * ((M + 127) / 128) * n, true), ell.ensure(sizeof(double), true);
     { const double one = 1.0; HIP_TRY(hipMemcpy(ell.p, &one, sizeof(double), hipMemcpyHostToDevice)); }
     std::vector<double> h((size_t)std::max<long long>(n * M, MM));
     unsigned long long s = 88172645463325252ULL;   // xorshift: full-range random operands (DVFS-realistic, guide rule 25)
