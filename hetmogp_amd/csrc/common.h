@@ -105,6 +105,13 @@ struct GemmArgs {
 void launch_combine_parts(const double* part, int tiles, long long n, double* p, double* c, double* pt, double* ct,
                           hipStream_t s, int nb = 1, long long sPart = 0, long long ldn = 0);
 void launch_gemm_f64(const GemmArgs& g, hipStream_t stream);
+// The two row-pass contractions (role 1 / 2) as specialised 8-wave kernels (gemm_rowpass.hip) when the shape allows it,
+// else the general kernel.  Returns the number of fused-row-statistics partials per 128-column tile the role-1 kernel
+// wrote (what launch_combine_parts has to sum): 4 (specialised) or 2 (general).
+bool gemm_rowpass_eligible(const GemmArgs& g);
+void launch_gemm_rowpass(const GemmArgs& g, hipStream_t stream);
+int launch_gemm_rowpass_or_general(const GemmArgs& g, hipStream_t stream);
+constexpr int GEMM_MAX_FWD_PARTS = 4;
 
 // ---- linear algebra on Q x M x M batches (linalg.hip) ---------------------------------------------------
 // In-place lower Cholesky of A[q]; info[q] = 0 or the 1-based index of the first non-positive pivot (LAPACK

@@ -60,7 +60,7 @@ struct DevBuf {
   T* as() const { return static_cast<T*>(p); }
 };
 
-constexpr int FWD_PARTS = 2;  // partials of the fused row statistics per 128-column tile = wave columns of the role-1 GEMM
+constexpr int FWD_PARTS = GEMM_MAX_FWD_PARTS;  // buffer sizing: partials of the fused row statistics per 128-column tile
 
 enum { CAT_TOTAL = 0, CAT_RBF, CAT_FWD, CAT_ROWSTATS, CAT_QUAD, CAT_GRAM, CAT_COLSTATS, CAT_MM, NCAT };
 
@@ -696,6 +696,7 @@ struct hmogp_engine {
           else
             HIP_TRY(hipStreamWaitEvent(st, ev_seg[li], 0));
         }
+        int nparts = 2;
         {
           // forward contraction for all latents (batched), row statistics fused into its epilogue; P~ itself is only
           // stored when the Z gradient (its one remaining consumer, colstats) is requested
@@ -714,11 +715,11 @@ struct hmogp_engine {
           g.fs_z = dZ.d(), g.fs_sZ = P, g.fs_ldz = ldz, g.fs_P = P, g.fs_hyper = want_hyper ? 1 : 0, g.fs_ell = dell.d();
           g.store_c = want_z ? 1 : 0;
           g.win = rw, g.win_stride = 2 * wtiles;
-          launch_gemm_f64(g, st);
+          nparts = launch_gemm_rowpass_or_general(g, st);
         }
         {
           Scope sc2(this, CAT_ROWSTATS, 1);  // sum of the per-column-tile partials of the fused row statistics
-          launch_combine_parts(fwdpart.d() + 4LL * FWD_PARTS * tiles * off, FWD_PARTS * tiles, rows, vp.d() + off, vc.d() + off,
+          launch_combine_parts(fwdpart.d() + 4LL * FWD_PARTS * tiles * off, nparts * tiles, rows, vp.d() + off, vc.d() + off,
                                want_hyper ? vpt.d() + off : nullptr, want_hyper ? vct.d() + off : nullptr, st, Q, sPart, ldn);
         }
       }
@@ -749,7 +750,7 @@ struct hmogp_engine {
         g.win = cw, g.win_stride = 2 * ncb;
         {
           Scope sc(this, CAT_GRAM, 1);
-          launch_gemm_f64(g, st);
+          launch_gemm_rowpass_or_general(g, st);
         }
         {
           Scope sc(this, CAT_COLSTATS, 1, st2);   // all 256-row slabs of the pool -> bundle
@@ -1104,8 +1105,8 @@ struct hmogp_engine {
         g.fs_part = fwdpart.d(), g.fs_a = a.d() + (long long)q * M, g.fs_x = dX.d(), g.fs_z = dZ.d() + q * P;
         g.fs_ldz = ldz, g.fs_P = P, g.fs_hyper = 0, g.fs_ell = dell.d() + q;
         g.store_c = 0;
-        launch_gemm_f64(g, st);
-        launch_combine_parts(fwdpart.d(), FWD_PARTS * ((M + 127) / 128), n, vp.d() + q * ldn, vc.d() + q * ldn, nullptr, nullptr, st);
+        const int nparts = launch_gemm_rowpass_or_general(g, st);
+        launch_combine_parts(fwdpart.d(), nparts * ((M + 127) / 128), n, vp.d() + q * ldn, vc.d() + q * ldn, nullptr, nullptr, st);
       }
       launch_qf_combine(vp.d(), vc.d(), ldn, n, Q, Df, dW.d(), dkap.d(), dvar.d(), dm.d(), dv.d(), st);
       HIP_TRY(hipMemcpyAsync(m + r0 * Df, dm.p, sizeof(double) * n * Df, hipMemcpyDeviceToHost, st));
@@ -1553,7 +1554,7 @@ int hmogp_bench_contraction(int32_t device, int32_t role, int64_t n, int32_t M, 
         g.C = Cc.d(), g.ldc = M;
         g.M = (int)n, g.N = M, g.K = M;
         g.role = 1;
-        launch_gemm_f64(g, nullptr);
+        launch_gemm_rowpass_or_general(g, nullptr);
       } else {
         const int ksplit = gram_ksplit(n, M);
         g.A = A.d(), g.lda = M, g.a_kmajor = 1;
@@ -1562,7 +1563,7 @@ int hmogp_bench_contraction(int32_t device, int32_t role, int64_t n, int32_t M, 
         g.C = slabs.d(), g.ldc = M;
         g.M = g.N = M, g.K = (int)n;
         g.lower_only = 1, g.ksplit = ksplit, g.sSplit = MM, g.role = 2;
-        launch_gemm_f64(g, nullptr);
+        launch_gemm_rowpass_or_general(g, nullptr);
         launch_reduce_slabs_lower(slabs.d(), ksplit, M, Cc.d(), true, nullptr);
       }
     };

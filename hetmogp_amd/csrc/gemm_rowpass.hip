@@ -1,0 +1,348 @@
+// gemm_rowpass.hip -- the two row-pass contractions of the svmogp_inf path as SPECIALISED FP64-MFMA kernels (gfx950):
+//   forward   P~ = K^ C_q  (+ fused row statistics)      n x M x M, A row-major, B k-major        svmogp_inf.py:212-218
+//   Gram      H_q += K^T diag(beta) K^ (lower tiles)     M x M x n, both operands k-major, split over n   :145-147
+// Same block tile (128 x 128 x 16), LDS images, XCD-aware block order and fused epilogue as the general kernel
+// (gemm_f64.hip), but
+//   * EIGHT waves per block, wave tile 64 x 32 (8 accumulators, <= 128 VGPRs): two blocks per CU = FOUR waves per SIMD.
+//     One wave per SIMD reaches half the FP64-MFMA rate, two reach all of it (tools/probes/probe_coissue.hip): with two
+//     waves per SIMD every barrier / waitcnt stall of one idles half the pipe; four leave slack
+//     (tools/probes/probe_gemm8.hip: 67.8 vs 64.0 TFLOP/s on the bare loop);
+//   * a branch-free main loop: full 128-column tiles and a k-extent that is a multiple of 16 are REQUIRED of the
+//     inducing dimension (gemm_rowpass_eligible; anything else takes the general kernel), ragged ROWS are handled by
+//     clamping the row index once per thread (forward) or by a zero k-scale (Gram), so a k-step is: 2-4 vector loads,
+//     32 MFMAs fed by 12 ds_read, 2-4 ds_write, one barrier -- no per-step bookkeeping.
+#include <cstdlib>
+
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, W = 8, NT = W * 64;
+constexpr int KM_LD = 144, RM_LD = 18, TILE_DOUBLES = BK * KM_LD;   // LDS images: see gemm_f64.hip
+constexpr int NB = 2, WN = 32, NWN = 4;                              // wave tile 64 x 32 = 4 x 2 sub-tiles; 4 wave columns
+
+struct Tile {
+  double a[2][TILE_DOUBLES];
+  double b[2][TILE_DOUBLES];
+};
+
+// Diagonal tiles of the lower-only Gram: wave -> wave tile (wm, wn): (1,0) (1,1) (0,0) (1,2) (0,2) (0,3) (1,3) (0,1), i.e.
+// 8, 8, 7, 7, 0, 0, 3, 3 needed sub-tiles: the two waves of every SIMD (w and w + 4) carry 8, 8, 10, 10 instead of 16.
+__device__ __forceinline__ int diag_wm(int w) { return (0x4B >> w) & 1; }
+__device__ __forceinline__ int diag_wn(int w) { return (0x7E84 >> (2 * w)) & 3; }
+
+// ROLE 1 = forward, ROLE 2 = weighted Gram (names the instantiation in profiles, like gemm_f64_kernel's ROLE)
+template <int ROLE>
+__global__ __launch_bounds__(NT, 4) void rowpass_gemm_kernel(GemmArgs g, int tiles_n, int ntiles) {
+  __shared__ __attribute__((aligned(16))) Tile lds;
+  __shared__ __attribute__((aligned(16))) double epi_a[ROLE == 1 ? 128 : 2];
+
+  // ---- which tile / batch / k-range (block b is observed to run on XCD b % 8: speed only) ----------------------------
+  int v = blockIdx.x, split = 0;
+  if (g.ksplit > 1) {               // all tiles of one K range on ONE XCD: they stream the same operand rows concurrently
+    const int xcd = v & 7, idx = v >> 3;
+    split = (idx / ntiles) * 8 + xcd;
+    v = idx % ntiles;
+    if (split >= g.ksplit) return;
+  } else if ((ntiles & 7) == 0) {   // a contiguous range of tiles per XCD: the column tiles of a row panel share its A panel
+    const int cpx = ntiles >> 3;
+    v = (v & 7) * cpx + (v >> 3);
+  }
+  int ti, tj;
+  if (ROLE == 2) {                  // lower tiles only
+    ti = (int)((sqrt(8.0 * (double)v + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= v) ++ti;
+    while (ti * (ti + 1) / 2 > v) --ti;
+    tj = v - ti * (ti + 1) / 2;
+  } else {
+    ti = v / tiles_n;
+    tj = v - ti * tiles_n;
+  }
+  const int batch = blockIdx.z;
+  const int M = g.M, N = g.N, K = g.K;
+  const int i0 = ti * BM, j0 = tj * BN;
+  if (i0 >= M || j0 >= N) return;
+  int wlo = 0;
+  if (ROLE == 1 && g.b_tri > 0) wlo = j0;                      // triangular fold of C: op(B)[k][j] == 0 for k < j
+  const int ksteps = (K - wlo + BK - 1) / BK;
+  const int per = (ksteps + g.ksplit - 1) / g.ksplit;
+  const int kbeg = wlo + split * per * BK;
+  const int kend = min(K, kbeg + per * BK);
+
+  const double* __restrict__ A = g.A + (long long)batch * g.sA;
+  const double* __restrict__ B = g.B + (long long)batch * g.sB;
+  const double* __restrict__ S = (ROLE == 2) ? g.kscale + (long long)batch * g.sS : nullptr;
+  double* __restrict__ C = g.C + (long long)batch * g.sC + (long long)split * g.sSplit;
+  double* fs_part = (ROLE == 1 && g.fs_part) ? g.fs_part + (long long)batch * g.fs_sPart : nullptr;
+
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  int wm = w >> 2, wn = w & 3;
+  unsigned sub = 0xFFu;                                         // bit a*2 + b: sub-tile (a, b) of the wave tile is computed
+  if (ROLE == 2 && ti == tj) {
+    wm = diag_wm(w), wn = diag_wn(w);
+    sub = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if (wn * NB + b <= wm * 4 + a) sub |= 1u << (a * NB + b);
+  }
+  // The forward contraction accumulates the TRANSPOSED sub-tiles (MFMA operands swapped, B fragment columns permuted): lane
+  // (lr, lk) register r of acc[a][b] holds P~[wm*64 + a*16 + lr][wn*32 + b*16 + 4*lk + r] -- a lane owns 4 adjacent columns
+  // of ONE row, so the fused row statistics are in-lane sums + two shuffles and P~ leaves as 16-byte stores.
+  constexpr bool SWAP = (ROLE == 1);
+  const int blr = SWAP ? 4 * (lr & 3) + (lr >> 2) : lr;
+
+  f64x4 acc[4][NB];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  // ---- operand streams: 4 doubles per thread, operand and k-step ------------------------------------------------------
+  // forward: A row-major (thread: row t/4, k's (t%4)*4..+3; rows beyond the matrix read the last row, never stored),
+  //          B k-major   (thread: k row t/32, column pairs (t%32)*2 and +64)
+  // Gram:    A and B k-major over the same rows (thread: k row t/32 ...); rows beyond the range get the k-scale 0
+  const int ar = t >> 2, ak = (t & 3) * 4, bk = t >> 5, bc = (t & 31) * 2;
+  const double* pa;
+  const double* pb;
+  if (ROLE == 1) {
+    pa = A + (long long)min(i0 + ar, M - 1) * g.lda + ak;
+    pb = B + (long long)bk * g.ldb + j0 + bc;
+  } else {
+    pa = A + i0 + bc;
+    pb = B + j0 + bc;
+  }
+  double ra[4], rb[4], ks = 1.0;
+  auto load = [&](int k0) {
+    if (ROLE == 1) {
+      const f64x2 x0 = *reinterpret_cast<const f64x2*>(pa + k0), x1 = *reinterpret_cast<const f64x2*>(pa + k0 + 2);
+      ra[0] = x0.x, ra[1] = x0.y, ra[2] = x1.x, ra[3] = x1.y;
+      const double* q = pb + (long long)k0 * g.ldb;
+      const f64x2 y0 = *reinterpret_cast<const f64x2*>(q), y1 = *reinterpret_cast<const f64x2*>(q + 64);
+      rb[0] = y0.x, rb[1] = y0.y, rb[2] = y1.x, rb[3] = y1.y;
+    } else {
+      const int row = k0 + bk;
+      const long long off = (long long)min(row, K - 1) * g.lda;
+      const f64x2 x0 = *reinterpret_cast<const f64x2*>(pa + off), x1 = *reinterpret_cast<const f64x2*>(pa + off + 64);
+      ra[0] = x0.x, ra[1] = x0.y, ra[2] = x1.x, ra[3] = x1.y;
+      const f64x2 y0 = *reinterpret_cast<const f64x2*>(pb + off), y1 = *reinterpret_cast<const f64x2*>(pb + off + 64);
+      rb[0] = y0.x, rb[1] = y0.y, rb[2] = y1.x, rb[3] = y1.y;
+      ks = (row < kend) ? S[row] : 0.0;
+    }
+  };
+  // (the k-scale is applied at stage time, after the MFMA block: a multiply at load time makes the compiler wait for the
+  // loads in front of the MFMAs and exposes the HBM latency every k-step)
+  auto stage = [&](int buf) {
+    if (ROLE == 1) {
+      double* sa = &lds.a[buf][ar * RM_LD + ak];
+      *reinterpret_cast<f64x2*>(sa) = f64x2{ra[0], ra[1]};
+      *reinterpret_cast<f64x2*>(sa + 2) = f64x2{ra[2], ra[3]};
+    } else {
+      double* sa = &lds.a[buf][bk * KM_LD + bc];
+      *reinterpret_cast<f64x2*>(sa) = f64x2{ra[0], ra[1]};
+      *reinterpret_cast<f64x2*>(sa + 64) = f64x2{ra[2], ra[3]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb[i] *= ks;
+    }
+    double* sb = &lds.b[buf][bk * KM_LD + bc];
+    *reinterpret_cast<f64x2*>(sb) = f64x2{rb[0], rb[1]};
+    *reinterpret_cast<f64x2*>(sb + 64) = f64x2{rb[2], rb[3]};
+  };
+  auto mma = [&](int buf) {
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const double* fpa = (ROLE == 1) ? &lds.a[buf][(wm * 64 + lr) * RM_LD + kk * 4 + lk] : &lds.a[buf][(kk * 4 + lk) * KM_LD + wm * 64 + lr];
+      const double* fpb = &lds.b[buf][(kk * 4 + lk) * KM_LD + wn * WN + blr];
+      double fa[4], fb[NB];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = fpa[i * 16 * (ROLE == 1 ? RM_LD : 1)];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) fb[i] = fpb[i * 16];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          if (ROLE == 2 && !((sub >> (a * NB + b)) & 1u)) continue;   // wave-uniform (scalar) guard; all set off the diagonal
+          acc[a][b] = SWAP ? __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[a][b], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+    }
+  };
+
+  int cur = 0;
+  if (kbeg < kend) {
+    load(kbeg);
+    stage(0);
+  }
+  __syncthreads();
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = (k0 + BK) < kend;
+    if (more) load(k0 + BK);
+    if (ROLE == 1 || sub) mma(cur);
+    if (more) stage(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: D fragment of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg --------------------------
+  if (ROLE == 1 && fs_part) {
+    // Fused row statistics (GemmArgs::fs_*): lane (lr, lk) owns row rl = wm*64 + a*16 + lr and the column quads
+    // wn*32 + b*16 + 4*lk + (0..3), b < 2, of slice a; it re-reads exactly its own 8 values of the K^ tile per slice
+    // (L2/MALL-warm) with LDS-DMA loads (global_load_lds_dwordx4: lane l's 16 bytes land at base + 16*l) into a
+    // wave-private double buffer, slice a+1 in flight while slice a is consumed -- no VGPRs, no block barriers.
+    const int P = g.fs_P;
+    const bool hyper = g.fs_hyper != 0;
+    constexpr int NCH = 2 * NB, WSTAGE = 2 * NCH * 128;
+    double* flat = &lds.a[0][0];                  // Tile = 4 * TILE_DOUBLES contiguous doubles
+    double* stg = flat + w * WSTAGE;              // [2 buffers][NCH chunks][64 lanes][2]
+    double* xs = flat + W * WSTAGE;               // [4][128] inputs of the block's rows / lengthscale (dimension-major)
+    double* zs = xs + 4 * 128;                    // [4][128] inducing inputs of the block's columns / lengthscale
+    static_assert(W * WSTAGE + 2 * 4 * 128 <= 4 * TILE_DOUBLES, "epilogue scratch fits the tile buffers");
+    const int colq = j0 + wn * WN + 4 * lk;       // + b*16 (+ 2h)
+    auto issue = [&](int a) {
+      const int grow = min(i0 + wm * 64 + a * 16 + lr, M - 1);
+      const double* src = A + (long long)grow * g.lda + colq;
+      double* dst = stg + (a & 1) * (NCH * 128);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)               // chunk c = 2*b + h
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (c >> 1) * 16 + (c & 1) * 2),
+                                         (void __attribute__((address_space(3)))*)(dst + c * 128), 16, 0, 0);
+    };
+    issue(0);
+    {
+      const double inv_l = 1.0 / g.fs_ell[batch];
+      for (int e = t; e < 4 * 128; e += NT) {
+        const int p = e >> 7, rr = e & 127;
+        xs[e] = (hyper && i0 + rr < M && p < P) ? g.fs_x[(long long)(i0 + rr) * P + p] * inv_l : 0.0;
+        zs[e] = (hyper && p < P) ? g.fs_z[(long long)batch * g.fs_sZ + (long long)(j0 + rr) * g.fs_ldz + p] * inv_l : 0.0;
+      }
+      if (t < 128) epi_a[t] = g.fs_a[(long long)batch * g.fs_sA + j0 + t];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // slice a has landed (and the previous partial stores)
+      if (a < 3) issue(a + 1);
+      const int rl = wm * 64 + a * 16 + lr;
+      double sp = 0.0, sc = 0.0, spt = 0.0, sct = 0.0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int cl = wn * WN + b * 16 + 4 * lk;  // this lane's 4 adjacent columns of sub-tile b (within the tile)
+        const double* kp = stg + (a & 1) * (NCH * 128) + (2 * b) * 128 + 2 * lane;
+        const f64x2 k01 = *reinterpret_cast<const f64x2*>(kp), k23 = *reinterpret_cast<const f64x2*>(kp + 128);
+        const double kv[4] = {k01.x, k01.y, k23.x, k23.y};
+        const f64x2 a01 = *reinterpret_cast<const f64x2*>(epi_a + cl), a23 = *reinterpret_cast<const f64x2*>(epi_a + cl + 2);
+        const double av[4] = {a01.x, a01.y, a23.x, a23.y};
+        double r2[4] = {0.0, 0.0, 0.0, 0.0};
+        if (hyper) {
+#pragma unroll 1
+          for (int p = 0; p < P; ++p) {              // uniform trip count (P <= 4); rolled: bounded register pressure
+            const f64x2 z01 = *reinterpret_cast<const f64x2*>(zs + p * 128 + cl), z23 = *reinterpret_cast<const f64x2*>(zs + p * 128 + cl + 2);
+            const double zz[4] = {z01.x, z01.y, z23.x, z23.y};
+            const double xp = xs[p * 128 + rl];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const double d = xp - zz[r];
+              r2[r] += d * d;
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double pv = acc[a][b][r];
+          sp += kv[r] * av[r];
+          sc += pv * kv[r];
+          if (hyper) {
+            const double wv = kv[r] * r2[r];
+            spt += wv * av[r];
+            sct += pv * wv;
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {           // the four lanes (lk) that share this row
+        sp += __shfl_xor(sp, o, 64);
+        sc += __shfl_xor(sc, o, 64);
+        if (hyper) {
+          spt += __shfl_xor(spt, o, 64);
+          sct += __shfl_xor(sct, o, 64);
+        }
+      }
+      if (lk == 0 && i0 + rl < M) {                  // partial of (column tile, wave column): [stat][4 * tiles_n][M]
+        double* o = fs_part + ((long long)(NWN * tj + wn)) * M + (i0 + rl);
+        const long long ss = (long long)NWN * tiles_n * M;
+        o[0] = sp, o[ss] = sc;
+        if (hyper) o[2 * ss] = spt, o[3 * ss] = sct;
+      }
+    }
+    if (!g.store_c) return;
+  }
+  if (SWAP) {  // lane (lr, lk): row wm*64 + a*16 + lr, columns wn*32 + b*16 + 4*lk + (0..3)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int row = i0 + wm * 64 + a * 16 + lr;
+      if (row >= M) continue;
+      double* crow = C + (long long)row * g.ldc + j0 + wn * WN + 4 * lk;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        *reinterpret_cast<f64x2*>(crow + b * 16) = f64x2{acc[a][b][0], acc[a][b][1]};
+        *reinterpret_cast<f64x2*>(crow + b * 16 + 2) = f64x2{acc[a][b][2], acc[a][b][3]};
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double* crow = C + (long long)(i0 + wm * 64 + a * 16 + 4 * r + lk) * g.ldc + j0 + wn * WN + lr;
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if ((sub >> (a * NB + b)) & 1u) crow[b * 16] = acc[a][b][r];   // (diagonal tiles: only what lies on or below the diagonal)
+    }
+}
+
+bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+// Can this contraction take the specialised kernel?  (full 128-column tiles of the inducing dimension, k-extent a
+// multiple of 16 for the forward, even leading dimensions and 16-byte aligned operands, none of the general kernel's extras)
+bool gemm_rowpass_eligible(const GemmArgs& g) {
+  if (g.nouter != 1 || g.alpha != 1.0 || g.beta != 0.0 || g.win || g.M_last || g.N_last || g.K_last || g.a_tri) return false;
+  if ((g.lda & 1) || (g.ldb & 1) || (g.ldc & 1) || !aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return false;
+  if ((g.sA & 1) || (g.sB & 1) || (g.sC & 1) || (g.sSplit & 1)) return false;
+  if (g.role == 1)
+    return !g.a_kmajor && g.b_kmajor && !g.lower_only && g.ksplit == 1 && !g.kscale && g.b_tri >= 0 && (g.N % BN) == 0 &&
+           (g.K % BK) == 0 && g.K == g.N && g.M >= 1;
+  if (g.role == 2)
+    return g.a_kmajor && g.b_kmajor && g.lower_only && g.kscale && g.b_tri == 0 && g.M == g.N && (g.N % BN) == 0 &&
+           g.lda == g.ldb && g.K >= 1;
+  return false;
+}
+
+void launch_gemm_rowpass(const GemmArgs& g, hipStream_t stream) {
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  const int ntiles = g.lower_only ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
+  const int gx = (g.ksplit > 1) ? ntiles * ((g.ksplit + 7) / 8) * 8 : ntiles;
+  dim3 grid(gx, 1, g.nbatch);
+  if (g.role == 1)
+    hipLaunchKernelGGL((rowpass_gemm_kernel<1>), grid, dim3(NT), 0, stream, g, tiles_n, ntiles);
+  else
+    hipLaunchKernelGGL((rowpass_gemm_kernel<2>), grid, dim3(NT), 0, stream, g, tiles_n, ntiles);
+}
+
+int launch_gemm_rowpass_or_general(const GemmArgs& g, hipStream_t stream) {
+  static const bool enabled = [] {   // HMOGP_ROWPASS=0 forces the general kernel (A/B measurements)
+    const char* e = getenv("HMOGP_ROWPASS");
+    return !(e && e[0] == '0');
+  }();
+  if (enabled && gemm_rowpass_eligible(g)) {
+    launch_gemm_rowpass(g, stream);
+    return NWN;
+  }
+  launch_gemm_f64(g, stream);
+  return 2;
+}

@@ -12,7 +12,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int BM = 128, BN = 128, BK = 16, KM_LD = 144, RM_LD = 18, TILE = BK * KM_LD;
 
-template <int W>
+template <int W, bool SWAP = false>
 __global__ __launch_bounds__(W * 64, W / 2) void gemm(const double* __restrict__ A, const double* __restrict__ B,
                                                   double* __restrict__ C, int n, int N, int K) {
   constexpr int NT = W * 64, NBSUB = (W == 4) ? 4 : 2, PER = 2048 / NT;  // doubles per thread per operand tile
@@ -59,15 +59,29 @@ __global__ __launch_bounds__(W * 64, W / 2) void gemm(const double* __restrict__
 #pragma unroll
       for (int i = 0; i < 4; ++i) fa[i] = la[cur][(wm * 64 + i * 16 + lr) * RM_LD + kk * 4 + lk];
 #pragma unroll
-      for (int i = 0; i < NBSUB; ++i) fb[i] = lb[cur][(kk * 4 + lk) * KM_LD + wn * (16 * NBSUB) + i * 16 + lr];
+      for (int i = 0; i < NBSUB; ++i) fb[i] = lb[cur][(kk * 4 + lk) * KM_LD + wn * (16 * NBSUB) + i * 16 + (SWAP ? 4 * (lr & 3) + (lr >> 2) : lr)];
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < NBSUB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < NBSUB; ++b)
+          acc[a][b] = SWAP ? __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[a][b], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
     }
     if (more) stage(cur ^ 1);
     __syncthreads();
     cur ^= 1;
+  }
+  if (SWAP) {  // transposed sub-tiles: lane (lr, lk) holds row wm*64 + a*16 + lr, 4 adjacent columns per sub-tile
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      double* crow = C + (long long)(i0 + wm * 64 + a * 16 + lr) * N + j0 + wn * (16 * NBSUB) + 4 * lk;
+#pragma unroll
+      for (int b = 0; b < NBSUB; ++b) {
+        *reinterpret_cast<f64x2*>(crow + b * 16) = f64x2{acc[a][b][0], acc[a][b][1]};
+        *reinterpret_cast<f64x2*>(crow + b * 16 + 2) = f64x2{acc[a][b][2], acc[a][b][3]};
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -91,10 +105,11 @@ int main() {
   hipEvent_t e0, e1;
   hipEventCreate(&e0), hipEventCreate(&e1);
   const int blocks = (n / BM) * (N / BN);
-  for (int variant = 0; variant < 2; ++variant) {
+  for (int variant = 0; variant < 3; ++variant) {
     auto run = [&] {
       if (variant == 0) hipLaunchKernelGGL(gemm<4>, dim3(blocks), dim3(256), 0, 0, A, B, C, n, N, K);
-      else hipLaunchKernelGGL(gemm<8>, dim3(blocks), dim3(512), 0, 0, A, B, C, n, N, K);
+      else if (variant == 1) hipLaunchKernelGGL(gemm<8>, dim3(blocks), dim3(512), 0, 0, A, B, C, n, N, K);
+      else hipLaunchKernelGGL((gemm<8, true>), dim3(blocks), dim3(512), 0, 0, A, B, C, n, N, K);
     };
     run();
     hipDeviceSynchronize();
@@ -109,8 +124,8 @@ int main() {
     hipMemcpy(c.data(), C + 12345 * (size_t)N + 100, sizeof(double) * 16, hipMemcpyDeviceToHost);
     double ref = 0;  // spot check of C[12345][100]
     for (int k = 0; k < K; ++k) ref += h[(size_t)12345 * K + k] * h[(size_t)k * N + 100];
-    printf("W=%d waves/block (%d waves/SIMD): %.3f ms  %.1f TFLOP/s   check %.3e\n", variant ? 8 : 4, variant ? 4 : 2, ms,
-           2.0 * n * N * K / ms / 1e9, c[0] - ref);
+    printf("W=%d waves/block (%d waves/SIMD)%s: %.3f ms  %.1f TFLOP/s   check %.3e\n", variant ? 8 : 4, variant ? 4 : 2,
+           variant == 2 ? " transposed accumulators" : "", ms, 2.0 * n * N * K / ms / 1e9, c[0] - ref);
   }
   return 0;
 }

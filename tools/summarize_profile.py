@@ -25,7 +25,7 @@ def short(name):
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "01"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "02"
     src = os.path.join(ROOT, "gpurun_out", "prof_r%s" % rnd)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -82,12 +82,12 @@ def main():
                 print("MFMA util %-36s grid=%-9d util=%.3f wait_any=%.3f lds_conflict=%.3f" %
                       (r["kernel"][:36], r["grid_threads"], r["mfma_util"], r["wait_any_frac"], r["lds_conflict_frac"]))
     # the forward contraction of the headline workload's full chunk: the dominant kernel's traffic for bench.py
-    fwd = [r for r in rows if r["kernel"].startswith("gemm_f64_kernel<false, true, 1>")]
+    fwd = [r for r in rows if r["kernel"].startswith("rowpass_gemm_kernel<1>") or r["kernel"].startswith("gemm_f64_kernel<false, true, 1>")]
     fwd.sort(key=lambda r: -r["grid_threads"])
     if fwd:
         json.dump({"kernel": fwd[0]["kernel"], "grid_threads": fwd[0]["grid_threads"], "launches": fwd[0]["launches"],
-                   "hbm_bytes_per_launch": fwd[0]["hbm_bytes_per_launch"],
-                   "note": "forward contraction of ONE launch = one pool of rows (all 4 tasks x 200000 rows) x all Q=3 latents of the headline workload; "
+                   "hbm_bytes_per_launch": fwd[0]["hbm_bytes_per_launch"], "source": "profiles/r%s_pmc_hbm.csv" % rnd,
+                   "note": "forward contraction of ONE launch = one task segment (200000 rows) x all Q=3 latents of the headline workload; "
                            "(2*FETCH_SIZE + WRITE_SIZE)*1024 from separate --pmc passes, round %s" % rnd},
                   open(os.path.join(dst, "pmc_forward_gemm.json"), "w"))
 
