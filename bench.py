@@ -228,6 +228,7 @@ def main():
         if reducer is not None:
             line["allreduce_ms_per_step"] = reducer.total_ms / max(reducer.n_calls, 1)
             line["allreduce_bytes"] = 8 * int(reducer.tensor.numel())
+            line["reducer_mode"] = reducer.mode        # "device" = RCCL in place on the engine's HBM buffer
         if world == 1 and not args.no_exact_zero_pass:
             line["exact_zero_windows"] = exact_zero_pass(args, prm, X, Y, N, M, Q, P, out)
         if world == 1 and not args.no_cpu_baseline:

@@ -816,6 +816,12 @@ struct hmogp_engine {
       if (want_qu) {
         launch_dlds(G.d(), Kuui.d(), Sqi.d(), dLdS.d(), MM * Q, st3);
         mm(dLdS.d(), false, L.d(), true, tmpA.d(), 1.0, -1, -1, st3, 0, +1);  // dL_dS L (:175-177), L lower
+        // this tail (product -> pack -> 12.6 MB D2H) is the longer one: the K_uu-side product of the main stream starts
+        // AFTER this one instead of sharing the matrix cores with it, and then runs beside the D2H copy
+        if (want_hz && out->g_L_u && (group_mask & HMOGP_GROUP_QU)) {
+          HIP_TRY(hipEventRecord(ev_S, st3));
+          HIP_TRY(hipStreamWaitEvent(st, ev_S, 0));
+        }
         launch_pack_gl(tmpA.d(), gL.d(), Q, M, st3);
         launch_gmu(Kr.d(), a.d(), gmu.d(), Q, M, st3);
         // the large gradient leaves on this stream as soon as it exists, beside the K_uu-side tail of the main stream

@@ -56,11 +56,25 @@ class StatsReducer(object):
         self.mode = mode
         self.tensor = None
         self.last_ms, self.total_ms, self.n_calls = 0.0, 0.0, 0
+        self.device = int(device)
         if mode == "device":
-            ptr, n = engine.wire_buffer()
-            self.tensor = torch.as_tensor(_DevicePtr(ptr, n), device="cuda:%d" % device)
-            if self.tensor.device.index != int(device):
-                raise RuntimeError("StatsReducer: wire buffer aliased on %s, engine on device %d" % (self.tensor.device, device))
+            # The engine allocates with the system HIP runtime, torch carries its own copy: aliasing the engine's buffer as
+            # a torch tensor works on the configurations tested (see tests/test_dist_gpu.py), but it is not something either
+            # library promises.  If it is refused, fall back to "staged": a torch-owned CUDA tensor filled through the host
+            # (two 12.7 MB PCIe copies per step instead of none) -- slower, never wrong.
+            try:
+                ptr, n = engine.wire_buffer()
+                self.tensor = torch.as_tensor(_DevicePtr(ptr, n), device="cuda:%d" % self.device)
+                if self.tensor.device.index != self.device:
+                    raise RuntimeError("wire buffer aliased on %s, engine on device %d" % (self.tensor.device, self.device))
+            except Exception as exc:                                   # noqa: BLE001
+                import warnings
+                warnings.warn("StatsReducer: cannot alias the engine's wire buffer as a torch tensor (%s); using the "
+                              "host-staged RCCL path" % (exc,))
+                self.mode = "staged"
+        if self.mode == "staged":
+            _, n = engine.wire_buffer()
+            self.tensor = torch.empty(n, dtype=torch.float64, device="cuda:%d" % self.device)
 
     def __call__(self):
         if self.world == 1:
@@ -71,8 +85,24 @@ class StatsReducer(object):
         t0 = time.perf_counter()
         self.engine.wire_pack()                          # synchronous: the triangle is in the wire buffer at return
         if self.mode == "device":
+            try:
+                dist.all_reduce(self.tensor, op=dist.ReduceOp.SUM, group=self.group)
+                torch.cuda.synchronize(self.tensor.device)   # the engine's own stream consumes it next
+            except RuntimeError as exc:
+                if self.n_calls > 0:
+                    raise
+                # refused on first use.  The decision must be the same on every rank: RCCL either accepts the aliased
+                # buffer everywhere or nowhere (same binaries, same driver), so no negotiation is attempted here.
+                import warnings
+                warnings.warn("StatsReducer: RCCL refused the aliased wire buffer (%s); using the host-staged RCCL path" % (exc,))
+                self.mode = "staged"
+                self.tensor = torch.empty(self.tensor.numel(), dtype=torch.float64, device="cuda:%d" % self.device)
+        if self.mode == "staged":
+            self.tensor.copy_(torch.from_numpy(self.engine.wire_read()))
             dist.all_reduce(self.tensor, op=dist.ReduceOp.SUM, group=self.group)
-            torch.cuda.synchronize(self.tensor.device)   # the engine's own stream consumes it next
+            self.engine.wire_write(self.tensor.cpu().numpy())
+        elif self.mode == "device":
+            pass
         else:
             self.engine.wire_write(all_reduce_host(self.engine.wire_read(), self.group))
         self.engine.wire_unpack()
