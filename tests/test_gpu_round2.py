@@ -291,3 +291,43 @@ def test_het_likelihood_samples_run_on_the_device():
     Y2 = lik.samples(F, md)
     assert [y.shape for y in Y1] == [(50, 1)] * 3 and all(np.array_equal(a, b) for a, b in zip(Y1, Y2))
     assert set(np.unique(Y1[1])) <= {1.0, 2.0, 3.0} and np.all(Y1[2] > 0)
+
+
+# ------------------------------------------------------------------------------------------------ specialised row-pass GEMMs
+@pytest.mark.parametrize("M,Ns,P", [(128, [777, 130, 1], 1), (256, [1030, 515], 2), (384, [2049, 17, 640], 1)])
+def test_specialised_rowpass_kernels_vs_oracle(M, Ns, P):
+    """gemm_rowpass.hip (8-wave forward / Gram kernels, taken when the inducing dimension is a multiple of 128) with ragged
+    row counts (not multiples of 128 nor of 16, a 1-row task), full gradients and the E-step's triangular fold, against
+    the oracle; and several pools (row chunks) against one."""
+    from oracle import svmogp_oracle as so
+    from hetmogp_amd import _lib
+    specs = [("Gaussian", {"sigma": 0.5}), ("Poisson", {}), ("Bernoulli", {})][:len(Ns)]
+    Q = 2
+    prm, prob, X, Y = synth(50 + M, specs, Ns, M, Q, P, (1.0, 1.25))
+    want = so.elbo_grad_fused(prm, prob, X, Y)
+    e = make_engine(prob, X, Y)
+    out = run(e, prm)
+    for k in KEYS:
+        assert rel(out[k], want[k]) < 1e-8, k
+    qu = run(e, prm, group_mask=_lib.GROUP_QU)            # forward against tril-folded C (b_tri), no P~ store
+    for k in ("elbo", "g_m_u", "g_L_u"):
+        assert rel(qu[k], want[k]) < 1e-8, k
+    hz = run(e, prm, group_mask=_lib.GROUP_HYPER)         # hyper statistics without the Z gradient: P~ never stored
+    for k in ("elbo", "g_variance", "g_lengthscale", "g_W"):
+        assert rel(hz[k], want[k]) < 1e-8, k
+    e2 = make_engine(prob, X, Y, chunk_rows=300)
+    chunked = run(e2, prm)
+    for k in KEYS:          # summation order only; the 2-D case has cond(K_uu) ~ 1e6 (random inducing jitter), hence 5e-8
+        assert rel(chunked[k], out[k]) < 5e-8 and rel(chunked[k], want[k]) < 5e-8, k
+    m, v = e.predict_f(X[0])
+    u = so.u_algebra(prm, prob)
+    for d in range(prob["Df"]):
+        if prob["f_index"][d] != 0:
+            continue
+        mm_, vv_ = 0.0, 0.0
+        for q in range(Q):
+            K = so.rbf_K(X[0], prm["Z"][:, q * P:(q + 1) * P], prm["variance"][q], prm["lengthscale"][q])
+            w = prm["W"][q, d]
+            mm_ = mm_ + w * (K @ u["a"][q])
+            vv_ = vv_ + (w * w + prm["kappa"][q, d]) * prm["variance"][q] + w * w * np.sum((K @ u["C"][q]) * K, 1)
+        assert rel(m[:, d], mm_) < 1e-8 and rel(v[:, d], vv_) < 2e-7    # (v = prior - explained: cancellation x cond(K_uu))
