@@ -1499,7 +1499,7 @@ int hmogp_sample(int32_t device, int32_t lik_id, double lik_param, int64_t N, ui
 int hmogp_bench_contraction(int32_t device, int32_t role, int64_t n, int32_t M, int32_t iters, double* avg_ms) {
   return guarded(nullptr, [&] {
     need_device(device);
-    if (n <= 0 || M <= 0 || iters <= 0 || !avg_ms || role < 1 || role > 5) throw EngineError{HMOGP_E_INVALID, "bad arguments"};
+    if (n <= 0 || M <= 0 || iters <= 0 || !avg_ms || role < 1 || role > 6) throw EngineError{HMOGP_E_INVALID, "bad arguments"};
     const long long MM = (long long)M * M;
     if (role == 5) {  // K_uf construction alone: the launch shape of the row pass (3 latents batched, P = 1, hot-path variant)
       const int Qb = 3;
@@ -1550,7 +1550,16 @@ int hmogp_bench_contraction(int32_t device, int32_t role, int64_t n, int32_t M, 
     HIP_TRY(hipEventCreate(&e1));
     auto once = [&] {
       GemmArgs g;
-      if (role != 2) {
+      if (role == 6) {   // diagnostic: the weighted Gram over ALL 64 tiles (no lower-only handling), general kernel
+        const int ksplit = gram_ksplit(n, M);
+        g.A = A.d(), g.lda = M, g.a_kmajor = 1;
+        g.B = A.d(), g.ldb = M, g.b_kmajor = 1;
+        g.kscale = beta.d();
+        g.C = slabs.d(), g.ldc = M;
+        g.M = g.N = M, g.K = (int)n;
+        g.lower_only = 0, g.ksplit = ksplit, g.sSplit = MM, g.role = 2;
+        launch_gemm_f64(g, nullptr);
+      } else if (role != 2) {
         if (role >= 3) {
           g.fs_part = part.d(), g.fs_a = beta.d(), g.fs_x = beta.d(), g.fs_z = B.d(), g.fs_ldz = 1, g.fs_P = 1;
           g.fs_hyper = 1, g.fs_ell = ell.d(), g.store_c = role == 3 ? 1 : 0;

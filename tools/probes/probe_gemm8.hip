@@ -12,7 +12,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int BM = 128, BN = 128, BK = 16, KM_LD = 144, RM_LD = 18, TILE = BK * KM_LD;
 
-template <int W, bool SWAP = false>
+template <int W, bool SWAP = false, bool FRAGPF = false>
 __global__ __launch_bounds__(W * 64, W / 2) void gemm(const double* __restrict__ A, const double* __restrict__ B,
                                                   double* __restrict__ C, int n, int N, int K) {
   constexpr int NT = W * 64, NBSUB = (W == 4) ? 4 : 2, PER = 2048 / NT;  // doubles per thread per operand tile
@@ -53,19 +53,41 @@ __global__ __launch_bounds__(W * 64, W / 2) void gemm(const double* __restrict__
   for (int k0 = 0; k0 < K; k0 += BK) {
     const bool more = k0 + BK < K;
     if (more) load(k0 + BK);
+    if (!FRAGPF) {
 #pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      double fa[4], fb[NBSUB];
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        double fa[4], fb[NBSUB];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = la[cur][(wm * 64 + i * 16 + lr) * RM_LD + kk * 4 + lk];
+        for (int i = 0; i < 4; ++i) fa[i] = la[cur][(wm * 64 + i * 16 + lr) * RM_LD + kk * 4 + lk];
 #pragma unroll
-      for (int i = 0; i < NBSUB; ++i) fb[i] = lb[cur][(kk * 4 + lk) * KM_LD + wn * (16 * NBSUB) + i * 16 + (SWAP ? 4 * (lr & 3) + (lr >> 2) : lr)];
+        for (int i = 0; i < NBSUB; ++i) fb[i] = lb[cur][(kk * 4 + lk) * KM_LD + wn * (16 * NBSUB) + i * 16 + (SWAP ? 4 * (lr & 3) + (lr >> 2) : lr)];
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < NBSUB; ++b)
-          acc[a][b] = SWAP ? __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[a][b], 0, 0, 0)
-                           : __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < NBSUB; ++b)
+            acc[a][b] = SWAP ? __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[a][b], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      }
+    } else {  // fragments of k4-step kk+1 are read from LDS before the MFMAs of kk are issued (two register sets)
+      double fa[2][4], fb[2][NBSUB];
+      auto frag = [&](int kk, int s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[s][i] = la[cur][(wm * 64 + i * 16 + lr) * RM_LD + kk * 4 + lk];
+#pragma unroll
+        for (int i = 0; i < NBSUB; ++i) fb[s][i] = lb[cur][(kk * 4 + lk) * KM_LD + wn * (16 * NBSUB) + i * 16 + (SWAP ? 4 * (lr & 3) + (lr >> 2) : lr)];
+      };
+      frag(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        if (kk + 1 < BK / 4) frag(kk + 1, (kk + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch in front of this k4-step's MFMAs
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < NBSUB; ++b)
+            acc[a][b] = SWAP ? __builtin_amdgcn_mfma_f64_16x16x4f64(fb[kk & 1][b], fa[kk & 1][a], acc[a][b], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f64_16x16x4f64(fa[kk & 1][a], fb[kk & 1][b], acc[a][b], 0, 0, 0);
+      }
     }
     if (more) stage(cur ^ 1);
     __syncthreads();
@@ -105,11 +127,13 @@ int main() {
   hipEvent_t e0, e1;
   hipEventCreate(&e0), hipEventCreate(&e1);
   const int blocks = (n / BM) * (N / BN);
-  for (int variant = 0; variant < 3; ++variant) {
+  for (int variant = 0; variant < 5; ++variant) {
     auto run = [&] {
       if (variant == 0) hipLaunchKernelGGL(gemm<4>, dim3(blocks), dim3(256), 0, 0, A, B, C, n, N, K);
       else if (variant == 1) hipLaunchKernelGGL(gemm<8>, dim3(blocks), dim3(512), 0, 0, A, B, C, n, N, K);
-      else hipLaunchKernelGGL((gemm<8, true>), dim3(blocks), dim3(512), 0, 0, A, B, C, n, N, K);
+      else if (variant == 2) hipLaunchKernelGGL((gemm<8, true>), dim3(blocks), dim3(512), 0, 0, A, B, C, n, N, K);
+      else if (variant == 3) hipLaunchKernelGGL((gemm<8, false, true>), dim3(blocks), dim3(512), 0, 0, A, B, C, n, N, K);
+      else hipLaunchKernelGGL((gemm<8, true, true>), dim3(blocks), dim3(512), 0, 0, A, B, C, n, N, K);
     };
     run();
     hipDeviceSynchronize();
@@ -125,7 +149,7 @@ int main() {
     double ref = 0;  // spot check of C[12345][100]
     for (int k = 0; k < K; ++k) ref += h[(size_t)12345 * K + k] * h[(size_t)k * N + 100];
     printf("W=%d waves/block (%d waves/SIMD)%s: %.3f ms  %.1f TFLOP/s   check %.3e\n", variant ? 8 : 4, variant ? 4 : 2,
-           variant == 2 ? " transposed accumulators" : "", ms, 2.0 * n * N * K / ms / 1e9, c[0] - ref);
+           variant == 2 ? " transposed accumulators" : (variant == 3 ? " fragment prefetch" : (variant == 4 ? " transposed + fragment prefetch" : "")), ms, 2.0 * n * N * K / ms / 1e9, c[0] - ref);
   }
   return 0;
 }
