@@ -222,3 +222,55 @@ def test_bench_self_launches_two_ranks():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and sum(line["rows_per_rank"]) == 4 * 20000
     assert line["allreduce_ms_per_step"] > 0.0
+
+
+def _facade_nccl_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from test_facade_gpu import build_model
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    g = np.load(os.path.join(ROOT, "tests", "golden", "model_config2_full.npz"))
+    import hetmogp_amd.svmogp as sv
+    orig = sv.SVMOGP.__init__
+
+    def patched(self, *a, **kw):                      # same fixture builder; device defaults to LOCAL_RANK
+        kw["distributed"] = True
+        return orig(self, *a, **kw)
+    sv.SVMOGP.__init__ = patched
+    model = build_model(g)
+    assert model._dist[1].mode == "device" and model._engine is not None
+    model.parameters_changed()
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, float(model.log_likelihood()[0, 0]), np.asarray(model.Z.gradient), np.asarray(model.q_u_chols.gradient)))
+
+
+@pytest.mark.timeout(600)
+def test_facade_distributed_two_gpus_rccl_matches_reference_fixture():
+    """SVMOGP(distributed=True) on two ranks, one GPU each, backend nccl (device defaults to LOCAL_RANK, device-mode
+    reducer on the wire buffer): every rank reproduces the reference's parameters_changed() fixture.  Skipped on 1-GPU boxes."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    import torch.multiprocessing as mp
+    g = np.load(os.path.join(ROOT, "tests", "golden", "model_config2_full.npz"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_facade_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, elbo, gZ, gL in res:
+        assert abs(elbo - float(np.ravel(g["elbo"])[0])) < 1e-8 * abs(float(np.ravel(g["elbo"])[0]))
+        assert np.max(np.abs(gZ - g["g_Z"])) < 1e-8 * np.max(np.abs(g["g_Z"]))
+        assert np.max(np.abs(gL - g["g_L_u"])) < 1e-8 * np.max(np.abs(g["g_L_u"]))
