@@ -303,7 +303,18 @@ struct hmogp_engine {
       int lo = 0, hi = 0;
       HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
       HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
-      HIP_TRY(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, lo));
+      // HMOGP_ST2_CUS=<n> (experiment): give the second stream a CU mask of n of the device's CUs instead of a low
+      // priority, so that the latency-bound chains of the other streams always find free CUs beside its HBM-bound work
+      const char* cus_env = getenv("HMOGP_ST2_CUS");
+      int cus = cus_env ? atoi(cus_env) : 0;
+      hipDeviceProp_t prop;
+      HIP_TRY(hipGetDeviceProperties(&prop, device));
+      if (cus > 0 && cus < prop.multiProcessorCount) {
+        std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0u);
+        for (int i = 0; i < cus; ++i) mask[i / 32] |= 1u << (i % 32);
+        if (hipExtStreamCreateWithCUMask(&st2, (uint32_t)mask.size(), mask.data()) != hipSuccess) st2 = nullptr;
+      }
+      if (!st2) HIP_TRY(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, lo));
       HIP_TRY(hipStreamCreateWithPriority(&st3, hipStreamNonBlocking, hi));
     }
     for (hipEvent_t* e : {&ev_fork, &ev_S, &ev_join, &ev_col, &ev_kuf, &ev_params, &ev_ua})
