@@ -112,6 +112,10 @@ bool gemm_rowpass_eligible(const GemmArgs& g);
 void launch_gemm_rowpass(const GemmArgs& g, hipStream_t stream);
 int launch_gemm_rowpass_or_general(const GemmArgs& g, hipStream_t stream);
 constexpr int GEMM_MAX_FWD_PARTS = 4;
+// 64 x 64-tile kernel for the replicated M x M products (gemm_small.hip); launch_gemm_f64 picks it when the 128-tile grid
+// would leave the device under-filled (env HMOGP_SMALL_GEMM=0 disables it).
+bool gemm_small_eligible(const GemmArgs& g);
+void launch_gemm_small(const GemmArgs& g, hipStream_t stream);
 
 // ---- linear algebra on Q x M x M batches (linalg.hip) ---------------------------------------------------
 // In-place lower Cholesky of A[q]; info[q] = 0 or the 1-based index of the first non-positive pivot (LAPACK

@@ -467,6 +467,15 @@ void launch_gemm_f64(const GemmArgs& g, hipStream_t stream) {
   if (g.kscale && !g.b_kmajor) throw HipError{hipErrorInvalidValue, "k-scale needs a k-major B operand", __FILE__, __LINE__};
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   const int ntiles = g.lower_only ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
+  // fewer than two 128 x 128 blocks per CU: one wave per SIMD reaches half the MFMA rate -> 64 x 64 tiles (gemm_small.hip)
+  static const bool small_enabled = [] {
+    const char* e = getenv("HMOGP_SMALL_GEMM");
+    return !(e && e[0] == '0');
+  }();
+  if (small_enabled && (long long)tiles_m * tiles_n * g.nouter * g.nbatch < 512 && gemm_small_eligible(g)) {
+    launch_gemm_small(g, stream);
+    return;
+  }
   const int gx = (g.ksplit > 1) ? ntiles * ((g.ksplit + 7) / 8) * 8 : ntiles;
   dim3 grid(gx, g.nouter, g.nbatch), block(NTHREADS);
   if (g.role == 1 && !g.a_kmajor && g.b_kmajor)

@@ -41,6 +41,21 @@ def test_gemm_f64_all_layouts(E, tA, tB, shape):
     assert rel(got, want) < 1e-13
 
 
+@pytest.mark.parametrize("tA,tB", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("shape", [(256, 256, 256), (320, 64, 48), (256, 192, 1024), (1024, 1024, 1024)])
+def test_gemm_f64_small_tiles(E, tA, tB, shape):
+    """beta = 0, extents that are multiples of 64 and fewer than 512 tiles of 128 x 128: launch_gemm_f64 takes the
+    64 x 64-tile kernel (gemm_small.hip).  C starts as NaN: it must be overwritten, never read."""
+    M, N, K = shape
+    rng = np.random.RandomState(M + 3 * N + 7 * K + tA * 2 + tB)
+    A = rng.randn(K, M) if tA else rng.randn(M, K)
+    B = rng.randn(N, K) if tB else rng.randn(K, N)
+    A += np.arange(A.shape[1])[None, :] * 0.01
+    want = -0.3 * (A.T if tA else A) @ (B.T if tB else B)
+    got = E.gemm(A, B, transA=bool(tA), transB=bool(tB), alpha=-0.3, beta=0.0, C0=np.full((M, N), np.nan))
+    assert rel(got, want) < 1e-13
+
+
 @pytest.mark.parametrize("P,N,M", [(1, 100, 37), (1, 257, 64), (2, 65, 50), (3, 33, 16), (1, 5, 1030)])
 def test_rbf_cross_cov(E, P, N, M):
     from oracle import svmogp_oracle as so
