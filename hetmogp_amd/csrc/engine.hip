@@ -1561,7 +1561,7 @@ int hmogp_bench_contraction(int32_t device, int32_t role, int64_t n, int32_t M, 
     HIP_TRY(hipEventCreate(&e1));
     auto once = [&] {
       GemmArgs g;
-      if (role == 6) {   // diagnostic: the weighted Gram over ALL 64 tiles (no lower-only handling), general kernel
+      if (role == 6) {   // diagnostic: the weighted Gram over ALL tiles (no lower-only handling), no slab reduction
         const int ksplit = gram_ksplit(n, M);
         g.A = A.d(), g.lda = M, g.a_kmajor = 1;
         g.B = A.d(), g.ldb = M, g.b_kmajor = 1;
@@ -1569,7 +1569,7 @@ int hmogp_bench_contraction(int32_t device, int32_t role, int64_t n, int32_t M, 
         g.C = slabs.d(), g.ldc = M;
         g.M = g.N = M, g.K = (int)n;
         g.lower_only = 0, g.ksplit = ksplit, g.sSplit = MM, g.role = 2;
-        launch_gemm_f64(g, nullptr);
+        launch_gemm_rowpass_or_general(g, nullptr);
       } else if (role != 2) {
         if (role >= 3) {
           g.fs_part = part.d(), g.fs_a = beta.d(), g.fs_x = beta.d(), g.fs_z = B.d(), g.fs_ldz = 1, g.fs_P = 1;

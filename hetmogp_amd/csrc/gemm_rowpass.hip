@@ -39,22 +39,42 @@ __global__ __launch_bounds__(NT, 4) void rowpass_gemm_kernel(GemmArgs g, int til
 
   // ---- which tile / batch / k-range (block b is observed to run on XCD b % 8: speed only) ----------------------------
   int v = blockIdx.x, split = 0;
-  if (g.ksplit > 1) {               // all tiles of one K range on ONE XCD: they stream the same operand rows concurrently
-    const int xcd = v & 7, idx = v >> 3;
-    split = (idx / ntiles) * 8 + xcd;
-    v = idx % ntiles;
-    if (split >= g.ksplit) return;
-  } else if ((ntiles & 7) == 0) {   // a contiguous range of tiles per XCD: the column tiles of a row panel share its A panel
-    const int cpx = ntiles >> 3;
-    v = (v & 7) * cpx + (v >> 3);
-  }
   int ti, tj;
-  if (ROLE == 2) {                  // lower tiles only
-    ti = (int)((sqrt(8.0 * (double)v + 1.0) - 1.0) * 0.5);
-    while ((ti + 1) * (ti + 2) / 2 <= v) ++ti;
-    while (ti * (ti + 1) / 2 > v) --ti;
-    tj = v - ti * (ti + 1) / 2;
+  if (ROLE == 2 && g.lower_only) {
+    // Lower tiles of the Gram, in TWO phases of equal-duration blocks.  The tiles of one K range stream the same operand rows,
+    // and they only share them through the XCD's L2 if they START together: blocks of unequal duration (a diagonal tile does
+    // ~0.6 of the work) spread the start times of everything behind them and the sharing is lost (measured: 36 mixed tiles
+    // per range run as slowly as 36 full ones).  So: first all strictly-lower tiles, range-major, all tiles of one K range on
+    // ONE XCD (block b is observed to run on XCD b % 8: speed only); then the diagonal tiles, which share nothing (tile
+    // (d, d) reads panel d only).
+    const int T = tiles_n, noff = T * (T - 1) / 2, ks8 = (g.ksplit > 1) ? ((g.ksplit + 7) / 8) * 8 : 1, gx1 = noff * ks8;
+    if (v < gx1) {
+      int u = v;                                          // strictly-lower index: u = ti (ti - 1) / 2 + tj, tj < ti
+      if (g.ksplit > 1) {
+        const int xcd = v & 7, idx = v >> 3;
+        split = (idx / noff) * 8 + xcd;
+        u = idx % noff;
+      }
+      ti = (int)((sqrt(8.0 * (double)u + 1.0) + 1.0) * 0.5);
+      while (ti * (ti + 1) / 2 <= u) ++ti;
+      while (ti * (ti - 1) / 2 > u) --ti;
+      tj = u - ti * (ti - 1) / 2;
+    } else {
+      const int u = v - gx1;
+      split = u / T;
+      ti = tj = u - split * T;
+    }
+    if (split >= g.ksplit) return;
   } else {
+    if (g.ksplit > 1) {               // all tiles of one K range on ONE XCD: they stream the same operand rows concurrently
+      const int xcd = v & 7, idx = v >> 3;
+      split = (idx / ntiles) * 8 + xcd;
+      v = idx % ntiles;
+      if (split >= g.ksplit) return;
+    } else if ((ntiles & 7) == 0) {   // a contiguous range of tiles per XCD: the column tiles of a row panel share its A panel
+      const int cpx = ntiles >> 3;
+      v = (v & 7) * cpx + (v >> 3);
+    }
     ti = v / tiles_n;
     tj = v - ti * tiles_n;
   }
@@ -79,7 +99,7 @@ __global__ __launch_bounds__(NT, 4) void rowpass_gemm_kernel(GemmArgs g, int til
   const int lr = lane & 15, lk = lane >> 4;
   int wm = w >> 2, wn = w & 3;
   unsigned sub = 0xFFu;                                         // bit a*2 + b: sub-tile (a, b) of the wave tile is computed
-  if (ROLE == 2 && ti == tj) {
+  if (ROLE == 2 && ti == tj && g.lower_only) {
     wm = diag_wm(w), wn = diag_wn(w);
     sub = 0;
 #pragma unroll
@@ -318,7 +338,7 @@ bool gemm_rowpass_eligible(const GemmArgs& g) {
     return !g.a_kmajor && g.b_kmajor && !g.lower_only && g.ksplit == 1 && !g.kscale && g.b_tri >= 0 && (g.N % BN) == 0 &&
            (g.K % BK) == 0 && g.K == g.N && g.M >= 1;
   if (g.role == 2)
-    return g.a_kmajor && g.b_kmajor && g.lower_only && g.kscale && g.b_tri == 0 && g.M == g.N && (g.N % BN) == 0 &&
+    return g.a_kmajor && g.b_kmajor && g.kscale && g.b_tri == 0 && g.M == g.N && (g.N % BN) == 0 &&
            g.lda == g.ldb && g.K >= 1;
   return false;
 }

@@ -292,7 +292,7 @@ int hmogp_sample(int32_t device, int32_t lik_id, double lik_param, int64_t N, ui
  * role 1: forward  P~[n,M] = K^[n,M] C[M,M];  role 2: weighted Gram  H[M,M] (lower tiles) = K^T diag(beta) K^ incl. the
  * slab reduction; roles 3 / 4: role 1 with the fused row-statistics epilogue, with / without the P~ store; role 5: K_uf
  * construction alone (rbf_kernel<1, false>, 3 latents batched: 3 * 8 * n * M bytes written per launch); role 6
- * (diagnostic): role 2 over ALL tiles instead of the lower ones, general kernel, no slab reduction (2 n M^2 flops).
+ * (diagnostic): role 2 over ALL tiles instead of the lower ones, same kernel, no slab reduction (2 n M^2 flops).
  * Returns the average milliseconds per launch over `iters` launches (HIP events).                              */
 int hmogp_bench_contraction(int32_t device, int32_t role, int64_t n, int32_t M, int32_t iters, double* avg_ms);
 
