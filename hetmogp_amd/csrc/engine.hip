@@ -226,7 +226,7 @@ struct hmogp_engine {
   hipEvent_t ev_begin0 = nullptr, ev_begin1 = nullptr, ev_fin0 = nullptr, ev_fin1 = nullptr;
   hipStream_t st2 = nullptr;  // second stream, LOW priority: bandwidth-bound work beside the main stream (K_uf prefetch, colstats)
   hipStream_t st3 = nullptr;  // third stream, HIGH priority like the main one: the q(u)-only chains (S, S^-1; dL/dL, D2H)
-  hipEvent_t ev_fork = nullptr, ev_S = nullptr, ev_join = nullptr, ev_col = nullptr, ev_kuf = nullptr, ev_params = nullptr,
+  hipEvent_t ev_fork = nullptr, ev_gsk = nullptr, ev_S = nullptr, ev_join = nullptr, ev_col = nullptr, ev_kuf = nullptr, ev_params = nullptr,
              ev_ua = nullptr;
 
   hipEvent_t new_event() {
@@ -265,7 +265,7 @@ struct hmogp_engine {
   ~hmogp_engine() {
     for (auto e : pool) (void)hipEventDestroy(e);
     for (auto e : ev_seg) (void)hipEventDestroy(e);
-    for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_S, ev_join, ev_col, ev_kuf, ev_params, ev_ua})
+    for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_gsk, ev_S, ev_join, ev_col, ev_kuf, ev_params, ev_ua})
       if (e) (void)hipEventDestroy(e);
     if (hstage) (void)hipHostFree(hstage);
     if (h_info) (void)hipHostFree(h_info);
@@ -317,7 +317,7 @@ struct hmogp_engine {
       if (!st2) HIP_TRY(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, lo));
       HIP_TRY(hipStreamCreateWithPriority(&st3, hipStreamNonBlocking, hi));
     }
-    for (hipEvent_t* e : {&ev_fork, &ev_S, &ev_join, &ev_col, &ev_kuf, &ev_params, &ev_ua})
+    for (hipEvent_t* e : {&ev_fork, &ev_gsk, &ev_S, &ev_join, &ev_col, &ev_kuf, &ev_params, &ev_ua})
       HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (hipEvent_t* e : {&ev_begin0, &ev_begin1, &ev_fin0, &ev_fin1}) HIP_TRY(hipEventCreate(e));
     f_index.assign(c->f_index, c->f_index + Df);
@@ -826,15 +826,22 @@ struct hmogp_engine {
       HIP_TRY(hipStreamWaitEvent(st3, ev_fork, 0));
       if (want_qu) {
         launch_dlds(G.d(), Kuui.d(), Sqi.d(), dLdS.d(), MM * Q, st3);
+        HIP_TRY(hipEventRecord(ev_S, st3));
         mm(dLdS.d(), false, L.d(), true, tmpA.d(), 1.0, -1, -1, st3, 0, +1);  // dL_dS L (:175-177), L lower
-        // this tail (product -> pack -> 12.6 MB D2H) is the longer one: the K_uu-side product of the main stream starts
-        // AFTER this one instead of sharing the matrix cores with it, and then runs beside the D2H copy
-        if (want_hz && out->g_L_u && (group_mask & HMOGP_GROUP_QU)) {
-          HIP_TRY(hipEventRecord(ev_S, st3));
-          HIP_TRY(hipStreamWaitEvent(st, ev_S, 0));
-        }
         launch_pack_gl(tmpA.d(), gL.d(), Q, M, st3);
         launch_gmu(Kr.d(), a.d(), gmu.d(), Q, M, st3);
+      }
+      if (want_hz) {
+        // G S K^-1 (tmp_dv, :151), released together with dL/dS L of the q(u) tail: the two products share the matrix cores.
+        // The 12.6 MB D2H copy of that tail waits for both: a product that is still running when the copy starts does
+        // not finish before the copy does (363-438 us instead of 121 measured, whichever stream or priority it is on);
+        // the small kernels behind it run beside the copy.
+        if (want_qu) HIP_TRY(hipStreamWaitEvent(st, ev_S, 0));
+        mm(G.d(), false, KiS.d(), false, GSK.d());
+        HIP_TRY(hipEventRecord(ev_gsk, st));
+        if (want_qu) HIP_TRY(hipStreamWaitEvent(st3, ev_gsk, 0));
+      }
+      if (want_qu) {
         // the large gradient leaves on this stream as soon as it exists, beside the K_uu-side tail of the main stream
         if (out->g_L_u && (group_mask & HMOGP_GROUP_QU))
           HIP_TRY(hipMemcpyAsync(out->g_L_u, gL.p, sizeof(double) * Mtri * Q, hipMemcpyDeviceToHost, st3));
@@ -843,7 +850,6 @@ struct hmogp_engine {
       }
       HIP_TRY(hipEventRecord(ev_join, st3));
       if (want_hz) {
-        mm(G.d(), false, KiS.d(), false, GSK.d());                   // G S K^-1        (tmp_dv, :151)
         launch_dkmm(G.d(), GSK.d(), Kuui.d(), KSK.d(), Kr.d(), a.d(), dKmm.d(), Q, M, st);
         launch_kzz_rows(dKmm.d(), dZ.d(), Q * P, P, dvar.d(), dell.d(), Q, M, rowout.d(), st);
       }
