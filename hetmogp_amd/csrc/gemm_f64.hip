@@ -198,9 +198,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-  // The loads of tile k+1 are issued before the MFMA block of tile k and must not be consumed until `stage` (after the
-  // MFMA block): the k-scale of the Gram operand is therefore applied at stage time, not at load time (a multiply at
-  // load time makes hipcc wait vmcnt(0) in front of the MFMAs and exposes the whole HBM latency every k-step).
+  // The loads of a tile are issued one k-step before they are consumed by `stage`: the k-scale of the Gram operand is
+  // therefore applied at stage time, not at load time (a multiply at load time makes hipcc wait vmcnt(0) right behind the
+  // loads and exposes the whole HBM latency every k-step).
   double ra[8], rb[8], ks = 1.0;
   auto load = [&](int k0) {
     const bool fk = (k0 + BK <= kend);
@@ -258,15 +258,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
     }
   };
 
+  // stage-first software pipeline (see gemm_rowpass.hip): step k + 1 goes from registers to the other buffer before the MFMA
+  // block of step k, the registers are refilled with step k + 2 at once
   int cur = 0;
   if (kbeg < kend) {
     load(kbeg);
     stage(0);
+    if (kbeg + BK < kend) load(kbeg + BK);
   }
   __syncthreads();
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = (k0 + BK) < kend;
-    if (more) load(k0 + BK);
+    if (k0 + BK < kend) stage(cur ^ 1);
+    if (k0 + 2 * BK < kend) load(k0 + 2 * BK);
     if (ROLE == 2 && mma_mode != 0) {
       if (mma_mode == 1) mma(cur, std::integral_constant<int, 1>{});
       else if (mma_mode == 2) mma(cur, std::integral_constant<int, 2>{});
@@ -274,7 +277,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_kernel(GemmArgs g, int t
     } else if (!idle_quadrant) {
       mma(cur, std::integral_constant<int, 0>{});
     }
-    if (more) stage(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }

@@ -191,17 +191,20 @@ __global__ __launch_bounds__(NT, 4) void rowpass_gemm_kernel(GemmArgs g, int til
     }
   };
 
+  // Software pipeline: the operands of step k + 1 are in registers when step k starts; they are staged into the other LDS
+  // buffer BEFORE the MFMA block of step k (so the ds_write latency is covered by it and the barrier follows the last MFMA
+  // directly) and the registers are refilled at once with step k + 2.
   int cur = 0;
   if (kbeg < kend) {
     load(kbeg);
     stage(0);
+    if (kbeg + BK < kend) load(kbeg + BK);
   }
   __syncthreads();
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = (k0 + BK) < kend;
-    if (more) load(k0 + BK);
+    if (k0 + BK < kend) stage(cur ^ 1);
+    if (k0 + 2 * BK < kend) load(k0 + 2 * BK);
     if (ROLE == 1 || sub) mma(cur);
-    if (more) stage(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }

@@ -83,15 +83,18 @@ __global__ __launch_bounds__(NTH, 3) void gemm_small_kernel(GemmArgs g, int tile
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
 
+  // stage-first software pipeline (see gemm_rowpass.hip): step k + 1 goes from registers to the other buffer before the MFMA
+  // block of step k, the registers are refilled with step k + 2 at once
   int cur = 0;
   if (wlo < whi) {
     load(wlo);
     stage(0);
+    if (wlo + TK < whi) load(wlo + TK);
   }
   __syncthreads();
   for (int k0 = wlo; k0 < whi; k0 += TK) {
-    const bool more = (k0 + TK) < whi;
-    if (more) load(k0 + TK);
+    if (k0 + TK < whi) stage(cur ^ 1);
+    if (k0 + 2 * TK < whi) load(k0 + 2 * TK);
 #pragma unroll
     for (int kk = 0; kk < TK / 4; ++kk) {
       const double* fpa = A_KMAJOR ? &lds.a[cur][(kk * 4 + lk) * KM_LD + wm * 32 + lr] : &lds.a[cur][(wm * 32 + lr) * RM_LD + kk * 4 + lk];
@@ -107,7 +110,6 @@ __global__ __launch_bounds__(NTH, 3) void gemm_small_kernel(GemmArgs g, int tile
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
     }
-    if (more) stage(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
