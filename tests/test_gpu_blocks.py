@@ -84,7 +84,7 @@ def test_jitchol_ladder_and_inverse_golden(E, path):
             assert rel(Ai[q] @ Aj, np.eye(L.shape[1])) < 1e-6
 
 
-@pytest.mark.parametrize("M", [1, 31, 32, 33, 50, 64, 200, 513, 1024])
+@pytest.mark.parametrize("M", [1, 31, 32, 33, 50, 64, 200, 256, 320, 513, 576, 1024])
 def test_potrf_potri_vs_lapack(E, M):
     rng = np.random.RandomState(M)
     Q = 2

@@ -294,11 +294,12 @@ def test_het_likelihood_samples_run_on_the_device():
 
 
 # ------------------------------------------------------------------------------------------------ specialised row-pass GEMMs
-@pytest.mark.parametrize("M,Ns,P", [(128, [777, 130, 1], 1), (256, [1030, 515], 2), (384, [2049, 17, 640], 1)])
+@pytest.mark.parametrize("M,Ns,P", [(128, [777, 130, 1], 1), (256, [1030, 515], 2), (320, [900, 333], 1), (384, [2049, 17, 640], 1)])
 def test_specialised_rowpass_kernels_vs_oracle(M, Ns, P):
     """gemm_rowpass.hip (8-wave forward / Gram kernels, taken when the inducing dimension is a multiple of 128) with ragged
     row counts (not multiples of 128 nor of 16, a 1-row task), full gradients and the E-step's triangular fold, against
-    the oracle; and several pools (row chunks) against one."""
+    the oracle; and several pools (row chunks) against one.  M >= 256 and a multiple of 64 also routes the replicated
+    M x M products through gemm_small.hip (M = 320: general row-pass kernels + 64 x 64-tile M x M products)."""
     from oracle import svmogp_oracle as so
     from hetmogp_amd import _lib
     specs = [("Gaussian", {"sigma": 0.5}), ("Poisson", {}), ("Bernoulli", {})][:len(Ns)]
