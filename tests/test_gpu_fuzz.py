@@ -1,0 +1,49 @@
+"""GPU: seeded random configurations against the oracle.  The shapes are drawn so that every dispatch branch of the
+contraction kernels is hit: inducing counts that are / are not multiples of 16, 64 and 128 (specialised 8-wave row-pass
+kernels, general kernel, 64 x 64-tile M x M products), odd and even tile counts (two-phase Gram tile order), one to
+three latents, 1-D and 2-D inputs, ragged / tiny / empty tasks, minibatch ranges, several row pools, both quirk modes."""
+import numpy as np
+import pytest
+
+from test_gpu_engine import KEYS, make_engine, rel, run, synth
+
+pytestmark = pytest.mark.gpu
+
+LIKS = [("Gaussian", {"sigma": 0.7}), ("Bernoulli", {}), ("Poisson", {}), ("Gamma", {}), ("Exponential", {}), ("HetGaussian", {}),
+        ("Beta", {}), ("Categorical", {"K": 3})]
+MS = [16, 48, 64, 100, 128, 192, 256, 272, 320, 384, 448, 512, 640]
+
+
+@pytest.mark.parametrize("seed", range(26))
+def test_random_configuration_vs_oracle(seed):
+    from oracle import svmogp_oracle as so
+    rng = np.random.RandomState(1000 + seed)
+    M = MS[seed % len(MS)]
+    P = 1 if rng.rand() < 0.7 else 2
+    Q = int(rng.randint(1, 4))
+    T = int(rng.randint(1, 4))
+    specs = [LIKS[i] for i in rng.choice(len(LIKS), T, replace=False)]
+    Ns = [int(rng.choice([0, 1, 17, 130, 257, 700, 1500], p=[0.05, 0.05, 0.1, 0.2, 0.2, 0.2, 0.2])) for _ in range(T)]
+    if sum(Ns) == 0:
+        Ns[0] = 129
+    cs = tuple(0.9 + 0.4 * rng.rand(Q))
+    prm, prob, X, Y = synth(2000 + seed, specs, Ns, M, Q, P, cs)
+    quirks = "exact" if seed % 3 == 0 else "reference"     # true gradients / the reference's (quirks Q1-Q5)
+    prob = dict(prob, quirks=quirks)
+    want = so.elbo_grad_fused(prm, prob, X, Y)
+    e = make_engine(prob, X, Y, chunk_rows=int(rng.choice([1 << 20, 600, 256])), quirks=quirks)
+    out = run(e, prm)
+    # 2-D grids of inducing points with jitter have cond(K_uu) up to ~1e6: parity there is conditioning-limited
+    tol = 1e-8 if P == 1 else 2e-7
+    for k in KEYS:
+        assert rel(out[k], want[k]) < tol, (k, M, P, Q, specs, Ns)
+    # a minibatch: a random contiguous range of every task with the reference's batch scale (svmogp.py:101-105)
+    rb = [int(rng.randint(0, n // 2 + 1)) for n in Ns]
+    re = [int(min(n, b + max(1, n // 3))) if n else 0 for n, b in zip(Ns, rb)]
+    bs = [float(n) / max(e_ - b, 1) for n, b, e_ in zip(Ns, rb, re)]
+    Xs, Ys = [x[b:e_] for x, b, e_ in zip(X, rb, re)], [y[b:e_] for y, b, e_ in zip(Y, rb, re)]
+    probs = dict(prob)
+    wantb = so.elbo_grad_fused(prm, probs, Xs, Ys, batch_scale=bs)
+    outb = run(e, prm, bs, row_begin=rb, row_end=re)
+    for k in KEYS:
+        assert rel(outb[k], wantb[k]) < tol, ("minibatch", k, M, P, Q, specs, Ns, rb, re)
