@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhetmogp_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 # likelihood ids (class names of the reference's likelihoods/<name>.py)
 LIK_GAUSSIAN, LIK_BERNOULLI, LIK_HETGAUSSIAN, LIK_CATEGORICAL, LIK_POISSON, LIK_EXPONENTIAL, LIK_GAMMA, LIK_BETA = range(8)
 LIK_IDS_BY_NAME = dict(Gaussian=0, Bernoulli=1, HetGaussian=2, Categorical=3, Poisson=4, Exponential=5, Gamma=6, Beta=7)
@@ -52,7 +52,7 @@ class Params(C.Structure):
 class Outputs(C.Structure):
     _fields_ = [("elbo", c_double_p), ("g_m_u", c_double_p), ("g_L_u", c_double_p), ("g_variance", c_double_p),
                 ("g_lengthscale", c_double_p), ("g_W", c_double_p), ("g_kappa", c_double_p), ("g_Z", c_double_p),
-                ("dL_dS", c_double_p), ("rung", c_int32_p), ("flags", c_uint32_p)]
+                ("dL_dS", c_double_p), ("rung", c_int32_p), ("flags", c_uint32_p), ("kl", c_double_p)]
 
 
 EXPORTS = {

@@ -892,7 +892,9 @@ struct hmogp_engine {
       double k[5] = {0, 0, 0, 0, 0};
       for (int b = 0; b < KL_BLOCKS; ++b)
         for (int i = 0; i < 5; ++i) k[i] += hkl[((size_t)q * KL_BLOCKS + b) * 5 + i];
-      KL += 0.5 * k[0] + 0.5 * k[1] - 0.5 * M + k[2] - k[3];  // svmogp_inf.py:245-249
+      const double klq = 0.5 * k[0] + 0.5 * k[1] - 0.5 * M + k[2] - k[3];  // svmogp_inf.py:245-249
+      KL += klq;
+      if (out->kl) out->kl[q] = klq;
       ninf += k[4];
     }
     if (out->elbo) out->elbo[0] = hg[0] - KL;

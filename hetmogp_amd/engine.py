@@ -165,7 +165,7 @@ class Engine(object):
         else:
             big = dict(g_m_u=np.zeros((M, Q)), g_L_u=np.zeros((self.Mtri, Q)), g_Z=np.zeros((M, Q * P)))
         o = dict(elbo=np.zeros(1), g_m_u=big["g_m_u"], g_L_u=big["g_L_u"], g_variance=np.zeros(Q),
-                 g_lengthscale=np.zeros(Q), g_W=np.zeros((Q, Df)), g_kappa=np.zeros((Q, Df)), g_Z=big["g_Z"])
+                 g_lengthscale=np.zeros(Q), g_W=np.zeros((Q, Df)), g_kappa=np.zeros((Q, Df)), g_Z=big["g_Z"], kl=np.zeros(Q))
         if want_dL_dS:
             o["dL_dS"] = np.zeros((Q, M, M))
         rung = np.zeros(Q, dtype=np.int32)
@@ -187,6 +187,7 @@ class Engine(object):
     def _wrap(self, o):
         res = dict(o)
         res["elbo"] = float(o["elbo"][0])
+        res["KL"] = float(np.sum(o["kl"]))          # calculate_KL (svmogp_inf.py:227-250), summed over the latents
         res["rungs"] = [int(r) for r in o["rung"]]
         res["v_negative"] = bool(int(o["flags"][0]) & _lib.FLAG_V_NEGATIVE)
         self.last = res
@@ -194,8 +195,8 @@ class Engine(object):
 
     # ------------------------------------------------------------------------------------------ hot path
     def elbo_grad(self, want_dL_dS=False, **params):
-        """One ``parameters_changed()``: returns dict(elbo, g_m_u, g_L_u, g_variance, g_lengthscale, g_W, g_kappa,
-        g_Z, rungs, v_negative[, dL_dS])."""
+        """One ``parameters_changed()``: returns dict(elbo, KL, kl [Q], g_m_u, g_L_u, g_variance, g_lengthscale, g_W,
+        g_kappa, g_Z, rungs, v_negative[, dL_dS])."""
         p, keep = self._params(**params)
         c, o = self._outputs(want_dL_dS, skip_qu=params.get("m_u") is None)
         check(lib.hmogp_elbo_grad(self._h, C.byref(p), C.byref(c)), self._h)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMOGP_ABI_VERSION 2
+#define HMOGP_ABI_VERSION 3
 
 /* likelihood ids (class names of /root/reference/likelihoods/<name>.py) */
 enum {
@@ -150,6 +150,8 @@ typedef struct {
   double* dL_dS;         /* [Q, M, M] or NULL: dL/dS_q (svmogp_inf.py:169), for natural gradients     */
   int32_t* rung;         /* [Q] jitter rung taken per latent (-1 = none)                              */
   uint32_t* flags;       /* [1] HMOGP_FLAG_*                                                          */
+  double* kl;            /* [Q] or NULL: KL(q(u_q) || p(u_q)) per latent (calculate_KL, svmogp_inf.py:227-250);
+                            elbo = (scaled data term) - sum_q kl[q]                      (ABI version 3) */
 } hmogp_outputs;
 
 /* ---- life cycle ------------------------------------------------------------------------------------ */

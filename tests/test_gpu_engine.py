@@ -65,6 +65,7 @@ def test_engine_vs_reference_inference(path):
     e = make_engine(prob, X, Y)
     out = run(e, prm, bs)
     assert rel(out["elbo"], g["elbo"]) < TOL
+    assert rel(out["KL"], g["KL"]) < TOL          # calculate_KL on its own (svmogp_inf.py:227-250), not only through the ELBO
     Q, Df = prob["Q"], prob["Df"]
     assert rel(out["g_m_u"], np.hstack([g["dL_dmu_u_%d" % q] for q in range(Q)])) < TOL
     assert rel(out["g_L_u"], np.hstack([g["dL_dL_u_%d" % q] for q in range(Q)])) < TOL
