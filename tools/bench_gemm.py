@@ -16,13 +16,14 @@ def run(role, n, M, iters=10):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) >= 4:                       # single shape: role n M [iters]
-        role, n, M = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-        ms, tf = run(role, n, M, int(sys.argv[4]) if len(sys.argv) > 4 else 10)
-        if role == 5:        # K_uf construction: 3 latents x 8 n M bytes written per launch
-            print("role=5 n=%d M=%d : %.3f ms %.0f GB/s written" % (n, M, ms, 3 * 8.0 * n * M / ms / 1e6))
-        else:
-            print("role=%d n=%d M=%d : %.3f ms %.1f TFLOP/s" % (role, n, M, ms, tf))
+    if len(sys.argv) >= 4:                       # single shape: role[,role...] n M [iters]
+        n, M = int(sys.argv[2]), int(sys.argv[3])
+        for role in [int(r) for r in sys.argv[1].split(",")]:      # one role or a comma-separated list (one process)
+            ms, tf = run(role, n, M, int(sys.argv[4]) if len(sys.argv) > 4 else 10)
+            if role == 5:        # K_uf construction: 3 latents x 8 n M bytes written per launch
+                print("role=5 n=%d M=%d : %.3f ms %.0f GB/s written" % (n, M, ms, 3 * 8.0 * n * M / ms / 1e6))
+            else:
+                print("role=%d n=%d M=%d : %.3f ms %.1f TFLOP/s" % (role, n, M, ms, tf))
         sys.exit(0)
     for role, name in ((1, "forward P~=K^C      (2nM^2)"), (3, "forward + fused stats   "), (4, "fwd + stats, no P~ store"),
                        (2, "gram H+=K^T b K^ (nM^2) ")):

@@ -12,5 +12,5 @@ mkdir -p $OUT
   echo "# stage-first bare loops: tools/probes/build/probe_gemm16"
   ./tools/probes/build/probe_gemm16
 } > $OUT/alone.txt 2>&1
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o alone --output-format csv -- bash -c 'for r in 3 2 6 5; do python tools/bench_gemm.py $r 800000 1024; done' > $OUT/rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o alone --output-format csv -- python tools/bench_gemm.py 3,2,6,5 800000 1024 > $OUT/rocprof.log 2>&1
 cat $OUT/alone.txt
