@@ -38,46 +38,97 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {  // wave-un
 
 constexpr int LSP = 144;  // k-major leading dimension of the parked panel rows (same bank argument as gemm_f64.hip)
 
-// Factorisation of the 32 x 32 diagonal block by ONE wave, entirely in registers: lane r owns row r (lanes 32..63
-// mirror 0..31).  Column c needs the pivot from lane c and, for the rank-1 update, the scaled column entries L[c2][c]
-// from lanes c2 -- both by v_readlane broadcasts (compile-time lane numbers), no LDS round trips inside the recurrence.
-// Entries above the diagonal carry garbage that nothing reads.  Returns LAPACK's info (0, or 1 + the failing column).
-__device__ __forceinline__ int factor_diag_wave(double (*D)[NBP + 1], double* Dinv, int jb, int lane) {
-  const int r = lane & (NB - 1);
-  double a[NB];
+// Value of half `HC` of the wave (lanes 32 HC .. 32 HC + 31) in BOTH halves: v_permlane32_swap_b32 of a register with itself
+// returns {lower half in both halves, upper half in both halves}.
+template <int HC>
+__device__ __forceinline__ double bcast_half(double v) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[HC], (int)a[HC]);
+}
+
+// One column of the in-wave factorisation (C is a compile-time constant: every register index and lane number below is).
+template <int C>
+__device__ __forceinline__ void factor_diag_column(double (&a)[NB / 2], double* Dinv, double (*Lv)[NB], int jb, int lane, int r,
+                                                   int h, int& bad) {
+  constexpr int HC = C & 1, KC = C >> 1;
+  const double d = readlane_f64(a[KC], C + 32 * HC);
+  if (C < jb && !bad && !(d > 0.0)) bad = C + 1;  // LAPACK: ajj <= 0 or NaN (uniform across lanes)
+  // pivot sqrt(d) and its reciprocal from v_rsq_f64 + Newton steps (a dependent chain of ~12 FMAs instead of an IEEE sqrt
+  // followed by an IEEE division; both end within an ulp or two of the correctly rounded values)
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * fma(-0.5 * d * y, y, 1.5);
+  y = y * fma(-0.5 * d * y, y, 1.5);
+  double piv = d * y;
+  piv = fma(0.5 * y, fma(-piv, piv, d), piv);
+  const double rinv = fma(y, fma(-piv, y, 1.0), y);
+  if (lane == C) Dinv[C] = rinv;
+  const double lown = (r == C) ? piv : a[KC] * rinv;  // column C of L, meaningful in the half that owns the column
+  if (h == HC) a[KC] = lown;
+  if (C + 1 < NB) {
+    const double l = bcast_half<HC>(lown);            // l[r] = L[r][C] in both halves
+    // the next pivot column first, straight from registers (it is the critical path) ...
+    constexpr int HN = (C + 1) & 1, KN = (C + 1) >> 1;
+    const double sn = readlane_f64(l, C + 1);
+    a[KN] = fma(-((h == HN) ? l : 0.0), sn, a[KN]);
+    // ... the other columns with the l vector broadcast through LDS: lane (r, h) needs l[2k + h] for its columns
+    Lv[C & 1][r] = l;
 #pragma unroll
-  for (int c = 0; c < NB; ++c) a[c] = D[r][c];
-  int bad = 0;
-#pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    const double d = readlane_f64(a[c], c);
-    if (c < jb && !bad && !(d > 0.0)) bad = c + 1;  // LAPACK: ajj <= 0 or NaN (uniform across lanes)
-    // pivot sqrt(d) and its reciprocal from v_rsq_f64 + Newton steps (a dependent chain of ~12 FMAs instead of an
-    // IEEE sqrt followed by an IEEE division; both end within an ulp or two of the correctly rounded values)
-    double y = __builtin_amdgcn_rsq(d);
-    y = y * fma(-0.5 * d * y, y, 1.5);
-    y = y * fma(-0.5 * d * y, y, 1.5);
-    double piv = d * y;
-    piv = fma(0.5 * y, fma(-piv, piv, d), piv);
-    const double rinv = fma(y, fma(-piv, y, 1.0), y);
-    if (lane == c) Dinv[c] = rinv;
-    const double l = (r == c) ? piv : a[c] * rinv;
-    a[c] = l;
-#pragma unroll
-    for (int c2 = c + 1; c2 < NB; ++c2) a[c2] = fma(-l, readlane_f64(l, c2), a[c2]);
+    for (int k = KC + 1; k < NB / 2; ++k) {
+      const double sk = Lv[C & 1][2 * k + h];
+      // C odd: column 2 (KC + 1) of half 0 is the next pivot column, already updated above
+      const double lk = (HC == 1 && k == KC + 1) ? ((h == 1) ? l : 0.0) : l;
+      a[k] = fma(-lk, sk, a[k]);
+    }
   }
-  if (lane < NB)
+}
+
+template <int C>
+__device__ __forceinline__ void factor_diag_columns(double (&a)[NB / 2], double* Dinv, double (*Lv)[NB], int jb, int lane, int r,
+                                                    int h, int& bad) {
+  if constexpr (C < NB) {
+    factor_diag_column<C>(a, Dinv, Lv, jb, lane, r, h, bad);
+    factor_diag_columns<C + 1>(a, Dinv, Lv, jb, lane, r, h, bad);
+  }
+}
+
+// Factorisation of the 32 x 32 diagonal block by ONE wave, in registers: lane (r, h) = r + 32 h owns the 16 columns 2k + h
+// of row r, so both halves of the wave carry half of every rank-1 update.  Column c needs the pivot from the lane that
+// owns (c, c) (v_readlane, compile-time lane); the scaled column l = L[:, c] is mirrored into the other half with
+// v_permlane32_swap; the NEXT pivot column is updated at once from a v_readlane broadcast (the recurrence's critical path),
+// all other columns from the l vector parked in LDS (per-lane addresses 2k + h: a uniform SGPR broadcast cannot serve two
+// halves that need different entries).  Every element sees the same operations in the same order as the plain
+// right-looking recurrence: a[c2] = fma(-L[r][c], L[c2][c], a[c2]) for c = 0, 1, ...  (3.4x fewer instructions than one
+// row per lane with 31 - c broadcasts per column.)  Entries above the diagonal carry garbage that nothing reads.
+// Returns LAPACK's info (0, or 1 + the failing column).
+__device__ __forceinline__ int factor_diag_wave(double (*D)[NBP + 1], double* Dinv, double (*Lv)[NB], int jb, int lane) {
+  static_assert(NB == 32, "one row per lane of a half wave");
+  const int r = lane & (NB - 1), h = lane >> 5;
+  double a[NB / 2];
 #pragma unroll
-    for (int c = 0; c < NB; ++c) D[r][c] = a[c];
+  for (int k = 0; k < NB / 2; ++k) a[k] = D[r][2 * k + h];
+  int bad = 0;
+  factor_diag_columns<0>(a, Dinv, Lv, jb, lane, r, h, bad);
+#pragma unroll
+  for (int k = 0; k < NB / 2; ++k) D[r][2 * k + h] = a[k];
   return bad;
 }
 
+// Where the reciprocal pivot c of the diagonal block at column j is parked in the out-of-place factor between the launch that
+// factorises the block ahead of time and the launch that consumes it: strictly above the diagonal of that block (nothing
+// else ever touches the upper triangle of `Lo`): (c, c + 1) for c <= 30, (0, 2) for c = 31.
+__device__ __forceinline__ long long dinv_slot(int j, int c, int M) {
+  return (c < NB - 1) ? (long long)(j + c) * M + (j + c + 1) : (long long)j * M + (j + 2);
+}
+
 __global__ __launch_bounds__(320) void potrf_step_kernel(double* __restrict__ Wall, double* __restrict__ Lall, int M, int j,
-                                                         int* __restrict__ info, long long* stamps) {
+                                                         int* __restrict__ info, long long* stamps, int pre) {
   STAMP(0);
   __shared__ __attribute__((aligned(16))) double D[NB][NBP + 1];  // even leading dimension: 16-byte column pairs
   __shared__ __attribute__((aligned(16))) double Ls[2][NB][LSP];
   __shared__ double Dinv[NB];  // reciprocals of the pivots
+  __shared__ __attribute__((aligned(16))) double Lv[2][NB];  // factor wave: the current column of L, for both half waves
   __shared__ int fail;
   const int q = blockIdx.y;
   if (info[q] != 0) return;
@@ -85,8 +136,12 @@ __global__ __launch_bounds__(320) void potrf_step_kernel(double* __restrict__ Wa
   double* Lo = Lall + (long long)q * M * M;
   const int jb = min(NB, M - j), base = j + jb, rem = M - base;
   const int t = threadIdx.x;
+  // The LAST block of a launch with rows below the panel is the look-ahead block: it repeats the panel solve of tile 0 and
+  // then only factorises the next diagonal block (below) -- on a CU of its own, because FP64 vector work shares the pipe
+  // with the FP64 MFMAs of a tile update (inside block 0 the same factorisation took twice as long).
+  const bool ahead_blk = rem > 0 && blockIdx.x == gridDim.x - 1;
   int ti = 0, tj = 0;
-  {
+  if (!ahead_blk) {
     const int v = blockIdx.x;
     ti = (int)((sqrt(8.0 * (double)v + 1.0) - 1.0) * 0.5);
     while ((ti + 1) * (ti + 2) / 2 <= v) ++ti;
@@ -94,9 +149,14 @@ __global__ __launch_bounds__(320) void potrf_step_kernel(double* __restrict__ Wa
     tj = v - ti * (ti + 1) / 2;
   }
   if (t == 0) fail = 0;
-  for (int e = t; e < NB * NB; e += blockDim.x) {
-    const int r = e / NB, c = e % NB;
-    D[r][c] = (r < jb && c <= r) ? W[(long long)(j + r) * M + (j + c)] : 0.0;
+  // pre != 0: the previous launch already factorised this diagonal block (look-ahead, below) into its final place in Lo
+  {
+    const double* src = pre ? Lo : W;
+    for (int e = t; e < NB * NB; e += blockDim.x) {
+      const int r = e / NB, c = e % NB;
+      D[r][c] = (r < jb && c <= r) ? src[(long long)(j + r) * M + (j + c)] : 0.0;
+    }
+    if (pre && rem > 0 && t < NB) Dinv[t] = Lo[dinv_slot(j, t, M)];
   }
   __syncthreads();
   STAMP(1);
@@ -106,8 +166,10 @@ __global__ __launch_bounds__(320) void potrf_step_kernel(double* __restrict__ Wa
   const bool pvalid = t < 256 && rem > 0 && prow < M;  // (a ragged last panel, jb < NB, has no rows below it: rem == 0)
   double x[NB];
   if (t >= 256) {
-    const int bad = factor_diag_wave(D, Dinv, jb, t & 63);
-    if (t == 256) fail = bad;
+    if (!pre) {
+      const int bad = factor_diag_wave(D, Dinv, Lv, jb, t & 63);
+      if (t == 256) fail = bad;
+    }
   } else {
     // Panel rows of the two row tiles (threads 0..127 -> tile ti, 128..255 -> tile tj): in flight while wave 4 factorises.
     if (pvalid) {
@@ -133,7 +195,7 @@ __global__ __launch_bounds__(320) void potrf_step_kernel(double* __restrict__ Wa
     if (blockIdx.x == 0 && t == 0) info[q] = j + fail;
     return;
   }
-  if (blockIdx.x == 0)
+  if (blockIdx.x == 0 && !pre)
     for (int e = t; e < jb * NB; e += blockDim.x) {
       const int r = e / NB, c = e % NB;
       if (c <= r) Lo[(long long)(j + r) * M + (j + c)] = D[r][c];
@@ -147,7 +209,7 @@ __global__ __launch_bounds__(320) void potrf_step_kernel(double* __restrict__ Wa
 #pragma unroll
       for (int k = c + 1; k < NB; ++k) x[k] = fma(-x[c], D[k][c], x[k]);
     }
-    if (pvalid && half == 0 && tj == 0) {
+    if (pvalid && half == 0 && tj == 0 && !ahead_blk) {
       double* lo = Lo + (long long)prow * M + j;
 #pragma unroll
       for (int c = 0; c < NB; ++c) lo[c] = x[c];
@@ -159,7 +221,7 @@ __global__ __launch_bounds__(320) void potrf_step_kernel(double* __restrict__ Wa
   // This block's tile of the trailing matrix goes straight into the MFMA accumulators (D fragment: col = lane & 15,
   // row = (lane >> 4) + 4 * reg); the loads are in flight across the barrier.
   const int lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1, lr = lane & 15, lk = lane >> 4;
-  const bool idle = t >= 256 || (ti == tj && wm == 0 && wn == 1);  // factor wave; strictly-upper quadrant of a diagonal tile
+  const bool idle = t >= 256 || ahead_blk || (ti == tj && wm == 0 && wn == 1);  // factor wave; look-ahead block; strictly-upper quadrant of a diagonal tile
   f64x4 acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -172,8 +234,70 @@ __global__ __launch_bounds__(320) void potrf_step_kernel(double* __restrict__ Wa
         acc[a][b][r] = (!idle && row < M && col <= row) ? W[(long long)row * M + col] : 0.0;
       }
     }
+  // Look-ahead (the factor wave of the look-ahead block): the NEXT diagonal block = W[base.., base..] - X X^T with X the
+  // first 32 solved rows, formed with the same MFMA sequence on the same operands as the main update of tile (0, 0)
+  // (bit-identical values), factorised while the regular blocks update the trailing matrix, and written to its final
+  // place in Lo: the next launch starts its panel solve at once instead of waiting for a factor wave of its own.
+  const bool ahead = ahead_blk && t >= 256;
+  const int jbn = min(NB, rem);
+  f64x4 la[2][2];
+  if (ahead) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = a * 16 + 4 * r + lk;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int col = b * 16 + lr;
+          la[a][b][r] = (row < jbn && col <= row) ? W[(long long)(base + row) * M + (base + col)] : 0.0;
+        }
+      }
+  }
   __syncthreads();
   STAMP(3);
+  if (ahead) {
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) {
+      double fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = -Ls[0][kk * 4 + lk][i * 16 + lr];
+        fb[i] = Ls[1][kk * 4 + lk][i * 16 + lr];
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) la[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], la[a][b], 0, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = a * 16 + 4 * r + lk;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int col = b * 16 + lr;
+          D[row][col] = (row < jbn && col <= row) ? la[a][b][r] : 0.0;
+        }
+      }
+    // (one wave: its LDS accesses are processed in order, no barrier between the stores above and the loads below)
+    const int bad = factor_diag_wave(D, Dinv, Lv, jbn, lane);
+    if (bad) {
+      if (lane == 0) info[q] = base + bad;
+    } else {
+#pragma unroll
+      for (int k = 0; k < NB / 2; ++k) {
+        const int r = lane & (NB - 1), c = 2 * k + (lane >> 5);
+        if (r < jbn && c <= r) Lo[(long long)(base + r) * M + (base + c)] = D[r][c];
+      }
+      if (lane < NB && base + NB < M) Lo[dinv_slot(base, lane, M)] = Dinv[lane];   // (only a block with rows below it needs them)
+    }
+#ifdef POTRF_STAMPS
+    if (stamps && blockIdx.y == 0 && t == 256) stamps[6] = clock64();
+#endif
+    return;
+  }
   if (idle) return;
 #pragma unroll
   for (int kk = 0; kk < NB / 4; ++kk) {
@@ -194,7 +318,9 @@ __global__ __launch_bounds__(320) void potrf_step_kernel(double* __restrict__ Wa
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = base + ti * 128 + wm * 64 + a * 16 + 4 * r + lk;
-      if (row >= M) continue;
+      // (the next diagonal block, rows base .. base + 31 of tile (0, 0), is NOT written back: the look-ahead block of this
+      // launch reads its un-updated values from W, and nothing reads it from W again -- the next launch takes it from Lo)
+      if (row >= M || row < base + NB) continue;
       double* wrow = W + (long long)row * M;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
@@ -300,7 +426,7 @@ void launch_potrf_batched(double* A, int Q, int M, int* d_info, double* scr, hip
     const int j = pnl * NB;
     const int rem = M - j - std::min(NB, M - j);
     const int T = (rem + 127) / 128;
-    hipLaunchKernelGGL(potrf_step_kernel, dim3(std::max(1, T * (T + 1) / 2), Q), dim3(320), 0, stream, A, scr, M, j, d_info, j == 0 ? g_potrf_stamps : nullptr);
+    hipLaunchKernelGGL(potrf_step_kernel, dim3(std::max(1, T * (T + 1) / 2) + (rem > 0 ? 1 : 0), Q), dim3(320), 0, stream, A, scr, M, j, d_info, j == 0 ? g_potrf_stamps : nullptr, pnl > 0 ? 1 : 0);
   }
   if (panel_end == npanels) hipLaunchKernelGGL(potrf_finalize_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, stream, A, M, scr);
 }
