@@ -211,7 +211,7 @@ struct hmogp_engine {
   bool began = false, evaluated = false;
   // device-resident q(u) for the SVI loop (hmogp_qu_*): dmu / dLflat ARE the parameters; Adadelta state beside them
   bool qu_resident = false;
-  DevBuf ad_gms_m, ad_sms_m, ad_step_m, ad_gms_L, ad_sms_L, ad_step_L;
+  DevBuf ad_gms_m, ad_sms_m, ad_step_m, ad_pend_m, ad_gms_L, ad_sms_L, ad_step_L, ad_pend_L;
 
   // timing
   struct Span {
@@ -962,11 +962,11 @@ struct hmogp_engine {
     const size_t nm = sizeof(double) * M * Q, nl = sizeof(double) * ((long long)M * (M + 1) / 2) * Q;
     HIP_TRY(hipMemcpyAsync(dmu.p, m_u, nm, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dLflat.p, L_flat, nl, hipMemcpyHostToDevice, st));
-    for (DevBuf* b : {&ad_gms_m, &ad_sms_m, &ad_step_m}) {
+    for (DevBuf* b : {&ad_gms_m, &ad_sms_m, &ad_step_m, &ad_pend_m}) {
       b->ensure(nm);
       HIP_TRY(hipMemsetAsync(b->p, 0, nm, st));
     }
-    for (DevBuf* b : {&ad_gms_L, &ad_sms_L, &ad_step_L}) {
+    for (DevBuf* b : {&ad_gms_L, &ad_sms_L, &ad_step_L, &ad_pend_L}) {
       b->ensure(nl);
       HIP_TRY(hipMemsetAsync(b->p, 0, nl, st));
     }
@@ -988,8 +988,8 @@ struct hmogp_engine {
     HIP_TRY(hipSetDevice(device));
     const long long nm = (long long)M * Q, nl = ((long long)M * (M + 1) / 2) * Q;
     const bool has = phase == 1 && (group_mask & HMOGP_GROUP_QU) != 0;
-    launch_adadelta(dmu.d(), ad_gms_m.d(), ad_sms_m.d(), ad_step_m.d(), has ? gmu.d() : nullptr, -1.0, nm, phase, rate, m, d, omd, o, st);
-    launch_adadelta(dLflat.d(), ad_gms_L.d(), ad_sms_L.d(), ad_step_L.d(), has ? gL.d() : nullptr, -1.0, nl, phase, rate, m, d, omd, o, st);
+    launch_adadelta(dmu.d(), ad_gms_m.d(), ad_sms_m.d(), ad_step_m.d(), ad_pend_m.d(), has ? gmu.d() : nullptr, -1.0, nm, phase, rate, m, d, omd, o, st);
+    launch_adadelta(dLflat.d(), ad_gms_L.d(), ad_sms_L.d(), ad_step_L.d(), ad_pend_L.d(), has ? gL.d() : nullptr, -1.0, nl, phase, rate, m, d, omd, o, st);
     HIP_TRY(hipStreamSynchronize(st));
   }
 

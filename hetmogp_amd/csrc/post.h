@@ -28,8 +28,8 @@ void launch_pack_tril(const double* T, double* out, int Q, int M, double scale, 
 void launch_scatter_mq(const double* v, double* out, int Q, int M, hipStream_t s);
 // device-resident Adadelta (climin recurrence, util.py:327) on one parameter block; phase 0 = momentum move before the
 // gradient, phase 1 = update from grad (nullptr = zero gradient); omd = 1 - d as the host computes it
-void launch_adadelta(double* x, double* gms, double* sms, double* step, const double* grad, double sign, long long n, int phase,
-                     double rate, double m, double d, double omd, double o, hipStream_t s);
+void launch_adadelta(double* x, double* gms, double* sms, double* step, double* pend, const double* grad, double sign, long long n,
+                     int phase, double rate, double m, double d, double omd, double o, hipStream_t s);
 // the small results of one evaluation gathered into one contiguous block (one D2H copy instead of 3 + Q)
 void launch_gather_small(const double* stats, long long n_hg, const double* kl, long long n_kl, long long per_q, long long oDZ,
                          long long n_tail, int Q, const double* rowout, long long n_row, double* dst, hipStream_t s);

@@ -251,22 +251,27 @@ void launch_qf_combine(const double* p, const double* c, long long ldn, long lon
 }
 
 // ---- device-resident Adadelta for q(u) (SVI loop; the recurrence of climin.Adadelta as the reference calls it, util.py:327)
-// phase 0 (before the gradient):  step1 = m * step;  x -= step1
-// phase 1 (after it):             gms = d gms + (1-d) g^2;  step2 = sqrt(sms+o)/sqrt(gms+o) * g * rate;  x -= step2;
+// phase 0 (before the gradient):  x -= pend (the second half-step of the previous iteration);  step1 = m * step;  x -= step1
+// phase 1 (after it):             gms = d gms + (1-d) g^2;  step2 = sqrt(sms+o)/sqrt(gms+o) * g * rate;  pend = step2;
 //                                 step = step1 + step2;  sms = d sms + (1-d) step^2        with g = sign * grad (or 0)
+// i.e. x -= step2 is deferred to the start of the next iteration (same operations in the same order on every element), so
+// that between iterations x is the point of the last evaluation -- what the reference's model object holds at that moment
+// (climin updates its own `wrt`; the model is only written by stochastic_grad, svmogp.py:188).
 // Every operation is a separately rounded IEEE operation in the order of hetmogp_amd/util.py:Adadelta (no FMA contraction),
 // so the iterates are bit-identical to the host optimiser's.
 namespace {
 __global__ void adadelta_kernel(double* __restrict__ x, double* __restrict__ gms, double* __restrict__ sms,
-                                double* __restrict__ step, const double* __restrict__ grad, double sign, long long n, int phase,
-                                double rate, double m, double d, double omd, double o) {
+                                double* __restrict__ step, double* __restrict__ pend, const double* __restrict__ grad, double sign,
+                                long long n, int phase, double rate, double m, double d, double omd, double o) {
 #pragma clang fp contract(off)
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
     const double step1 = step[i] * m;
     if (phase == 0) {
-      x[i] = x[i] - step1;
+      const double xv = x[i] - pend[i];
+      x[i] = xv - step1;
+      pend[i] = 0.0;
       continue;
     }
     const double g = grad ? sign * grad[i] : 0.0;
@@ -280,7 +285,7 @@ __global__ void adadelta_kernel(double* __restrict__ x, double* __restrict__ gms
     a = a / b;
     a = a * g;
     a = a * rate;
-    x[i] = x[i] - a;
+    pend[i] = a;
     const double st = step1 + a;
     step[i] = st;
     double t2 = st * st;
@@ -325,10 +330,10 @@ void launch_gather_small(const double* stats, long long n_hg, const double* kl, 
                      n_tail, Q, rowout, n_row, dst);
 }
 
-void launch_adadelta(double* x, double* gms, double* sms, double* step, const double* grad, double sign, long long n, int phase,
-                     double rate, double m, double d, double omd, double o, hipStream_t s) {
+void launch_adadelta(double* x, double* gms, double* sms, double* step, double* pend, const double* grad, double sign, long long n,
+                     int phase, double rate, double m, double d, double omd, double o, hipStream_t s) {
   if (n <= 0) return;
   const unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 4096);
-  hipLaunchKernelGGL(adadelta_kernel, dim3(blocks), dim3(256), 0, s, x, gms, sms, step, grad, sign, n, phase, rate, m, d, omd, o);
+  hipLaunchKernelGGL(adadelta_kernel, dim3(blocks), dim3(256), 0, s, x, gms, sms, step, pend, grad, sign, n, phase, rate, m, d, omd, o);
 }
 

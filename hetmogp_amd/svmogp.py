@@ -100,8 +100,10 @@ class DeviceAdadelta(object):
                 pass
 
     def finish(self):
-        """Bring q(u) back into the model's parameter arrays (no re-evaluation: the device state is what the last
-        evaluation... preceded; the model is marked dirty so the next read of a derived quantity re-evaluates)."""
+        """Bring q(u) back into the model's parameter arrays.  Like every other parameter it is left at the point of the
+        LAST EVALUATION, which is what the reference's model object holds when its Adadelta loop ends (climin applies
+        the second half-step to its own `wrt` only; the model is written by stochastic_grad, svmogp.py:188): the engine
+        keeps that half-step pending (`hmogp_qu_adadelta`).  No re-evaluation here; the model is marked dirty."""
         m = self.model
         if getattr(m, "_qu_on_device", False):
             mu, L = m._engine.qu_read()

@@ -213,11 +213,14 @@ int hmogp_natgrad_step(hmogp_handle h, double gamma, double* m_u_new, double* L_
  * operations in the same order as the host one, so the iterates are bit-identical.
  *   hmogp_qu_load      upload q(u) (zeroes the accumulators); evaluations with params.m_u = params.L_flat = NULL use it,
  *                      outputs.g_m_u / g_L_u may then be NULL (nothing is copied back)
- *   hmogp_qu_adadelta  phase 0: step1 = momentum * step; q(u) -= step1                 (before the gradient evaluation)
- *                      phase 1: gms = d gms + (1-d) g^2; step2 = sqrt(sms+o)/sqrt(gms+o) g rate; q(u) -= step2;
+ *   hmogp_qu_adadelta  phase 0: q(u) -= step2 of the previous iteration; step1 = momentum * step; q(u) -= step1
+ *                               (before the gradient evaluation)
+ *                      phase 1: gms = d gms + (1-d) g^2; step2 = sqrt(sms+o)/sqrt(gms+o) g rate (kept pending);
  *                               step = step1 + step2; sms = d sms + (1-d) step^2       with g = -dELBO/dq(u) of the last
  *                               evaluation, or 0 if its group_mask excluded HMOGP_GROUP_QU (the M-steps of svmogp.py:196)
- *   hmogp_qu_read      download the current q(u)                                                                  */
+ *   hmogp_qu_read      download q(u) as of the LAST EVALUATION (the second half-step of the last update still pending):
+ *                      what the reference's model object holds between iterations -- climin updates its own vector, the
+ *                      model is only written by stochastic_grad (svmogp.py:188)                                       */
 int hmogp_qu_load(hmogp_handle h, const double* m_u, const double* L_flat);
 int hmogp_qu_read(hmogp_handle h, double* m_u, double* L_flat);
 int hmogp_qu_adadelta(hmogp_handle h, int32_t phase, double step_rate, double momentum, double decay,

@@ -240,10 +240,14 @@ def test_fixed_groups_are_skipped_in_batch_mode():
     assert any(float(k.variance.gradient[0]) != 0.0 for k in model.kern_list)
 
 
-def test_device_adadelta_iterates_are_bit_identical_to_host_adadelta():
-    """f1: 50 SVI iterations (4 E-steps / 1 M-step gating, contiguous minibatches) from the state of the reference's
+@pytest.mark.parametrize("n_iter", [50, 48])
+def test_device_adadelta_iterates_are_bit_identical_to_host_adadelta(n_iter):
+    """f1: SVI iterations (4 E-steps / 1 M-step gating, contiguous minibatches) from the state of the reference's
     model_config2_svi fixture: util.Adadelta on the host (climin's recurrence on model.optimizer_array) and
-    DeviceAdadelta (q(u) + accumulators resident in HBM) must produce bit-identical parameters and ELBO traces."""
+    DeviceAdadelta (q(u) + accumulators resident in HBM) must produce bit-identical ELBO traces and leave bit-identical
+    parameters in the model -- the point of the last evaluation, as in the reference (the second half-step of the last
+    update only exists in the optimiser's own vector).  50 iterations end on an M-step (q(u) did not move in it), 48 on
+    an E-step (q(u) moved, the other parameters did not)."""
     import hetmogp_amd as H
     from hetmogp_amd.util import Adadelta
     g = np.load(os.path.join(GOLDEN, "model_config2_svi_E.npz"))
@@ -262,7 +266,7 @@ def test_device_adadelta_iterates_are_bit_identical_to_host_adadelta():
 
         def stop(info):
             elbo.append(float(model._log_marginal_likelihood[0, 0]))
-            return info["n_iter"] >= 50
+            return info["n_iter"] >= n_iter
         opt.minimize_until(stop)
         traces.append(elbo)
         finals.append([model.q_u_means.values.copy(), model.q_u_chols.values.copy(), model.Z.values.copy()] +
