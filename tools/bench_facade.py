@@ -21,6 +21,7 @@ prm, X, Y = make_case(specs, [N] * 4, M=M, Q=Q, P=P, seed=3)
 liks = [H.Gaussian(sigma=0.5), H.Bernoulli(), H.Poisson(), H.Gamma()]
 lik = H.HetLikelihood(liks)
 meta = lik.generate_metadata()
+np.random.seed(1)                   # the constructor draws W and the first batch (as the reference does): same model in both modes
 kern = [RBF(P, variance=float(prm["variance"][q]), lengthscale=float(prm["lengthscale"][q])) for q in range(Q)]
 model = H.SVMOGP(X=X, Y=[y[:, None] for y in Y], Z=prm["Z"][:, :P].copy(), kern_list=kern, likelihood=lik, Y_metadata=meta,
                  batch_size=B)
