@@ -516,6 +516,9 @@ struct hmogp_engine {
     // are the one place where it is free.
     HIP_TRY(hipStreamWaitEvent(st2, ev_params, 0));
     if (!pools.empty()) {
+      // (with it, off the critical path of the main stream: the zeroed statistic bundle and the pool-contiguous inputs)
+      HIP_TRY(hipMemsetAsync(stats.p, 0, sizeof(double) * nstats, st2));
+      stage_pool_inputs(pools[0], st2);
       kuf_pool(pools[0], st2);
       HIP_TRY(hipEventRecord(ev_kuf, st2));
       kuf_prefetched = true;
@@ -625,6 +628,14 @@ struct hmogp_engine {
     }
   }
 
+  // inputs of a multi-segment pool, contiguous in pool order (fs_x of the forward epilogue, the column statistics)
+  void stage_pool_inputs(const std::vector<Seg>& pl, hipStream_t stream) {
+    if (pl.size() <= 1) return;
+    for (auto& sg : pl)
+      HIP_TRY(hipMemcpyAsync(Xws.d() + sg.off * P, tasks[sg.t].X.d() + sg.r0 * P, sizeof(double) * sg.n * P,
+                             hipMemcpyDeviceToDevice, stream));
+  }
+
   // ------------------------------------------------------------------------------------------ row pass
   void row_pass() {
     const long long MM = (long long)M * M;
@@ -633,7 +644,7 @@ struct hmogp_engine {
     const bool want_z = (group_mask & HMOGP_GROUP_Z) != 0;
     // (pools: see plan_pools())
     const long long ldn = ws_rows;
-    HIP_TRY(hipMemsetAsync(stats.p, 0, sizeof(double) * nstats, st));
+    if (!kuf_prefetched) HIP_TRY(hipMemsetAsync(stats.p, 0, sizeof(double) * nstats, st));   // (else: with the prefetch)
     const int tiles = (M + 127) / 128;
     const long long wtiles = (ws_rows + 127) / 128;
     const long long sK = ldn * M;                           // per-latent stride of the K^ / P~ workspaces
@@ -643,13 +654,11 @@ struct hmogp_engine {
       int* rw = use_windows ? winrow.as<int>() : nullptr;    // [Q][wtiles][2]
       int* cw = use_windows ? wincol.as<int>() : nullptr;    // [Q][ncb][2]
       const double* X = tasks[pl[0].t].X.d() + pl[0].r0 * P; // inputs of the pool's rows
+      const bool prefetched = &pl == &pools[0] && kuf_prefetched;
       if (pl.size() > 1) {
-        for (auto& sg : pl)
-          HIP_TRY(hipMemcpyAsync(Xws.d() + sg.off * P, tasks[sg.t].X.d() + sg.r0 * P, sizeof(double) * sg.n * P,
-                                 hipMemcpyDeviceToDevice, st));
+        if (!prefetched) stage_pool_inputs(pl, st);
         X = Xws.d();
       }
-      const bool prefetched = &pl == &pools[0] && kuf_prefetched;
       if (!prefetched) kuf_pool(pl, st);
       // Forward contraction for all latents (batched), row statistics fused into its epilogue; P~ itself is only stored
       // when the Z gradient (its one remaining consumer, colstats) is requested.  One launch per pool -- or one per

@@ -341,32 +341,35 @@ __global__ void potrf_finalize_kernel(double* __restrict__ A, int M, const doubl
 }
 
 // ---------------------------------------------------------------------------------------------- trtri
-// Inverse of each 32 x 32 lower-triangular diagonal block (thread c solves L x = e_c).
+// Inverse of each 32 x 32 lower-triangular diagonal block: lane c solves L x = e_c by forward substitution with its column in
+// REGISTERS (fully unrolled: static register indices) and the rows of L as uniform LDS broadcasts; the sum of row r runs
+// over k = 0 .. r-1 for every lane (x[k] == 0 for k < c contributes exact zeros), so all lanes execute one instruction
+// stream and every element sees the operations of the plain recurrence  x_r = -(sum_{k=c}^{r-1} L_rk x_k) / L_rr.
 __global__ __launch_bounds__(64) void trtri_diag_kernel(const double* __restrict__ Lall, double* __restrict__ Xall, int M) {
-  __shared__ double D[NB][NBP];
-  __shared__ double X[NB][NBP];
+  __shared__ __attribute__((aligned(16))) double D[NB][NBP + 1];
   const int q = blockIdx.y, j = blockIdx.x * NB, jb = min(NB, M - j), t = threadIdx.x;
   const double* L = Lall + (long long)q * M * M;
   double* Xo = Xall + (long long)q * M * M;
   for (int e = t; e < NB * NB; e += blockDim.x) {
     const int r = e / NB, c = e % NB;
     D[r][c] = (r < jb && c <= r) ? L[(long long)(j + r) * M + (j + c)] : 0.0;
-    X[r][c] = 0.0;
   }
   __syncthreads();
-  if (t < jb) {
-    const int c = t;
-    X[c][c] = 1.0 / D[c][c];
-    for (int r = c + 1; r < jb; ++r) {
-      double s = 0.0;
-      for (int k = c; k < r; ++k) s += D[r][k] * X[k][c];
-      X[r][c] = -s / D[r][r];
-    }
+  if (t >= NB) return;
+  const int c = t;
+  double x[NB];
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < r; ++k) s = fma(D[r][k], x[k], s);
+    const double num = (r == c) ? 1.0 : -s;
+    x[r] = (r >= c) ? num / D[r][r] : 0.0;
   }
-  __syncthreads();
-  for (int e = t; e < jb * jb; e += blockDim.x) {
-    const int r = e / jb, c = e % jb;
-    Xo[(long long)(j + r) * M + (j + c)] = X[r][c];
+  if (c < jb) {
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+      if (r < jb) Xo[(long long)(j + r) * M + (j + c)] = x[r];
   }
 }
 
