@@ -122,8 +122,9 @@ void launch_gemm_small(const GemmArgs& g, hipStream_t stream);
 // dpotrf convention; the matrix content is then undefined). Upper triangle is zeroed. dscr: Q*M*M doubles (out-of-place factor).
 void launch_potrf_batched(double* A, int Q, int M, int* d_info, double* dscr, hipStream_t stream, int panel_begin = 0,
                           int panel_end = -1);
-// Linv[q] = L[q]^-1 (lower triangular, upper zero). `L` is preserved; tmp: Q*M*M doubles.
-void launch_trtri_batched(const double* L, double* Linv, double* tmp, int Q, int M, hipStream_t stream);
+// Linv[q] = L[q]^-1 (lower triangular, upper zero). `L` is preserved; tmp: Q*M*M doubles.  linv_is_zero: the caller has
+// already zeroed Linv (off the critical path of a latency-bound chain).
+void launch_trtri_batched(const double* L, double* Linv, double* tmp, int Q, int M, hipStream_t stream, bool linv_is_zero = false);
 // Out[q] = Linv[q]^T Linv[q]  (= (L L^T)^-1), full symmetric.
 void launch_ltl_batched(const double* Linv, double* Out, int Q, int M, hipStream_t stream);
 

@@ -226,7 +226,7 @@ struct hmogp_engine {
   hipEvent_t ev_begin0 = nullptr, ev_begin1 = nullptr, ev_fin0 = nullptr, ev_fin1 = nullptr;
   hipStream_t st2 = nullptr;  // second stream, LOW priority: bandwidth-bound work beside the main stream (K_uf prefetch, colstats)
   hipStream_t st3 = nullptr;  // third stream, HIGH priority like the main one: the q(u)-only chains (S, S^-1; dL/dL, D2H)
-  hipEvent_t ev_fork = nullptr, ev_gsk = nullptr, ev_S = nullptr, ev_join = nullptr, ev_col = nullptr, ev_kuf = nullptr, ev_params = nullptr,
+  hipEvent_t ev_fork = nullptr, ev_gsk = nullptr, ev_zero = nullptr, ev_S = nullptr, ev_join = nullptr, ev_col = nullptr, ev_kuf = nullptr, ev_params = nullptr,
              ev_ua = nullptr;
 
   hipEvent_t new_event() {
@@ -265,7 +265,7 @@ struct hmogp_engine {
   ~hmogp_engine() {
     for (auto e : pool) (void)hipEventDestroy(e);
     for (auto e : ev_seg) (void)hipEventDestroy(e);
-    for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_gsk, ev_S, ev_join, ev_col, ev_kuf, ev_params, ev_ua})
+    for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_gsk, ev_zero, ev_S, ev_join, ev_col, ev_kuf, ev_params, ev_ua})
       if (e) (void)hipEventDestroy(e);
     if (hstage) (void)hipHostFree(hstage);
     if (h_info) (void)hipHostFree(h_info);
@@ -317,7 +317,7 @@ struct hmogp_engine {
       if (!st2) HIP_TRY(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, lo));
       HIP_TRY(hipStreamCreateWithPriority(&st3, hipStreamNonBlocking, hi));
     }
-    for (hipEvent_t* e : {&ev_fork, &ev_gsk, &ev_S, &ev_join, &ev_col, &ev_kuf, &ev_params, &ev_ua})
+    for (hipEvent_t* e : {&ev_fork, &ev_gsk, &ev_zero, &ev_S, &ev_join, &ev_col, &ev_kuf, &ev_params, &ev_ua})
       HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (hipEvent_t* e : {&ev_begin0, &ev_begin1, &ev_fin0, &ev_fin1}) HIP_TRY(hipEventCreate(e));
     f_index.assign(c->f_index, c->f_index + Df);
@@ -525,6 +525,10 @@ struct hmogp_engine {
     }
     // The q(u) chain goes to a stream of the SAME (high) priority as the main one: on the low-priority stream it would
     // not be dispatched before the 32 back-to-back factorisation launches of the main stream have drained.
+    if (!kuu_hit) {   // the zeroed target of the K_uu chain's triangular inverse: 25 MB memset, not on the chain's stream
+      HIP_TRY(hipMemsetAsync(tmpA.p, 0, sizeof(double) * MM * Q, st3));
+      HIP_TRY(hipEventRecord(ev_zero, st3));
+    }
     launch_unpack_tril(dLflat.d(), L.d(), Q, M, st3);             // flat_to_triang   (svmogp_inf.py:193)
     mm(L.d(), false, L.d(), false, S.d(), 1.0, -1, -1, st3, +1, -1);  // S = L L^T    (:194-195), L lower
     HIP_TRY(hipEventRecord(ev_S, st3));
@@ -535,7 +539,8 @@ struct hmogp_engine {
       jitchol_enqueue(Kuu.d(), Luu.d(), Q, M, h_var.data(), rung.data(), dinfo.as<int>(), djit.d(), dscr.d(), st, js, 1);
     if (!kuu_hit) {
       jitchol_resolve(Kuu.d(), Luu.d(), Q, M, h_var.data(), rung.data(), dinfo.as<int>(), djit.d(), dscr.d(), st, js);
-      launch_trtri_batched(Luu.d(), tmpA.d(), tmpB.d(), Q, M, st);
+      HIP_TRY(hipStreamWaitEvent(st, ev_zero, 0));
+      launch_trtri_batched(Luu.d(), tmpA.d(), tmpB.d(), Q, M, st, true);   // (tmpA zeroed on the third stream, below)
       launch_ltl_batched(tmpA.d(), Kuui.d(), Q, M, st);             // K_uu^-1          (util.py:199)
       if (cache_kuu) kuu_key.swap(key), kuu_rung = rung, kuu_key_valid = true;
     }

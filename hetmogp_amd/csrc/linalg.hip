@@ -2,7 +2,7 @@
 //
 //   potrf  : blocked right-looking lower Cholesky, one fused launch per 32-column panel (diagonal block in registers,
 //            panel solve, FP64-MFMA trailing update).  Replaces LAPACK dpotrf behind GPy jitchol (hetmogp/util.py:198).
-//   trtri  : triangular inverse by LDS diagonal-block inverses + log2(M/32) levels of batched GEMM merges.
+//   trtri  : triangular inverse by in-register 64 x 64 diagonal-block inverses + log2(M/64) levels of batched GEMM merges.
 //   ltl    : (L L^T)^-1 = Linv^T Linv.  trtri + ltl replace LAPACK dpotri behind GPy dpotri
 //            (hetmogp/util.py:199, hetmogp/svmogp_inf.py:124).
 #include "common.h"
@@ -341,34 +341,45 @@ __global__ void potrf_finalize_kernel(double* __restrict__ A, int M, const doubl
 }
 
 // ---------------------------------------------------------------------------------------------- trtri
-// Inverse of each 32 x 32 lower-triangular diagonal block: lane c solves L x = e_c by forward substitution with its column in
-// REGISTERS (fully unrolled: static register indices) and the rows of L as uniform LDS broadcasts; the sum of row r runs
-// over k = 0 .. r-1 for every lane (x[k] == 0 for k < c contributes exact zeros), so all lanes execute one instruction
-// stream and every element sees the operations of the plain recurrence  x_r = -(sum_{k=c}^{r-1} L_rk x_k) / L_rr.
-__global__ __launch_bounds__(64) void trtri_diag_kernel(const double* __restrict__ Lall, double* __restrict__ Xall, int M) {
-  __shared__ __attribute__((aligned(16))) double D[NB][NBP + 1];
-  const int q = blockIdx.y, j = blockIdx.x * NB, jb = min(NB, M - j), t = threadIdx.x;
+// Inverse of each TB x TB lower-triangular diagonal block (TB = 64: one column per lane of a wave): lane c solves L x = e_c by
+// forward substitution with its column in REGISTERS (fully unrolled: static register indices) and the rows of L as uniform
+// LDS broadcasts; the sum of row r runs over k = 0 .. r-1 for every lane (x[k] == 0 for k < c contributes exact zeros), so
+// all lanes execute one instruction stream:  x_r = -(sum_{k<r} L_rk x_k) * (1 / L_rr).  A 64 x 64 base block replaces the
+// 32 x 32 blocks plus the first level of GEMM merges (two launches of the latency-bound chain).
+constexpr int TB = 64;
+__global__ __launch_bounds__(256) void trtri_diag_kernel(const double* __restrict__ Lall, double* __restrict__ Xall, int M) {
+  __shared__ __attribute__((aligned(16))) double D[TB][TB + 2];
+  __shared__ double Rinv[TB];
+  const int q = blockIdx.y, j = blockIdx.x * TB, jb = min(TB, M - j), t = threadIdx.x;
   const double* L = Lall + (long long)q * M * M;
   double* Xo = Xall + (long long)q * M * M;
-  for (int e = t; e < NB * NB; e += blockDim.x) {
-    const int r = e / NB, c = e % NB;
+  for (int e = t; e < TB * TB; e += blockDim.x) {
+    const int r = e / TB, c = e % TB;
     D[r][c] = (r < jb && c <= r) ? L[(long long)(j + r) * M + (j + c)] : 0.0;
   }
   __syncthreads();
-  if (t >= NB) return;
+  if (t >= TB) return;              // (four waves fetch the block, one solves)
   const int c = t;
-  double x[NB];
+  Rinv[t] = 1.0 / D[t][t];          // all reciprocal pivots at once, one per lane (rows beyond the block: 1/0, never used)
+  double x[TB];
+  // (one wave: its LDS accesses are processed in order, no barrier needed before the broadcast reads of Rinv below)
 #pragma unroll
-  for (int r = 0; r < NB; ++r) {
-    double s = 0.0;
+  for (int r = 0; r < TB; ++r) {
+    // four interleaved partial sums: the recurrence is latency-bound (one wave, dependent FMAs), not throughput-bound
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-    for (int k = 0; k < r; ++k) s = fma(D[r][k], x[k], s);
-    const double num = (r == c) ? 1.0 : -s;
-    x[r] = (r >= c) ? num / D[r][r] : 0.0;
+    for (int k = 0; k < r; ++k) {
+      if ((k & 3) == 0) s0 = fma(D[r][k], x[k], s0);
+      else if ((k & 3) == 1) s1 = fma(D[r][k], x[k], s1);
+      else if ((k & 3) == 2) s2 = fma(D[r][k], x[k], s2);
+      else s3 = fma(D[r][k], x[k], s3);
+    }
+    const double num = (r == c) ? 1.0 : -((s0 + s1) + (s2 + s3));
+    x[r] = (r >= c) ? num * Rinv[r] : 0.0;
   }
   if (c < jb) {
 #pragma unroll
-    for (int r = 0; r < NB; ++r)
+    for (int r = 0; r < TB; ++r)
       if (r < jb) Xo[(long long)(j + r) * M + (j + c)] = x[r];
   }
 }
@@ -435,12 +446,12 @@ void launch_potrf_batched(double* A, int Q, int M, int* d_info, double* scr, hip
 }
 
 // Linv = L^-1.  `tmp` is a Q x M x M scratch.
-void launch_trtri_batched(const double* L, double* Linv, double* tmp, int Q, int M, hipStream_t stream) {
+void launch_trtri_batched(const double* L, double* Linv, double* tmp, int Q, int M, hipStream_t stream, bool linv_is_zero) {
   const long long MM = (long long)M * M;
-  HIP_TRY(hipMemsetAsync(Linv, 0, sizeof(double) * MM * Q, stream));
-  hipLaunchKernelGGL(trtri_diag_kernel, dim3((M + NB - 1) / NB, Q), dim3(64), 0, stream, L, Linv, M);
+  if (!linv_is_zero) HIP_TRY(hipMemsetAsync(Linv, 0, sizeof(double) * MM * Q, stream));
+  hipLaunchKernelGGL(trtri_diag_kernel, dim3((M + TB - 1) / TB, Q), dim3(256), 0, stream, L, Linv, M);
   // merge [[X11, 0], [X21, X22]] with X21 = -X22 * L21 * X11, block size s doubling
-  for (int s = NB; s < M; s *= 2) {
+  for (int s = TB; s < M; s *= 2) {
     const int npairs = (M - s - 1) / (2 * s) + 1;  // pairs whose right block is non-empty
     const int last_right = (2 * (npairs - 1) + 1) * s;
     const int r_last = std::min(s, M - last_right);
