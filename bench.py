@@ -171,7 +171,7 @@ def main():
 
     if rank == 0:
         pairs_rows = rows_rank * Q                               # (row, latent) pairs per step on this rank
-        # dominant kernel: forward contraction; one launch = all Q latents of one task segment (200 000 rows at the headline
+        # dominant kernel: forward contraction; one launch = all Q latents of all rows of the step (800 000 at the headline
         # size) = 2 * rows * Q * M * M algorithmic flops; the category holds exactly that kernel, so
         # cat_ms / launches = its average launch duration (HIP events on the engine's stream around every launch)
         fwd_flops = 2.0 * pairs_rows * M * M * args.steps

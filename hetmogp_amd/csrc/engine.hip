@@ -264,7 +264,6 @@ struct hmogp_engine {
 
   ~hmogp_engine() {
     for (auto e : pool) (void)hipEventDestroy(e);
-    for (auto e : ev_seg) (void)hipEventDestroy(e);
     for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_gsk, ev_zero, ev_S, ev_join, ev_col, ev_kuf, ev_params, ev_ua})
       if (e) (void)hipEventDestroy(e);
     if (hstage) (void)hipHostFree(hstage);
@@ -569,16 +568,11 @@ struct hmogp_engine {
   struct Seg { int t; long long r0, n, off; };
   std::vector<std::vector<Seg>> pools;
   bool kuf_prefetched = false;
-  std::vector<hipEvent_t> ev_seg;   // K_uf of segment i of the prefetched pool is complete
-  // A segment gets its own forward launch when it is large enough to fill the device by itself: the forward contraction of
-  // segment i then only waits for K_uf of segment i, and the (HBM-bound) construction of the later segments hides behind it.
-  static constexpr long long SEG_FORWARD_MIN_ROWS = 32768;
+  // K_uf is built in launches of KUF_CHUNK_ROWS rows on the side stream (see kuf_pool); the forward contraction is ONE launch
+  // per pool.  (Measured alternative: one forward launch per task segment, each waiting only for its own part of K_uf --
+  // 127.3 vs 126.3 ms at the headline size, 34.15 vs 33.7 ms at 50 000 rows per task: K_uf construction beside a forward
+  // costs the forward what it takes alone, and every extra launch adds a partially filled last round of blocks.)
   static constexpr long long KUF_CHUNK_ROWS = 16384;
-  bool seg_forward(const std::vector<Seg>& pl) const {
-    bool per_seg = !use_windows && pl.size() > 1;
-    for (auto& sg : pl) per_seg = per_seg && sg.n >= SEG_FORWARD_MIN_ROWS;
-    return per_seg;
-  }
   void plan_pools() {
     pools.clear();
     kuf_prefetched = false;
@@ -621,15 +615,6 @@ struct hmogp_engine {
       for (long long r = 0; r < sg.n; r += step)
         launch_rbf(Xs + r * P, P, std::min(step, sg.n - r), P, dZ.d(), ldz, M, 0.0, 1.0, Kh.d() + (sg.off + r) * M, false, stream,
                    rw, false, &rbt);
-      if (stream != st) {            // prefetch on another stream: one completion event per segment
-        const size_t i = si;
-        while (ev_seg.size() <= i) {
-          hipEvent_t e;
-          HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-          ev_seg.push_back(e);
-        }
-        HIP_TRY(hipEventRecord(ev_seg[i], stream));
-      }
     }
   }
 
@@ -666,13 +651,10 @@ struct hmogp_engine {
       }
       if (!prefetched) kuf_pool(pl, st);
       // Forward contraction for all latents (batched), row statistics fused into its epilogue; P~ itself is only stored
-      // when the Z gradient (its one remaining consumer, colstats) is requested.  One launch per pool -- or one per
-      // segment when every segment is large (see SEG_FORWARD_MIN_ROWS).
-      const bool per_seg = seg_forward(pl);
+      // when the Z gradient (its one remaining consumer, colstats) is requested.  One launch per pool.
       const long long sPart = 4LL * FWD_PARTS * tiles * ldn;
-      const size_t nlaunch = per_seg ? pl.size() : 1;
       const long long clen = (long long)M * (1 + P);          // one column-statistics slab: [ r (M) | dZ (M*P) ]
-      // slabs of the column statistics: 256-row splits, per segment when the segments are launched separately
+      // slabs of the column statistics: 256-row splits
       const long long nsp = (n + 255) / 256;                  // 256-row slabs of the column statistics
 
       auto quad_segment = [&](const Seg& sg) {
@@ -713,14 +695,9 @@ struct hmogp_engine {
                         X + off * P, P, dZ.d(), ldz, rows, M, 256, want_z, colpart.d() + slab_first * clen, st2, cw, &cb);
       };
 
-      for (size_t li = 0; li < nlaunch; ++li) {
-        const long long off = per_seg ? pl[li].off : 0, rows = per_seg ? pl[li].n : n;
-        if (prefetched) {
-          if (!per_seg)
-            HIP_TRY(hipStreamWaitEvent(st, ev_kuf, 0));
-          else
-            HIP_TRY(hipStreamWaitEvent(st, ev_seg[li], 0));
-        }
+      {
+        const long long off = 0, rows = n;
+        if (prefetched) HIP_TRY(hipStreamWaitEvent(st, ev_kuf, 0));
         int nparts = 2;
         {
           // forward contraction for all latents (batched), row statistics fused into its epilogue; P~ itself is only

@@ -87,7 +87,7 @@ def main():
     if fwd:
         json.dump({"kernel": fwd[0]["kernel"], "grid_threads": fwd[0]["grid_threads"], "launches": fwd[0]["launches"],
                    "hbm_bytes_per_launch": fwd[0]["hbm_bytes_per_launch"], "source": "profiles/r%s_pmc_hbm.csv" % rnd,
-                   "note": "forward contraction of ONE launch = one task segment (200000 rows) x all Q=3 latents of the headline workload; "
+                   "note": "forward contraction of ONE launch = all 800000 rows x all Q=3 latents of the headline workload; "
                            "(2*FETCH_SIZE + WRITE_SIZE)*1024 from separate --pmc passes, round %s" % rnd},
                   open(os.path.join(dst, "pmc_forward_gemm.json"), "w"))
 
