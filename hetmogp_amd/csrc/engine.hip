@@ -226,7 +226,7 @@ struct hmogp_engine {
   hipEvent_t ev_begin0 = nullptr, ev_begin1 = nullptr, ev_fin0 = nullptr, ev_fin1 = nullptr;
   hipStream_t st2 = nullptr;  // second stream, LOW priority: bandwidth-bound work beside the main stream (K_uf prefetch, colstats)
   hipStream_t st3 = nullptr;  // third stream, HIGH priority like the main one: the q(u)-only chains (S, S^-1; dL/dL, D2H)
-  hipEvent_t ev_fork = nullptr, ev_gsk = nullptr, ev_zero = nullptr, ev_S = nullptr, ev_join = nullptr, ev_col = nullptr, ev_kuf = nullptr, ev_params = nullptr,
+  hipEvent_t ev_fork = nullptr, ev_gsk = nullptr, ev_zero = nullptr, ev_info = nullptr, ev_S = nullptr, ev_join = nullptr, ev_col = nullptr, ev_kuf = nullptr, ev_params = nullptr,
              ev_ua = nullptr;
 
   hipEvent_t new_event() {
@@ -264,7 +264,7 @@ struct hmogp_engine {
 
   ~hmogp_engine() {
     for (auto e : pool) (void)hipEventDestroy(e);
-    for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_gsk, ev_zero, ev_S, ev_join, ev_col, ev_kuf, ev_params, ev_ua})
+    for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_gsk, ev_zero, ev_info, ev_S, ev_join, ev_col, ev_kuf, ev_params, ev_ua})
       if (e) (void)hipEventDestroy(e);
     if (hstage) (void)hipHostFree(hstage);
     if (h_info) (void)hipHostFree(h_info);
@@ -316,7 +316,7 @@ struct hmogp_engine {
       if (!st2) HIP_TRY(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, lo));
       HIP_TRY(hipStreamCreateWithPriority(&st3, hipStreamNonBlocking, hi));
     }
-    for (hipEvent_t* e : {&ev_fork, &ev_gsk, &ev_zero, &ev_S, &ev_join, &ev_col, &ev_kuf, &ev_params, &ev_ua})
+    for (hipEvent_t* e : {&ev_fork, &ev_gsk, &ev_zero, &ev_info, &ev_S, &ev_join, &ev_col, &ev_kuf, &ev_params, &ev_ua})
       HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (hipEvent_t* e : {&ev_begin0, &ev_begin1, &ev_fin0, &ev_fin1}) HIP_TRY(hipEventCreate(e));
     f_index.assign(c->f_index, c->f_index + Df);
@@ -536,25 +536,41 @@ struct hmogp_engine {
     HIP_TRY(hipEventRecord(ev_join, st3));
     if (!kuu_hit && !js.complete)
       jitchol_enqueue(Kuu.d(), Luu.d(), Q, M, h_var.data(), rung.data(), dinfo.as<int>(), djit.d(), dscr.d(), st, js, 1);
+    if (!kuu_hit) HIP_TRY(hipEventRecord(ev_info, st));          // behind the read-back of the factorisation's info
+    // Everything behind the factorisation is enqueued SPECULATIVELY, before the host knows whether it succeeded: the device
+    // goes straight on while the host waits for `info` alone (an event, not the stream) and then enqueues the row pass
+    // behind ~0.6 ms of queued work -- no host round trip in the latency-bound chain.  If a latent did fail (GPy's jitter
+    // ladder is needed: rare), the ladder runs synchronously as before and the same launches are simply issued again.
+    auto tail = [&](bool first) {
+      if (!kuu_hit) {
+        if (first) HIP_TRY(hipStreamWaitEvent(st, ev_zero, 0));     // (tmpA zeroed on the third stream, above)
+        launch_trtri_batched(Luu.d(), tmpA.d(), tmpB.d(), Q, M, st, first);
+        launch_ltl_batched(tmpA.d(), Kuui.d(), Q, M, st);           // K_uu^-1          (util.py:199)
+      }
+      launch_gemv_batched(Kuui.d(), dmu.d(), a.d(), Q, M, 1, Q, st);  // a = K_uu^-1 m
+      HIP_TRY(hipStreamWaitEvent(st, ev_S, 0));
+      mm(Kuui.d(), false, S.d(), true, KiS.d());
+      mm(KiS.d(), false, Kuui.d(), true, KSK.d());
+      launch_sub(KSK.d(), Kuui.d(), C.d(), MM * Q, st);             // C = K^-1 S K^-1 - K^-1
+      launch_tri_fold(C.d(), Ctri.d(), Q, M, st);                   // x^T Ctri x == x^T C x with a triangular matrix
+      HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));
+      // the KL terms (svmogp_inf.py:227-250) only need what exists now: they run on the third stream beside the row pass
+      // instead of sitting in the tail of hmogp_step_finish
+      HIP_TRY(hipEventRecord(ev_ua, st));
+      HIP_TRY(hipStreamWaitEvent(st3, ev_ua, 0));
+      launch_kl_terms(Kuui.d(), S.d(), dmu.d(), a.d(), Luu.d(), L.d(), Sqi.d(), Q, M, klout.d(), st3);
+    };
+    tail(true);
     if (!kuu_hit) {
-      jitchol_resolve(Kuu.d(), Luu.d(), Q, M, h_var.data(), rung.data(), dinfo.as<int>(), djit.d(), dscr.d(), st, js);
-      HIP_TRY(hipStreamWaitEvent(st, ev_zero, 0));
-      launch_trtri_batched(Luu.d(), tmpA.d(), tmpB.d(), Q, M, st, true);   // (tmpA zeroed on the third stream, below)
-      launch_ltl_batched(tmpA.d(), Kuui.d(), Q, M, st);             // K_uu^-1          (util.py:199)
+      HIP_TRY(hipEventSynchronize(ev_info));
+      bool failed = false;
+      for (int q = 0; q < Q; ++q) failed = failed || js.info[q] != 0;
+      if (failed) {
+        jitchol_resolve(Kuu.d(), Luu.d(), Q, M, h_var.data(), rung.data(), dinfo.as<int>(), djit.d(), dscr.d(), st, js);
+        tail(false);
+      }
       if (cache_kuu) kuu_key.swap(key), kuu_rung = rung, kuu_key_valid = true;
     }
-    launch_gemv_batched(Kuui.d(), dmu.d(), a.d(), Q, M, 1, Q, st);  // a = K_uu^-1 m
-    HIP_TRY(hipStreamWaitEvent(st, ev_S, 0));
-    mm(Kuui.d(), false, S.d(), true, KiS.d());
-    mm(KiS.d(), false, Kuui.d(), true, KSK.d());
-    launch_sub(KSK.d(), Kuui.d(), C.d(), MM * Q, st);             // C = K^-1 S K^-1 - K^-1
-    launch_tri_fold(C.d(), Ctri.d(), Q, M, st);                   // x^T Ctri x == x^T C x with a triangular matrix
-    HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));
-    // the KL terms (svmogp_inf.py:227-250) only need what exists now: they run on the second stream beside the row pass
-    // instead of sitting in the tail of hmogp_step_finish
-    HIP_TRY(hipEventRecord(ev_ua, st));
-    HIP_TRY(hipStreamWaitEvent(st3, ev_ua, 0));
-    launch_kl_terms(Kuui.d(), S.d(), dmu.d(), a.d(), Luu.d(), L.d(), Sqi.d(), Q, M, klout.d(), st3);
   }
 
   // ------------------------------------------------------------------------------------------ row pools
