@@ -135,7 +135,7 @@ bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 bool gemm_small_eligible(const GemmArgs& g) {
   if (g.role != 0 || g.beta != 0.0 || g.ksplit != 1 || g.kscale || g.win || g.fs_part) return false;
   if ((g.M_last && g.M_last != g.M) || (g.N_last && g.N_last != g.N) || (g.K_last && g.K_last != g.K)) return false;
-  if ((g.M % TM) || (g.N % TN) || (g.K % TK) || g.M < 256) return false;   // (small problems: the 128-tile kernel's launch is as fast)
+  if ((g.M % TM) || (g.N % TN) || (g.K % TK)) return false;
   return true;
 }
 
