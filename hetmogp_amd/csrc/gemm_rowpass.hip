@@ -31,53 +31,9 @@ struct Tile {
 __device__ __forceinline__ int diag_wm(int w) { return (0x4B >> w) & 1; }
 __device__ __forceinline__ int diag_wn(int w) { return (0x7E84 >> (2 * w)) & 3; }
 
-// ROLE 1 = forward, ROLE 2 = weighted Gram (names the instantiation in profiles, like gemm_f64_kernel's ROLE)
+// One 128 x 128 tile of the contraction: main loop + epilogue (everything the kernel does once it knows its tile).
 template <int ROLE>
-__global__ __launch_bounds__(NT, 4) void rowpass_gemm_kernel(GemmArgs g, int tiles_n, int ntiles) {
-  __shared__ __attribute__((aligned(16))) Tile lds;
-  __shared__ __attribute__((aligned(16))) double epi_a[ROLE == 1 ? 128 : 2];
-
-  // ---- which tile / batch / k-range (block b is observed to run on XCD b % 8: speed only) ----------------------------
-  int v = blockIdx.x, split = 0;
-  int ti, tj;
-  if (ROLE == 2 && g.lower_only) {
-    // Lower tiles of the Gram, in TWO phases of equal-duration blocks.  The tiles of one K range stream the same operand rows,
-    // and they only share them through the XCD's L2 if they START together: blocks of unequal duration (a diagonal tile does
-    // ~0.6 of the work) spread the start times of everything behind them and the sharing is lost (measured: 36 mixed tiles
-    // per range run as slowly as 36 full ones).  So: first all strictly-lower tiles, range-major, all tiles of one K range on
-    // ONE XCD (block b is observed to run on XCD b % 8: speed only); then the diagonal tiles, which share nothing (tile
-    // (d, d) reads panel d only).
-    const int T = tiles_n, noff = T * (T - 1) / 2, ks8 = (g.ksplit > 1) ? ((g.ksplit + 7) / 8) * 8 : 1, gx1 = noff * ks8;
-    if (v < gx1) {
-      int u = v;                                          // strictly-lower index: u = ti (ti - 1) / 2 + tj, tj < ti
-      if (g.ksplit > 1) {
-        const int xcd = v & 7, idx = v >> 3;
-        split = (idx / noff) * 8 + xcd;
-        u = idx % noff;
-      }
-      ti = (int)((sqrt(8.0 * (double)u + 1.0) + 1.0) * 0.5);
-      while (ti * (ti + 1) / 2 <= u) ++ti;
-      while (ti * (ti - 1) / 2 > u) --ti;
-      tj = u - ti * (ti - 1) / 2;
-    } else {
-      const int u = v - gx1;
-      split = u / T;
-      ti = tj = u - split * T;
-    }
-    if (split >= g.ksplit) return;
-  } else {
-    if (g.ksplit > 1) {               // all tiles of one K range on ONE XCD: they stream the same operand rows concurrently
-      const int xcd = v & 7, idx = v >> 3;
-      split = (idx / ntiles) * 8 + xcd;
-      v = idx % ntiles;
-      if (split >= g.ksplit) return;
-    } else if ((ntiles & 7) == 0) {   // a contiguous range of tiles per XCD: the column tiles of a row panel share its A panel
-      const int cpx = ntiles >> 3;
-      v = (v & 7) * cpx + (v >> 3);
-    }
-    ti = v / tiles_n;
-    tj = v - ti * tiles_n;
-  }
+__device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int ti, int tj, int split, Tile& lds, double* epi_a) {
   const int batch = blockIdx.z;
   const int M = g.M, N = g.N, K = g.K;
   const int i0 = ti * BM, j0 = tj * BN;
@@ -327,6 +283,75 @@ __global__ __launch_bounds__(NT, 4) void rowpass_gemm_kernel(GemmArgs g, int til
     }
 }
 
+template <int ROLE, bool PAIR>
+__device__ __forceinline__ void rowpass_block(const GemmArgs& g, int tiles_n, int ntiles, Tile& lds, double* epi_a) {
+
+  // ---- which tile / batch / k-range (block b is observed to run on XCD b % 8: speed only) ----------------------------
+  int v = blockIdx.x, split = 0;
+  int ti, tj;
+  if (ROLE == 2 && g.lower_only) {
+    // Lower tiles of the Gram, in TWO phases of equal-duration blocks.  The tiles of one K range stream the same operand rows,
+    // and they only share them through the XCD's L2 if they START together: blocks of unequal duration (a diagonal tile does
+    // ~0.6 of the work) spread the start times of everything behind them and the sharing is lost (measured: 36 mixed tiles
+    // per range run as slowly as 36 full ones).  So: first all strictly-lower tiles, range-major, all tiles of one K range on
+    // ONE XCD (block b is observed to run on XCD b % 8: speed only); then the diagonal tiles, which share nothing (tile
+    // (d, d) reads panel d only).
+    const int T = tiles_n, noff = T * (T - 1) / 2, ks8 = (g.ksplit > 1) ? ((g.ksplit + 7) / 8) * 8 : 1, gx1 = noff * ks8;
+    if (v < gx1) {
+      int u = v;                                          // strictly-lower index: u = ti (ti - 1) / 2 + tj, tj < ti
+      if (g.ksplit > 1) {
+        const int xcd = v & 7, idx = v >> 3;
+        split = (idx / noff) * 8 + xcd;
+        u = idx % noff;
+      }
+      ti = (int)((sqrt(8.0 * (double)u + 1.0) + 1.0) * 0.5);
+      while (ti * (ti + 1) / 2 <= u) ++ti;
+      while (ti * (ti - 1) / 2 > u) --ti;
+      tj = u - ti * (ti - 1) / 2;
+    } else {
+      const int u = v - gx1;
+      split = u / T;
+      ti = tj = u - split * T;
+    }
+    if (split >= g.ksplit) return;
+  } else {
+    if (g.ksplit > 1) {               // all tiles of one K range on ONE XCD: they stream the same operand rows concurrently
+      const int xcd = v & 7, idx = v >> 3;
+      split = (idx / ntiles) * 8 + xcd;
+      v = idx % ntiles;
+      if (split >= g.ksplit) return;
+    } else if ((ntiles & 7) == 0) {   // a contiguous range of tiles per XCD: the column tiles of a row panel share its A panel
+      const int cpx = ntiles >> 3;
+      v = (v & 7) * cpx + (v >> 3);
+    }
+    const int tcols = PAIR ? tiles_n / 2 : tiles_n;
+    ti = v / tcols;
+    tj = v - ti * tcols;
+  }
+  rowpass_tile<ROLE>(g, tiles_n, ti, tj, split, lds, epi_a);
+  // Triangular fold (b_tri > 0, the E-step's / predict_f's forward): the k-loop of column tile j starts at j, so the tiles of
+  // a row panel do 8, 7, ... 1 eighths of a full tile's work.  In paired mode a block takes column tiles j and
+  // tiles_n - 1 - j one after the other: every block does (tiles_n + 1) / tiles_n of a full tile -- equal durations.
+  if (PAIR) {
+    __syncthreads();                 // the epilogue of the first tile used the tile buffers as scratch
+    rowpass_tile<ROLE>(g, tiles_n, ti, tiles_n - 1 - tj, split, lds, epi_a);
+  }
+}
+
+// ROLE 1 = forward, ROLE 2 = weighted Gram (names the instantiation in profiles, like gemm_f64_kernel's ROLE)
+template <int ROLE>
+__global__ __launch_bounds__(NT, 4) void rowpass_gemm_kernel(GemmArgs g, int tiles_n, int ntiles) {
+  __shared__ __attribute__((aligned(16))) Tile lds;
+  __shared__ __attribute__((aligned(16))) double epi_a[ROLE == 1 ? 128 : 2];
+  rowpass_block<ROLE, false>(g, tiles_n, ntiles, lds, epi_a);
+}
+// the forward contraction against the triangular fold of C, two column tiles per block (see rowpass_block)
+__global__ __launch_bounds__(NT, 4) void rowpass_fold_pair_kernel(GemmArgs g, int tiles_n, int ntiles) {
+  __shared__ __attribute__((aligned(16))) Tile lds;
+  __shared__ __attribute__((aligned(16))) double epi_a[128];
+  rowpass_block<1, true>(g, tiles_n, ntiles, lds, epi_a);
+}
+
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
@@ -351,10 +376,18 @@ void launch_gemm_rowpass(const GemmArgs& g, hipStream_t stream) {
   const int ntiles = g.lower_only ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
   const int gx = (g.ksplit > 1) ? ntiles * ((g.ksplit + 7) / 8) * 8 : ntiles;
   dim3 grid(gx, 1, g.nbatch);
-  if (g.role == 1)
-    hipLaunchKernelGGL((rowpass_gemm_kernel<1>), grid, dim3(NT), 0, stream, g, tiles_n, ntiles);
-  else
+  if (g.role == 1) {
+    // triangular fold: column tiles paired (j, tiles_n - 1 - j) per block (see the kernel)
+    const int pair = (g.b_tri > 0 && g.ksplit == 1 && tiles_n >= 2 && (tiles_n & 1) == 0) ? 1 : 0;
+    if (pair) {
+      grid.x = tiles_m * (tiles_n / 2);
+      hipLaunchKernelGGL(rowpass_fold_pair_kernel, grid, dim3(NT), 0, stream, g, tiles_n, (int)grid.x);
+    } else {
+      hipLaunchKernelGGL((rowpass_gemm_kernel<1>), grid, dim3(NT), 0, stream, g, tiles_n, ntiles);
+    }
+  } else {
     hipLaunchKernelGGL((rowpass_gemm_kernel<2>), grid, dim3(NT), 0, stream, g, tiles_n, ntiles);
+  }
 }
 
 int launch_gemm_rowpass_or_general(const GemmArgs& g, hipStream_t stream) {
