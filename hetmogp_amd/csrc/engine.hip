@@ -553,7 +553,9 @@ struct hmogp_engine {
       mm(KiS.d(), false, Kuui.d(), true, KSK.d());
       launch_sub(KSK.d(), Kuui.d(), C.d(), MM * Q, st);             // C = K^-1 S K^-1 - K^-1
       launch_tri_fold(C.d(), Ctri.d(), Q, M, st);                   // x^T Ctri x == x^T C x with a triangular matrix
-      HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));
+      // (the main stream does NOT wait for S^-1 here: the row pass needs C only, S^-1 is consumed on the third stream --
+      // KL terms, dL/dS -- and hmogp_step_finish orders itself behind that chain before it reuses its scratch buffers.
+      // With a cached K_uu chain this wait used to hold the forward contraction back by ~0.3 ms.)
       // the KL terms (svmogp_inf.py:227-250) only need what exists now: they run on the third stream beside the row pass
       // instead of sitting in the tail of hmogp_step_finish
       HIP_TRY(hipEventRecord(ev_ua, st));
@@ -820,6 +822,7 @@ struct hmogp_engine {
     const bool want_qu = (group_mask & HMOGP_GROUP_QU) != 0 || out->dL_dS != nullptr;
     const bool want_hz = (group_mask & (HMOGP_GROUP_HYPER | HMOGP_GROUP_Z)) != 0;
     HIP_TRY(hipEventRecord(ev_fin0, st));
+    HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));   // the S^-1 chain of hmogp_step_begin (third stream) used HK / G as scratch
     {
       Scope sc(this, CAT_MM, 0);
       launch_mirror_lower(Hq(0), Q, M, per_q, st);                   // the row pass / the exchange fill the lower triangle

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
-"""Timeline of one engine step from a rocprofv3 kernel trace: python tools/step_timeline.py <kernel_trace.csv> [step_index]
-(steps are delimited by the batched K_uu covariance launch, rbf_kernel<P, true>)."""
+"""Timeline of one engine step from a rocprofv3 kernel trace:
+python tools/step_timeline.py <kernel_trace.csv> [step_index] [marker]
+Steps are delimited by the batched K_uu covariance launch, rbf_kernel<P, true>, or by the first kernel whose short name
+starts with `marker` (e.g. unpack_tril_kernel for E-steps with a cached K_uu chain, which have no covariance launch)."""
 import csv
 import re
 import sys
@@ -15,7 +17,8 @@ def short(n):
 
 
 names = [short(r['Kernel_Name']) for r in rows]
-marks = [i for i, n in enumerate(names) if n.startswith('rbf_kernel<') and 'true>' in n]
+marker = sys.argv[3] if len(sys.argv) > 3 else None
+marks = [i for i, n in enumerate(names) if (n.startswith(marker) if marker else (n.startswith('rbf_kernel<') and 'true>' in n))]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(marks) - 2
 s, e = marks[k], marks[k + 1]
 t0 = int(rows[s]['Start_Timestamp'])
