@@ -14,12 +14,26 @@ LIKS = [("Gaussian", {"sigma": 0.7}), ("Bernoulli", {}), ("Poisson", {}), ("Gamm
 MS = [16, 48, 64, 100, 128, 192, 256, 272, 320, 384, 448, 512, 640]
 
 
+MS_LARGE = [768, 1024, 1280, 2048]      # multiples of 128: specialised row-pass kernels, look-ahead Cholesky over 24-64 panels
+
+
 @pytest.mark.parametrize("seed", range(26))
 def test_random_configuration_vs_oracle(seed):
+    _case(seed, MS, False)
+
+
+@pytest.mark.parametrize("seed", range(100, 104))
+def test_random_configuration_large_M_vs_oracle(seed):
+    """The same at the inducing counts of the BASELINE configurations (1-D inputs: with 2-D grids of 1000+ inducing points
+    cond(K_uu) ~ 1e6 limits the agreement of the two implementations to ~1e-6 in the cancelling sums of g_variance)."""
+    _case(seed, MS_LARGE, True)
+
+
+def _case(seed, ms, one_d):
     from oracle import svmogp_oracle as so
     rng = np.random.RandomState(1000 + seed)
-    M = MS[seed % len(MS)]
-    P = 1 if rng.rand() < 0.7 else 2
+    M = ms[seed % len(ms)]
+    P = 1 if (rng.rand() < 0.7 or one_d) else 2
     Q = int(rng.randint(1, 4))
     T = int(rng.randint(1, 4))
     specs = [LIKS[i] for i in rng.choice(len(LIKS), T, replace=False)]
