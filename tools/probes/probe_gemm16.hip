@@ -8,11 +8,14 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int BM = 128, BN = 128, BK = 16, KM_LD = 144, RM_LD = 18, TILE = BK * KM_LD;
 
-// W = 8: wave grid 2 x 4, wave tile 64 x 32 (SA = 4, SB = 2);  W = 16: wave grid 4 x 4, wave tile 32 x 32 (SA = 2, SB = 2)
-template <int W>
+// W = 8, WGN = 4: wave grid 2 x 4, wave tile 64 x 32 (the product layout);  W = 16, WGN = 4: 4 x 4, wave tile 32 x 32;
+// W = 8, WGN = 1: wave grid 8 x 1, wave tile 16 x 128 (a wave owns complete rows of the tile: one row-statistics partial
+// per column tile instead of four -- at the price of 9 instead of 6 fragment reads per 8 MFMAs)
+template <int W, int WGN>
 __global__ __launch_bounds__(W * 64, W / 2) void gemm(const double* __restrict__ A, const double* __restrict__ B,
                                                       double* __restrict__ C, int n, int N, int K) {
-  constexpr int NT = W * 64, SA = (W == 8) ? 4 : 2, SB = 2, PER = 2048 / NT;
+  constexpr int NT = W * 64, SB = 8 / WGN, SA = 8 / (W / WGN), PER = 2048 / NT;
+  static_assert(SA * 16 * (W / WGN) == 128 && SB * 16 * WGN == 128, "wave tiles cover the block tile");
   __shared__ __attribute__((aligned(16))) double la[2][TILE];
   __shared__ __attribute__((aligned(16))) double lb[2][TILE];
   const int tiles_n = N / BN;
@@ -21,7 +24,7 @@ __global__ __launch_bounds__(W * 64, W / 2) void gemm(const double* __restrict__
   if ((ntiles & 7) == 0) { const int cpx = ntiles >> 3; v = (v & 7) * cpx + (v >> 3); }
   const int ti = v / tiles_n, tj = v - ti * tiles_n, i0 = ti * BM, j0 = tj * BN;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, lr = lane & 15, lk = lane >> 4;
-  const int wm = w >> 2, wn = w & 3;
+  const int wm = w / WGN, wn = w % WGN;
   f64x4 acc[SA][SB];
 #pragma unroll
   for (int a = 0; a < SA; ++a)
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(W * 64, W / 2) void gemm(const double* __restrict__
 #pragma unroll
       for (int i = 0; i < SA; ++i) fa[i] = la[cur][(wm * 16 * SA + i * 16 + lr) * RM_LD + kk * 4 + lk];
 #pragma unroll
-      for (int i = 0; i < SB; ++i) fb[i] = lb[cur][(kk * 4 + lk) * KM_LD + wn * 32 + i * 16 + lr];
+      for (int i = 0; i < SB; ++i) fb[i] = lb[cur][(kk * 4 + lk) * KM_LD + wn * (16 * SB) + i * 16 + lr];
 #pragma unroll
       for (int a = 0; a < SA; ++a)
 #pragma unroll
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(W * 64, W / 2) void gemm(const double* __restrict__
   for (int a = 0; a < SA; ++a)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      double* crow = C + (long long)(i0 + wm * 16 * SA + a * 16 + 4 * r + lk) * N + j0 + wn * 32;
+      double* crow = C + (long long)(i0 + wm * 16 * SA + a * 16 + 4 * r + lk) * N + j0 + wn * (16 * SB);
 #pragma unroll
       for (int b = 0; b < SB; ++b) crow[b * 16 + lr] = acc[a][b][r];
     }
@@ -92,10 +95,11 @@ int main() {
   hipEventCreate(&e0), hipEventCreate(&e1);
   const int blocks = (n / BM) * (N / BN);
   for (int rep = 0; rep < 2; ++rep)
-    for (int variant = 0; variant < 2; ++variant) {
+    for (int variant = 0; variant < 3; ++variant) {
       auto run = [&] {
-        if (variant == 0) hipLaunchKernelGGL(gemm<8>, dim3(blocks), dim3(512), 0, 0, A, B, C, n, N, K);
-        else hipLaunchKernelGGL(gemm<16>, dim3(blocks), dim3(1024), 0, 0, A, B, C, n, N, K);
+        if (variant == 0) hipLaunchKernelGGL((gemm<8, 4>), dim3(blocks), dim3(512), 0, 0, A, B, C, n, N, K);
+        else if (variant == 1) hipLaunchKernelGGL((gemm<16, 4>), dim3(blocks), dim3(1024), 0, 0, A, B, C, n, N, K);
+        else hipLaunchKernelGGL((gemm<8, 1>), dim3(blocks), dim3(512), 0, 0, A, B, C, n, N, K);
       };
       run();
       hipDeviceSynchronize();
@@ -110,8 +114,8 @@ int main() {
       hipMemcpy(&c0, C + 12345 * (size_t)N + 100, sizeof(double), hipMemcpyDeviceToHost);
       double ref = 0;  // spot check of C[12345][100]
       for (int k = 0; k < K; ++k) ref += h[(size_t)12345 * K + k] * h[(size_t)k * N + 100];
-      printf("%2d waves/block, %d waves/SIMD, stage-first: %.3f ms  %.1f TFLOP/s   check %.3e\n", variant ? 16 : 8, variant ? 8 : 4, ms,
-             2.0 * n * N * K / ms / 1e9, c0 - ref);
+      printf("%2d waves/block, %d waves/SIMD, wave tile %s, stage-first: %.3f ms  %.1f TFLOP/s   check %.3e\n", variant == 1 ? 16 : 8,
+             variant == 1 ? 8 : 4, variant == 0 ? "64x32" : (variant == 1 ? "32x32" : "16x128"), ms, 2.0 * n * N * K / ms / 1e9, c0 - ref);
     }
   return 0;
 }
