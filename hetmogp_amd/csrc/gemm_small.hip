@@ -130,8 +130,8 @@ bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 }  // namespace
 
 // Full 64 x 64 tiles, a k-extent that is a multiple of 16, no accumulation into C, no K split, no ragged last batch, no
-// row-pass extras.  Operands that are not 16-byte aligned (odd strides / offsets) are read with 8-byte loads.  lower_only is not honoured (every tile is computed: the
-// callers that ask for it mirror the result anyway).
+// row-pass extras.  Operands that are not 16-byte aligned (odd strides / offsets) are read with 8-byte loads.
+// lower_only is not honoured (every tile is computed: the callers that ask for it mirror the result anyway).
 bool gemm_small_eligible(const GemmArgs& g) {
   if (g.role != 0 || g.beta != 0.0 || g.ksplit != 1 || g.kscale || g.win || g.fs_part) return false;
   if ((g.M_last && g.M_last != g.M) || (g.N_last && g.N_last != g.N) || (g.K_last && g.K_last != g.K)) return false;
