@@ -16,9 +16,15 @@ torch.distributed.run.
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline      FP64-MFMA roofline of the dominant kernel (forward N x M x M contraction P~ = K^ C_q)
   roofline_kuf  HBM roofline of K_uf construction (rbf_cross_cov), the kernel the north-star singles out
-  cpu_baseline  baseline B: the NumPy/BLAS oracle ("port", all host cores) timed at two row samples (N=1 only)
+  cpu_baseline  baseline B: the NumPy/BLAS oracle ("port", all host cores) timed at two row samples (N=1 only), next
+                to the host's plain dgemm rate (host_dgemm_gflops) so that the port's efficiency is visible
   cpu_baseline_literal  baseline A: the literal reference algorithm (N x N terms) at C1 and up to N_t = 8192
   parity_at_headline_M  engine vs oracle on the sampled rows at the headline M (the bench fails above 1e-5)
+  other_configs the other BASELINE.json configurations (C1, C2, C3 as the facade's SVI loop over N_all = 1M, the per-rank
+                share of C4, C5 + predict_f on a 256 x 256 grid), a few steps each, with executed flops and the fraction
+                of the FP64-MFMA peak (N=1 only; these are reported beside `value`, never mixed into it)
+  N > 1: exchange_modes_ms_per_step times the step with the library's own RCCL communicator ("native", the default) and
+         with the torch.distributed all-reduce on the aliased wire buffer ("device"); replicated_ms_per_rank.
 """
 import argparse
 import json
@@ -77,8 +83,10 @@ def main():
     ap.add_argument("--rows", type=int, default=200000, help="rows per task (headline: 200000)")
     ap.add_argument("--inducing", type=int, default=1024, help="M (headline: 1024)")
     ap.add_argument("--latents", type=int, default=3, help="Q (headline: 3)")
-    ap.add_argument("--cpu-sample-rows", type=int, default=3000, help="rows per task of the larger CPU-baseline sample")
-    ap.add_argument("--cpu-literal-budget", type=float, default=100.0, help="seconds the literal-reference baseline may use")
+    ap.add_argument("--cpu-sample-rows", type=int, default=20000, help="rows per task of the larger CPU-baseline sample")
+    ap.add_argument("--cpu-literal-budget", type=float, default=70.0, help="seconds the literal-reference baseline may use")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip C1 / C2 / C3 / C4-share / C5 (N=1 only)")
+    ap.add_argument("--other-steps", type=int, default=5, help="timed steps per other configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-zero-pass", action="store_true", help="skip the extra (untimed-for-value) opt-in mode pass")
     args = ap.parse_args()
@@ -130,11 +138,13 @@ def main():
         prm[k] = a
     reducer = hdist.StatsReducer(eng, device=local_rank) if world > 1 else None
 
-    def step():
-        if world == 1:
+    def step(red=reducer):
+        # world > 1, default: the engine holds its own RCCL communicator ("native") and hmogp_elbo_grad IS the sharded step
+        # (row pass -> pack / ncclAllReduce / unpack on the engine's stream -> replicated finish, one host sync at the end)
+        if world == 1 or red.mode == "native":
             return eng.elbo_grad(**prm)
         eng.step_begin(**prm)
-        reducer()
+        red()
         return eng.step_finish()
 
     def fence():
@@ -168,6 +178,39 @@ def main():
         rows_all = [int(g.item()) for g in gathered]
     if not np.isfinite(out["elbo"]):
         raise SystemExit("bench.py: non-finite ELBO")
+
+    # ---- N > 1: the same steps with the other exchange modes (reported, not `value`) ------------------------------------
+    exchange_modes, repl_all = {}, None
+    if world > 1:
+        def timed_mode(red):
+            for _ in range(max(1, args.warmup)):
+                step(red)
+            fence()
+            t0m, ex = time.perf_counter(), 0.0
+            red.total_ms, red.n_calls = 0.0, 0
+            for _ in range(args.steps):
+                step(red)
+                ex += eng.timings()[0]["exchange"]
+            fence()
+            el = torch.tensor([time.perf_counter() - t0m], dtype=torch.float64, device="cuda")
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            exch = ex / args.steps if red.mode == "native" else red.total_ms / max(red.n_calls, 1)
+            return {"ms_per_step": 1e3 * float(el.item()) / args.steps, "exchange_ms_per_step": exch}
+        native_ms = cat_ms.get("exchange", 0.0) / args.steps
+        exchange_modes[reducer.mode] = {"ms_per_step": 1e3 * elapsed / args.steps,
+                                        "exchange_ms_per_step": native_ms if reducer.mode == "native" else
+                                        reducer.total_ms / max(reducer.n_calls, 1)}
+        for alt in ("native", "device"):
+            if alt in exchange_modes:
+                continue
+            try:
+                red_alt = hdist.StatsReducer(eng, device=local_rank, mode=alt)
+            except RuntimeError:            # not available on every rank (agreed collectively): nothing to time
+                continue
+            exchange_modes[alt] = timed_mode(red_alt)
+        gathered = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([cat_ms["mxm_algebra"] / args.steps], dtype=torch.float64, device="cuda"))
+        repl_all = [float(g.item()) for g in gathered]
 
     if rank == 0:
         pairs_rows = rows_rank * Q                               # (row, latent) pairs per step on this rank
@@ -206,6 +249,7 @@ def main():
             "roofline": {"kernel": "rowpass_gemm_kernel<1> (forward P~ = K^ C_q + fused row statistics)", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_measured_in_run": False,   # PMC passes need rocprofv3 around the process: profiles/
                          "launches": cat_n["forward_gemm"], "avg_launch_ms": cat_ms["forward_gemm"] / max(cat_n["forward_gemm"], 1)},
             # K_uf construction (the kernel the north-star singles out).  In the step it runs on the low-priority stream in
             # launches of 16384 rows interleaved with the latency-bound K_uu chain, so its in-step SPAN (in_step_*) includes
@@ -226,13 +270,20 @@ def main():
             "elbo": out["elbo"],
         }
         if reducer is not None:
-            line["allreduce_ms_per_step"] = reducer.total_ms / max(reducer.n_calls, 1)
-            line["allreduce_bytes"] = 8 * int(reducer.tensor.numel())
-            line["reducer_mode"] = reducer.mode        # "device" = RCCL in place on the engine's HBM buffer
+            # "native" = ncclAllReduce issued by the library on the engine's stream (device time, HIP events around pack +
+            # all-reduce + unpack); "device" = torch.distributed on the aliased wire buffer (host wall time incl. its syncs)
+            line["allreduce_ms_per_step"] = exchange_modes[reducer.mode]["exchange_ms_per_step"]
+            line["allreduce_bytes"] = 8 * int(eng.wire_buffer()[1])
+            line["reducer_mode"] = reducer.mode
+            line["exchange_modes_ms_per_step"] = exchange_modes
+            line["replicated_ms_per_rank"] = repl_all
         if world == 1 and not args.no_exact_zero_pass:
             line["exact_zero_windows"] = exact_zero_pass(args, prm, X, Y, N, M, Q, P, out)
         if world == 1 and not args.no_cpu_baseline:
             line.update(cpu_baselines(args, eng, prm, X, Y, N, M, Q, P))
+        if world == 1 and not args.no_other_configs:
+            eng.close()                                   # give the headline's 40 GB of row workspaces back first
+            line["other_configs"] = other_configs(args)
         print(json.dumps(line))
         sys.stdout.flush()
     if world > 1:
@@ -321,7 +372,16 @@ def cpu_baselines(args, eng, prm, X, Y, N, M, Q, P):
     blas, threads = _blas_info()
     prob = so.make_problem(SPECS, Q, M, P)
     ns2 = min(args.cpu_sample_rows, N)
-    ns1 = max(1, ns2 // 3)
+    ns1 = max(1, ns2 // 4)
+    reps_b = 3
+
+    # calibration: what this host's BLAS does on a plain dgemm with all threads (the yardstick for the port's GFLOP/s)
+    nd = 4096
+    ga, gb = np.random.RandomState(0).rand(nd, nd), np.random.RandomState(1).rand(nd, nd)
+    ga @ gb
+    t_dgemm, _ = _median_time(lambda: ga @ gb, 3)
+    host_dgemm_gflops = 2.0 * nd ** 3 / t_dgemm / 1e9
+    del ga, gb
 
     # NumPy's element-wise passes over the N x M blocks are single-threaded; to give the CPU all of its cores the rows are
     # cut into shards evaluated by a thread pool (NumPy and BLAS release the GIL; the statistic bundle is additive over
@@ -348,8 +408,8 @@ def cpu_baselines(args, eng, prm, X, Y, N, M, Q, P):
         return so.finish(prm, prob, u, total)
 
     run_b(ns1)                                                    # warm-up (BLAS thread pool, page faults)
-    t1, _ = _median_time(lambda: run_b(ns1), 5)
-    t2, ts2 = _median_time(lambda: run_b(ns2), 5)
+    t1, _ = _median_time(lambda: run_b(ns1), reps_b)
+    t2, ts2 = _median_time(lambda: run_b(ns2), reps_b)
     per_row = max((t2 - t1) / (T * (ns2 - ns1)), 0.0) if ns2 > ns1 else t2 / (T * ns2)
     fixed = max(t1 - per_row * T * ns1, 0.0)
     full = fixed + per_row * T * N
@@ -357,12 +417,16 @@ def cpu_baselines(args, eng, prm, X, Y, N, M, Q, P):
     res = {"cpu_baseline": {
         "value": 1.0 / full, "unit": "steps/s", "cores": min(ncpu, workers * blas_per_worker), "host_cores": ncpu, "kind": "port",
         "blas": blas, "threads": threads, "row_shard_workers": workers, "blas_threads_per_worker": blas_per_worker,
-        "gflops": flops_sample / t2 / 1e9, "fixed_s": fixed, "per_row_s": per_row, "reps": 5,
+        "gflops": flops_sample / t2 / 1e9, "host_dgemm_gflops": host_dgemm_gflops,
+        "frac_of_host_dgemm": flops_sample / t2 / 1e9 / host_dgemm_gflops,
+        "fixed_s": fixed, "per_row_s": per_row, "reps": reps_b,
         "sample": "baseline B: oracle.svmogp_oracle u_algebra + local_stats + finish (NumPy + %s, fp64; rows sharded over %d "
                   "worker threads x %d BLAS threads) on the first %d and %d of %d rows of each of the %d tasks, M=%d, Q=%d: "
-                  "median of 5 steps = %.2f s and %.2f s -> %.3f s independent of the rows + %.3e s per row; full step = "
-                  "fixed + per_row * %d rows" % (blas, workers, blas_per_worker, ns1, ns2, N, T, M, Q, t1, t2, fixed, per_row,
-                                                 T * N),
+                  "median of %d steps = %.2f s and %.2f s -> %.3f s independent of the rows + %.3e s per row; full step = "
+                  "fixed + per_row * %d rows.  The same host runs a plain %d^3 dgemm at %.0f GFLOP/s: the port reaches %.1f %% "
+                  "of that (NumPy element-wise passes and small per-shard GEMMs), so GPU/B overstates the hardware ratio"
+                  % (blas, workers, blas_per_worker, ns1, ns2, N, T, M, Q, reps_b, t1, t2, fixed, per_row, T * N, nd,
+                     host_dgemm_gflops, 100.0 * flops_sample / t2 / 1e9 / host_dgemm_gflops),
         "sample_seconds_per_step": t2}}
     # ---- parity at the headline M: the engine on exactly the sampled rows vs the oracle ------------------------------
     # (the engine of a 1-GPU run holds all rows; row_end restricts the evaluation to the sample)
@@ -393,7 +457,7 @@ def cpu_baselines(args, eng, prm, X, Y, N, M, Q, P):
     tA, _ = _median_time(lambda: run_a(c1, p1, X1, Y1, 50, 2), 3)
     lit["runs"].append({"config": "C1: T=3 [HetGaussian,Bernoulli,Categorical(3)], N_t=1000, M=50, Q=2", "seconds_per_step": tA,
                         "reps": 3})
-    budget, spent, nt = float(args.cpu_literal_budget), 0.0, 512
+    budget, spent, nt = float(args.cpu_literal_budget), 0.0, 2048
     while nt <= 8192 and N >= nt:
         Xa, Ya = [x[:nt] for x in X], [y[:nt] for y in Y]
         t0 = time.perf_counter()
@@ -401,15 +465,152 @@ def cpu_baselines(args, eng, prm, X, Y, N, M, Q, P):
         dt = time.perf_counter() - t0
         spent += dt
         lit["runs"].append({"config": "headline mix, N_t=%d, M=%d, Q=%d" % (nt, M, Q), "seconds_per_step": dt, "reps": 1})
-        if spent + 2.5 * dt > budget:                      # the next size costs 2-4x (O(N^2) terms on top of the M^3 ones)
+        if spent + 5.0 * dt > budget:                      # the next size (4x the rows) costs 4-5x (O(N^2) terms)
             break
-        nt *= 2
+        nt *= 4
     last = lit["runs"][-1]
     lit["value"] = 1.0 / last["seconds_per_step"]
     lit["unit"] = "steps/s at the size of the last run (O(N^2): not runnable at the full batch)"
     res["cpu_baseline_literal"] = lit
     pool.shutdown()
     return res
+
+
+def _dominant(cat):
+    k = max((k for k in cat if k not in ("total", "exchange")), key=lambda k: cat[k])
+    return k, cat[k]
+
+
+def _time_steps(eng, prm, steps, warmup=2, **kw):
+    """Wall ms per `elbo_grad` (synchronous at return) and the per-family kernel ms of the last `steps` calls."""
+    for _ in range(warmup):
+        out = eng.elbo_grad(**dict(prm, **kw))
+    t0, cat = time.perf_counter(), {}
+    for _ in range(steps):
+        out = eng.elbo_grad(**dict(prm, **kw))
+        for k, v in eng.timings()[0].items():
+            cat[k] = cat.get(k, 0.0) + v
+    dt = 1e3 * (time.perf_counter() - t0) / steps
+    return dt, {k: v / steps for k, v in cat.items()}, out
+
+
+def other_configs(args):
+    """The other BASELINE.json configurations on this GPU (a few steps each; synthetic inputs from the same generator,
+    BASELINE.md 3).  `flops_executed` = 3 * rows * Q * M^2 (forward 2, lower-tile Gram 1) + 20 * Q * M^3 (replicated algebra,
+    SURVEY 8d) per full-gradient step; `frac_of_peak` = that / ms_per_step / the FP64-MFMA peak."""
+    import numpy as np
+    from hetmogp_amd.engine import Engine
+    from hetmogp_amd.synthetic import make_case
+    K = max(1, args.other_steps)
+    res = []
+
+    def entry(name, rows, Q, M, ms, cat, out, **extra):
+        fl = 3.0 * rows * Q * M * M + 20.0 * Q * M ** 3
+        dk, dms = _dominant(cat)
+        e = {"workload": name, "ms_per_step": ms, "steps_per_s": 1e3 / ms, "flops_executed": fl,
+             "tflops": fl / ms / 1e9, "frac_of_peak": fl / ms / 1e9 / PEAK_FP64_MFMA_TFLOPS,
+             "dominant_kernel": dk, "dominant_kernel_ms": dms,
+             "kernel_ms_per_step": {k: round(v, 4) for k, v in cat.items()}, "elbo": out["elbo"], "steps": K}
+        e.update(extra)
+        res.append(e)
+
+    def run(name, specs, N, M, Q, P, seed, **extra):
+        prm, X, Y = make_case(specs, [N] * len(specs), M=M, Q=Q, P=P, seed=seed)
+        eng = Engine(specs, Q, M, P, reuse_outputs=True)
+        eng.set_data(X, Y)
+        ms, cat, out = _time_steps(eng, prm, K)
+        if not np.isfinite(out["elbo"]):
+            raise SystemExit("bench.py: non-finite ELBO in " + name)
+        return eng, prm, X, Y, ms, cat, out
+
+    # C1 -- the reference's own CPU-runnable case (README usage snippet's likelihood list)
+    c1 = [("HetGaussian", {}), ("Bernoulli", {}), ("Categorical", {"K": 3})]
+    eng, prm, X, Y, ms, cat, out = run("C1", c1, 1000, 50, 2, 1, 20260930)
+    entry("C1: T=3 [HetGaussian,Bernoulli,Categorical(3)] Df=5, N_t=1000, M=50, Q=2, full-batch ELBO+gradients", 3000, 2, 50,
+          ms, cat, out, note="launch-latency bound (about 40 kernel launches); compare cpu_baseline_literal.runs[0]")
+    eng.close()
+    # C2 -- the headline mix at M = 512
+    eng, prm, X, Y, ms, cat, out = run("C2", SPECS, 200000, 512, 3, 1, 20260931)
+    entry("C2: T=4 [Gaussian,Bernoulli,Poisson,Gamma] Df=5, N_t=200000, M=512, Q=3, full-batch ELBO+gradients", 800000, 3, 512,
+          ms, cat, out, forward_tflops=2.0 * 800000 * 3 * 512 ** 2 / cat["forward_gemm"] / 1e9,
+          gram_tflops=1.0 * 800000 * 3 * 512 ** 2 / cat["gram_gemm"] / 1e9)
+    eng.close()
+    # C3 -- SVI streaming: N_all = 1M rows per task, contiguous minibatches of 8192 rows per task and step
+    res.append(svi_config(args, K))
+    # C4 -- the share of ONE of 8 ranks: 125 000 of 1M rows of each of the 8 tasks, Q = 4, Df = 14
+    c4 = [("HetGaussian", {}), ("Categorical", {"K": 5}), ("Beta", {}), ("Exponential", {}), ("Gaussian", {"sigma": 0.5}),
+          ("Bernoulli", {}), ("Poisson", {}), ("Gamma", {})]
+    eng, prm, X, Y, ms, cat, out = run("C4", c4, 125000, 1024, 4, 1, 20260933)
+    entry("C4 (1/8 row share of one rank): T=8 [HetGaussian,Categorical(5),Beta,Exponential,Gaussian,Bernoulli,Poisson,Gamma] "
+          "Df=14, 125000 of N_t=1M rows per task, M=1024, Q=4", 8 * 125000, 4, 1024, ms, cat, out,
+          note="single-GPU measurement of a rank's share; the 8-GPU step adds one 16.9 MB all-reduce")
+    eng.close()
+    # C5 -- 2-D spatial, M = 2048, + predict_f on a 256 x 256 grid (SURVEY 8f row f2)
+    c5 = [("Categorical", {"K": 4}), ("Gaussian", {"sigma": 0.5})]
+    eng, prm, X, Y, ms, cat, out = run("C5", c5, 50000, 2048, 2, 2, 20260934)
+    g = np.stack(np.meshgrid(np.linspace(0, 1, 256), np.linspace(0, 1, 256), indexing="ij"), -1).reshape(-1, 2)
+    eng.predict_f(g)                                   # sizes the row workspaces for the grid
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eng.predict_f(g)
+    pms = 1e3 * (time.perf_counter() - t0) / 3
+    entry("C5: T=2 [Categorical(4),Gaussian] Df=4, P=2, N_t=50000, M=2048, Q=2, full-batch ELBO+gradients", 100000, 2, 2048,
+          ms, cat, out, predict_f_grid_ms=pms, predict_f_points=65536,
+          predict_f_tflops=1.0 * 65536 * 2 * 2048 ** 2 / pms / 1e9)   # triangular fold: n Q M^2 executed
+    eng.close()
+    return res
+
+
+def svi_config(args, K):
+    """BASELINE config C3 through the facade (SVMOGP.stochastic_grad, svmogp.py:188-199: next contiguous minibatch, 4 E-steps
+    then 1 M-step gating) with N_all = 1 000 000 rows per task resident in HBM, batch 8192 rows per task, q(u) and its
+    Adadelta state device-resident (hmogp_qu_adadelta).  Reports the wall time of one training iteration (new batch +
+    ELBO/gradients + optimiser update) and, separately, one full-gradient evaluation of a minibatch."""
+    import numpy as np
+    import hetmogp_amd as H
+    from hetmogp_amd.engine import Engine
+    from hetmogp_amd.kern import RBF
+    from hetmogp_amd.synthetic import make_case
+    N_all, B, M, Q, P = 1000000, 8192, 1024, 3, 1
+    prm, X, Y = make_case(SPECS, [N_all] * 4, M=M, Q=Q, P=P, seed=20260932)
+    # (a) one full-gradient evaluation of a minibatch (all groups) straight through the C ABI
+    eng = Engine(SPECS, Q, M, P, reuse_outputs=True)
+    eng.set_data(X, Y)
+    bs = [N_all / float(B)] * 4
+    ms, cat, out = _time_steps(eng, prm, K, row_begin=[123456] * 4, row_end=[123456 + B] * 4, batch_scale=bs)
+    eng.close()
+    fl = 3.0 * 4 * B * Q * M * M + 20.0 * Q * M ** 3
+    dk, dms = _dominant(cat)
+    # (b) the training loop
+    lik = H.HetLikelihood([H.Gaussian(sigma=0.5), H.Bernoulli(), H.Poisson(), H.Gamma()])
+    np.random.seed(1)
+    kern = [RBF(P, variance=float(prm["variance"][q]), lengthscale=float(prm["lengthscale"][q])) for q in range(Q)]
+    model = H.SVMOGP(X=X, Y=[y[:, None] for y in Y], Z=prm["Z"][:, :P].copy(), kern_list=kern, likelihood=lik,
+                     Y_metadata=lik.generate_metadata(), batch_size=B)
+    model[".*.lengthscale"].fix()       # as util.vem_algorithm does (util.py:284-331)
+    model[".*.kappa"].fix()
+    model.Z.fix()
+    model.stochastic = True
+    opt = model.device_adadelta(step_rate=0.005, momentum=0.9)
+    it = iter(opt)
+    for _ in range(6):
+        next(it)
+    n_it = 5 * max(2, K)                # whole 4xE + 1xM cycles
+    t0 = time.perf_counter()
+    for _ in range(n_it):
+        next(it)
+    it_ms = 1e3 * (time.perf_counter() - t0) / n_it
+    elbo = float(model._log_marginal_likelihood[0, 0])
+    it.close()
+    return {"workload": "C3: SVI streaming, T=4 [Gaussian,Bernoulli,Poisson,Gamma], N_all=1000000 rows/task resident, minibatch "
+                        "8192 rows/task/step, M=1024, Q=3",
+            "ms_per_step": ms, "steps_per_s": 1e3 / ms, "flops_executed": fl, "tflops": fl / ms / 1e9,
+            "frac_of_peak": fl / ms / 1e9 / PEAK_FP64_MFMA_TFLOPS, "dominant_kernel": dk, "dominant_kernel_ms": dms,
+            "kernel_ms_per_step": {k: round(v, 4) for k, v in cat.items()}, "elbo": out["elbo"], "steps": K,
+            "note": "ms_per_step = one full-gradient evaluation of a minibatch (all parameter groups); svi_* = the facade's "
+                    "training loop (4 E-steps with q(u) gradients only + 1 M-step, device-resident Adadelta)",
+            "svi_ms_per_iteration": it_ms, "svi_iterations_per_s": 1e3 / it_ms, "svi_iterations_timed": n_it,
+            "svi_elbo_last": elbo}
 
 
 if __name__ == "__main__":

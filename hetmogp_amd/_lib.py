@@ -10,11 +10,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhetmogp_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 # likelihood ids (class names of the reference's likelihoods/<name>.py)
 LIK_GAUSSIAN, LIK_BERNOULLI, LIK_HETGAUSSIAN, LIK_CATEGORICAL, LIK_POISSON, LIK_EXPONENTIAL, LIK_GAMMA, LIK_BETA = range(8)
 LIK_IDS_BY_NAME = dict(Gaussian=0, Bernoulli=1, HetGaussian=2, Categorical=3, Poisson=4, Exponential=5, Gamma=6, Beta=7)
-E_INVALID, E_NO_DEVICE, E_NOT_PD, E_SQI_UNSTABLE, E_STATE = -1, -2, -3, -4, -5
+E_INVALID, E_NO_DEVICE, E_NOT_PD, E_SQI_UNSTABLE, E_STATE, E_COMM = -1, -2, -3, -4, -5, -6
+NTIMINGS = 9
+COMM_ID_BYTES = 128
 FLAG_V_NEGATIVE = 1
 GROUP_QU, GROUP_HYPER, GROUP_Z, GROUP_ALL = 1, 2, 4, 7
 CFG_EXACT_ZERO_WINDOWS = 1
@@ -66,6 +68,12 @@ EXPORTS = {
     "hmogp_step_begin": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "hmogp_stats_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_int64_p]),
     "hmogp_step_finish": (C.c_int, [C.c_void_p, C.POINTER(Outputs)]),
+    "hmogp_comm_available": (C.c_int, []),
+    "hmogp_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "hmogp_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "hmogp_comm_destroy": (C.c_int, [C.c_void_p]),
+    "hmogp_comm_info": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),
+    "hmogp_step_exchange": (C.c_int, [C.c_void_p]),
     "hmogp_stats_read": (C.c_int, [C.c_void_p, c_double_p]),
     "hmogp_stats_write": (C.c_int, [C.c_void_p, c_double_p]),
     "hmogp_wire_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_int64_p]),

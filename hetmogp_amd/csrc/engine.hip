@@ -18,6 +18,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is resolved at run time (dlopen), see RcclApi
+
 #include "../../include/hetmogp_hip.h"
 #include "common.h"
 #include "post.h"
@@ -62,7 +65,8 @@ struct DevBuf {
 
 constexpr int FWD_PARTS = GEMM_MAX_FWD_PARTS;  // buffer sizing: partials of the fused row statistics per 128-column tile
 
-enum { CAT_TOTAL = 0, CAT_RBF, CAT_FWD, CAT_ROWSTATS, CAT_QUAD, CAT_GRAM, CAT_COLSTATS, CAT_MM, NCAT };
+enum { CAT_TOTAL = 0, CAT_RBF, CAT_FWD, CAT_ROWSTATS, CAT_QUAD, CAT_GRAM, CAT_COLSTATS, CAT_MM, CAT_EXCHANGE, NCAT };
+static_assert(NCAT == HMOGP_NTIMINGS, "hmogp_last_timings layout");
 
 struct Task {
   long long N = 0;
@@ -173,6 +177,51 @@ void jitchol_batched(const double* Kuu, double* Luu, int Q, int M, const double*
   jitchol_resolve(Kuu, Luu, Q, M, diag_mean, rung_io, d_info, d_jit, dscr, st, js);
 }
 
+// ------------------------------------------------------------------------------------ RCCL, resolved at run time
+// The exchange step of a row-sharded run is ONE ncclAllReduce on the engine's own stream.  librccl is not a
+// link-time dependency: a single-GPU user never needs it, and in a process that has already loaded a librccl.so.1 (PyTorch
+// bundles one) dlopen() by soname returns THAT copy, so the library owns exactly one RCCL per process.
+struct RcclApi {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+  decltype(&ncclCommInitRank) commInitRank = nullptr;
+  decltype(&ncclCommDestroy) commDestroy = nullptr;
+  decltype(&ncclAllReduce) allReduce = nullptr;
+  decltype(&ncclGetErrorString) getErrorString = nullptr;
+  std::string why;
+  bool ok() const { return lib != nullptr; }
+};
+RcclApi& rccl() {
+  static RcclApi api = [] {
+    RcclApi a;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      a.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (a.lib) break;
+      const char* e = dlerror();
+      a.why = e ? e : "dlopen failed";
+    }
+    if (!a.lib) return a;
+    a.getUniqueId = (decltype(a.getUniqueId))dlsym(a.lib, "ncclGetUniqueId");
+    a.commInitRank = (decltype(a.commInitRank))dlsym(a.lib, "ncclCommInitRank");
+    a.commDestroy = (decltype(a.commDestroy))dlsym(a.lib, "ncclCommDestroy");
+    a.allReduce = (decltype(a.allReduce))dlsym(a.lib, "ncclAllReduce");
+    a.getErrorString = (decltype(a.getErrorString))dlsym(a.lib, "ncclGetErrorString");
+    if (!a.getUniqueId || !a.commInitRank || !a.commDestroy || !a.allReduce || !a.getErrorString) {
+      a.why = "librccl is missing one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce";
+      a.lib = nullptr;
+    }
+    return a;
+  }();
+  return api;
+}
+#define RCCL_TRY(expr)                                                                               \
+  do {                                                                                               \
+    ncclResult_t _r = (expr);                                                                        \
+    if (_r != ncclSuccess)                                                                           \
+      throw EngineError{HMOGP_E_COMM, std::string("RCCL: ") + rccl().getErrorString(_r) + " in " #expr}; \
+  } while (0)
+
 }  // namespace
 
 // =================================================================================================== engine
@@ -262,7 +311,47 @@ struct hmogp_engine {
     pool_used = 0;
   }
 
+  // ---- native exchange step (hmogp_comm_*): one RCCL communicator per engine, collectives on the engine's stream ----
+  ncclComm_t comm = nullptr;
+  int comm_ranks = 1, comm_rank = 0;
+  bool exchanged = false;      // the bundle of the current step has been all-reduced
+
+  void comm_init(int nranks, int rank, const void* id) {
+    if (nranks < 1 || rank < 0 || rank >= nranks || !id) throw EngineError{HMOGP_E_INVALID, "bad communicator arguments"};
+    if (comm) throw EngineError{HMOGP_E_STATE, "this engine already has a communicator (hmogp_comm_destroy first)"};
+    RcclApi& r = rccl();
+    if (!r.ok()) throw EngineError{HMOGP_E_COMM, "librccl not available: " + r.why};
+    HIP_TRY(hipSetDevice(device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof uid);
+    wire.ensure(sizeof(double) * nwire, true);   // allocated (and zeroed) before the first collective, outside any timing
+    RCCL_TRY(r.commInitRank(&comm, nranks, uid, rank));
+    comm_ranks = nranks, comm_rank = rank;
+  }
+  void comm_destroy() {
+    if (!comm) return;
+    (void)hipSetDevice(device);
+    (void)hipStreamSynchronize(st);
+    (void)rccl().commDestroy(comm);
+    comm = nullptr, comm_ranks = 1, comm_rank = 0;
+  }
+  // pack -> ncclAllReduce(sum, fp64, in place on the wire buffer) -> unpack, all ENQUEUED on the engine's stream: no host
+  // synchronisation, no other library's stream.  The wire format holds the lower triangles of H_q only (12.7 MB instead
+  // of 25.2 MB at M = 1024, Q = 3).
+  void exchange() {
+    if (!began) throw EngineError{HMOGP_E_STATE, "exchange outside hmogp_step_begin .. hmogp_step_finish"};
+    if (!comm) throw EngineError{HMOGP_E_STATE, "no communicator (hmogp_comm_init)"};
+    if (exchanged) throw EngineError{HMOGP_E_STATE, "the bundle of this step has already been exchanged"};
+    HIP_TRY(hipSetDevice(device));
+    Scope sc(this, CAT_EXCHANGE, 3);
+    launch_wire_copy(stats.d(), wire.d(), NG, Q, M, per_q, 0, st);
+    RCCL_TRY(rccl().allReduce(wire.p, wire.p, (size_t)nwire, ncclDouble, ncclSum, comm, st));
+    launch_wire_copy(stats.d(), wire.d(), NG, Q, M, per_q, 1, st);
+    exchanged = true;
+  }
+
   ~hmogp_engine() {
+    comm_destroy();
     for (auto e : pool) (void)hipEventDestroy(e);
     for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_gsk, ev_zero, ev_info, ev_S, ev_join, ev_col, ev_kuf, ev_params, ev_ua})
       if (e) (void)hipEventDestroy(e);
@@ -797,7 +886,7 @@ struct hmogp_engine {
 
   void begin(const hmogp_params* p, bool sync = true) {
     HIP_TRY(hipSetDevice(device));
-    began = false;
+    began = false, exchanged = false;
     spans.clear();  // a failed evaluation may have left unmatched timing spans behind
     pool_used = 0;
     for (int c = 0; c < NCAT; ++c) ms[c] = 0.0, launches[c] = 0;
@@ -894,7 +983,7 @@ struct hmogp_engine {
     float f0 = 0.f, f1 = 0.f;
     (void)hipEventElapsedTime(&f0, ev_begin0, ev_begin1);
     (void)hipEventElapsedTime(&f1, ev_fin0, ev_fin1);
-    ms[CAT_TOTAL] = f0 + f1;
+    ms[CAT_TOTAL] = f0 + f1 + ms[CAT_EXCHANGE];
 
     // ---- host assembly (svmogp.py:101-166) -----------------------------------------------------------
     double KL = 0.0, ninf = 0.0;
@@ -1292,6 +1381,42 @@ int hmogp_wire_write(hmogp_handle h, const double* host) {
   });
 }
 
+int hmogp_comm_available(void) { return rccl().ok() ? 1 : 0; }
+
+int hmogp_comm_unique_id(void* id128) {
+  if (!id128) return HMOGP_E_INVALID;
+  return guarded(nullptr, [&] {
+    RcclApi& r = rccl();
+    if (!r.ok()) throw EngineError{HMOGP_E_COMM, "librccl not available: " + r.why};
+    static_assert(sizeof(ncclUniqueId) == HMOGP_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId uid;
+    RCCL_TRY(r.getUniqueId(&uid));
+    std::memcpy(id128, &uid, sizeof uid);
+  });
+}
+
+int hmogp_comm_init(hmogp_handle h, int32_t nranks, int32_t rank, const void* id128) {
+  if (!h) return HMOGP_E_INVALID;
+  return guarded(h, [&] { h->comm_init(nranks, rank, id128); });
+}
+
+int hmogp_comm_destroy(hmogp_handle h) {
+  if (!h) return HMOGP_E_INVALID;
+  return guarded(h, [&] { h->comm_destroy(); });
+}
+
+int hmogp_comm_info(hmogp_handle h, int32_t* nranks, int32_t* rank) {
+  if (!h) return HMOGP_E_INVALID;
+  if (nranks) *nranks = h->comm ? h->comm_ranks : 0;
+  if (rank) *rank = h->comm ? h->comm_rank : -1;
+  return HMOGP_OK;
+}
+
+int hmogp_step_exchange(hmogp_handle h) {
+  if (!h) return HMOGP_E_INVALID;
+  return guarded(h, [&] { h->exchange(); });
+}
+
 int hmogp_step_finish(hmogp_handle h, hmogp_outputs* out) {
   if (!h) return HMOGP_E_INVALID;
   return guarded(h, [&] { h->finish(out); });
@@ -1301,6 +1426,7 @@ int hmogp_elbo_grad(hmogp_handle h, const hmogp_params* p, hmogp_outputs* out) {
   if (!h) return HMOGP_E_INVALID;
   return guarded(h, [&] {
     h->begin(p, false);
+    if (h->comm) h->exchange();   // row-sharded run: the one collective of the path, enqueued between the two halves
     h->finish(out);
   });
 }
@@ -1341,11 +1467,11 @@ int hmogp_predict_f(hmogp_handle h, const double* Xnew, int64_t Nnew, double* m,
   return guarded(h, [&] { h->predict_f(Xnew, Nnew, m, v); });
 }
 
-int hmogp_last_timings(hmogp_handle h, double* out_ms8, int64_t* launches8) {
-  if (!h || !out_ms8) return HMOGP_E_INVALID;
+int hmogp_last_timings(hmogp_handle h, double* out_ms, int64_t* launches) {
+  if (!h || !out_ms) return HMOGP_E_INVALID;
   for (int c = 0; c < NCAT; ++c) {
-    out_ms8[c] = h->ms[c];
-    if (launches8) launches8[c] = h->launches[c];
+    out_ms[c] = h->ms[c];
+    if (launches) launches[c] = h->launches[c];
   }
   return HMOGP_OK;
 }

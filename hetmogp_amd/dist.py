@@ -40,72 +40,163 @@ class _DevicePtr(object):
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
 
 
+def _flag_device(group, device):
+    """Where a negotiation flag has to live for the group's backend (RCCL only moves device memory)."""
+    import torch
+    import torch.distributed as dist
+    return torch.device("cuda", int(device)) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
+def all_agree(ok, group=None, device=0):
+    """True on every rank iff `ok` is true on every rank (a MIN all-reduce of one flag).  Every mode decision of the
+    exchange step goes through this, so ranks can never end up in different modes."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_flag_device(group, device))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()) == 1)
+
+
+def attach_native_comm(engine, group=None, device=0):
+    """Give `engine` its own RCCL communicator spanning the ranks of `group` (hmogp_comm_init): rank 0 draws the
+    ncclUniqueId through the library, torch.distributed only carries those 128 bytes.  Collective; returns True on
+    every rank or False on every rank (then no rank keeps a communicator)."""
+    import torch
+    import torch.distributed as dist
+    from .engine import comm_available, comm_unique_id
+    from . import _lib
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if not all_agree(comm_available(), group, device):
+        return False
+    dev = _flag_device(group, device)
+    uid = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+    ok = True
+    if rank == 0:
+        try:
+            uid = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).to(dev)
+        except Exception:                                              # noqa: BLE001
+            ok = False
+    if not all_agree(ok, group, device):
+        return False
+    dist.broadcast(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    try:
+        engine.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
+    except Exception as exc:                                           # noqa: BLE001
+        import warnings
+        warnings.warn("hetmogp_amd.dist: hmogp_comm_init failed on rank %d (%s)" % (rank, exc))
+        ok = False
+    if not all_agree(ok, group, device):
+        if ok:
+            engine.comm_destroy()
+        return False
+    return True
+
+
 class StatsReducer(object):
-    """All-reduce of one engine's statistic bundle in its wire format (lower triangles of the symmetric H_q only:
-    12.7 MB instead of 25.2 MB at M=1024, Q=3).  mode "device": the engine's wire buffer is aliased as a torch CUDA
-    tensor and reduced in place by RCCL (no host copy); mode "host": read -> CPU all-reduce -> write back (gloo).
-    `last_ms` = wall milliseconds of the last exchange (pack + all-reduce + unpack), `n_calls` = exchanges so far."""
+    """The exchange step of one engine: sum-all-reduce of the statistic bundle in its wire format (lower triangles of the
+    symmetric H_q only: 12.7 MB instead of 25.2 MB at M=1024, Q=3).  Modes, best first:
+
+      "native"  the library's own RCCL communicator: pack -> ncclAllReduce -> unpack enqueued on the engine's stream, no
+                host synchronisation, nothing of torch on the data path (hmogp_comm_init / hmogp_step_exchange);
+      "device"  the engine's wire buffer aliased as a torch CUDA tensor, reduced in place by torch.distributed (RCCL);
+      "staged"  a torch-owned CUDA tensor filled through the host (two PCIe copies per step) -- slower, never wrong;
+      "host"    read -> CPU all-reduce -> write back (gloo; the CPU tests of this module).
+
+    `mode=None` picks the best mode EVERY rank can do: each candidate is probed locally and the outcome is agreed on with
+    a MIN all-reduce of a flag (`all_agree`), so ranks cannot diverge; nothing is decided by catching an exception inside
+    the step.  `last_ms` = host wall milliseconds of the last exchange (for "native": host time to enqueue it; the device
+    time is category "exchange" of Engine.timings()), `n_calls` = exchanges so far."""
 
     def __init__(self, engine, device=0, mode=None, group=None):
         import torch
         import torch.distributed as dist
         self.engine, self.group = engine, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        if mode is None:
-            mode = "device" if (dist.is_initialized() and dist.get_backend(group) == "nccl") else "host"
-        self.mode = mode
+        self.device = int(device)
         self.tensor = None
         self.last_ms, self.total_ms, self.n_calls = 0.0, 0.0, 0
-        self.device = int(device)
-        if mode == "device":
-            # The engine allocates with the system HIP runtime, torch carries its own copy: aliasing the engine's buffer as
-            # a torch tensor works on the configurations tested (see tests/test_dist_gpu.py), but it is not something either
-            # library promises.  If it is refused, fall back to "staged": a torch-owned CUDA tensor filled through the host
-            # (two 12.7 MB PCIe copies per step instead of none) -- slower, never wrong.
-            try:
-                ptr, n = engine.wire_buffer()
-                self.tensor = torch.as_tensor(_DevicePtr(ptr, n), device="cuda:%d" % self.device)
-                if self.tensor.device.index != self.device:
-                    raise RuntimeError("wire buffer aliased on %s, engine on device %d" % (self.tensor.device, self.device))
-            except Exception as exc:                                   # noqa: BLE001
-                import warnings
-                warnings.warn("StatsReducer: cannot alias the engine's wire buffer as a torch tensor (%s); using the "
-                              "host-staged RCCL path" % (exc,))
+        self.owns_comm = False
+        nccl = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        if mode is not None:
+            candidates = [mode]
+        elif not nccl:
+            candidates = ["host"]
+        else:       # (a single rank has nothing to exchange: no communicator is set up for it unless asked for)
+            candidates = ["native", "device", "staged"] if self.world > 1 else ["device", "staged"]
+        self.mode = None
+        for cand in candidates:
+            if cand == "native":
+                if not dist.is_initialized():
+                    raise RuntimeError("StatsReducer(mode='native') needs an initialised torch.distributed group to carry "
+                                       "the ncclUniqueId (or attach the communicator yourself: Engine.comm_init)")
+                have = engine.comm_info()[0] == self.world
+                if all_agree(have, group, self.device):                     # the caller attached one on every rank
+                    self.mode = "native"
+                elif not have and all_agree(engine.comm_info()[0] == 0, group, self.device) and \
+                        attach_native_comm(engine, group, self.device):
+                    self.owns_comm = True
+                    self.mode = "native"
+            elif cand == "device":
+                # The engine allocates with the HIP runtime of the process, torch wraps the pointer: aliasing works on the
+                # configurations tested (tests/test_dist_gpu.py) but neither library promises it -- probe it with a real
+                # all-reduce of the (zero-filled, not yet used) wire buffer and agree on the outcome.
+                ok = True
+                try:
+                    ptr, n = engine.wire_buffer()
+                    t = torch.as_tensor(_DevicePtr(ptr, n), device="cuda:%d" % self.device)
+                    if t.device.index != self.device:
+                        raise RuntimeError("wire buffer aliased on %s, engine on device %d" % (t.device, self.device))
+                except Exception:                                      # noqa: BLE001
+                    ok, t = False, None
+                if all_agree(ok, group, self.device):
+                    try:
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                        torch.cuda.synchronize(t.device)
+                    except Exception:                                  # noqa: BLE001
+                        ok = False
+                    if all_agree(ok, group, self.device):
+                        self.tensor, self.mode = t, "device"
+            elif cand == "staged":
+                _, n = engine.wire_buffer()
+                self.tensor = torch.empty(n, dtype=torch.float64, device="cuda:%d" % self.device)
                 self.mode = "staged"
-        if self.mode == "staged":
-            _, n = engine.wire_buffer()
-            self.tensor = torch.empty(n, dtype=torch.float64, device="cuda:%d" % self.device)
+            elif cand == "host":
+                self.mode = "host"
+            else:
+                raise ValueError("unknown StatsReducer mode %r" % (cand,))
+            if self.mode is not None:
+                break
+        if self.mode is None:
+            raise RuntimeError("StatsReducer: mode %r is not available on every rank" % (mode,))
+
+    def close(self):
+        if self.owns_comm:
+            self.engine.comm_destroy()
+            self.owns_comm = False
 
     def __call__(self):
-        if self.world == 1:
+        if self.world == 1 and self.mode != "native":     # (a one-rank communicator still runs its three launches: tests)
             return
         import time
         import torch
         import torch.distributed as dist
         t0 = time.perf_counter()
-        self.engine.wire_pack()                          # synchronous: the triangle is in the wire buffer at return
-        if self.mode == "device":
-            try:
+        if self.mode == "native":
+            self.engine.step_exchange()                  # enqueued on the engine's stream; step_finish follows on it
+        else:
+            self.engine.wire_pack()                      # synchronous: the triangle is in the wire buffer at return
+            if self.mode == "device":
                 dist.all_reduce(self.tensor, op=dist.ReduceOp.SUM, group=self.group)
                 torch.cuda.synchronize(self.tensor.device)   # the engine's own stream consumes it next
-            except RuntimeError as exc:
-                if self.n_calls > 0:
-                    raise
-                # refused on first use.  The decision must be the same on every rank: RCCL either accepts the aliased
-                # buffer everywhere or nowhere (same binaries, same driver), so no negotiation is attempted here.
-                import warnings
-                warnings.warn("StatsReducer: RCCL refused the aliased wire buffer (%s); using the host-staged RCCL path" % (exc,))
-                self.mode = "staged"
-                self.tensor = torch.empty(self.tensor.numel(), dtype=torch.float64, device="cuda:%d" % self.device)
-        if self.mode == "staged":
-            self.tensor.copy_(torch.from_numpy(self.engine.wire_read()))
-            dist.all_reduce(self.tensor, op=dist.ReduceOp.SUM, group=self.group)
-            self.engine.wire_write(self.tensor.cpu().numpy())
-        elif self.mode == "device":
-            pass
-        else:
-            self.engine.wire_write(all_reduce_host(self.engine.wire_read(), self.group))
-        self.engine.wire_unpack()
+            elif self.mode == "staged":
+                self.tensor.copy_(torch.from_numpy(self.engine.wire_read()))
+                dist.all_reduce(self.tensor, op=dist.ReduceOp.SUM, group=self.group)
+                self.engine.wire_write(self.tensor.cpu().numpy())
+            else:
+                self.engine.wire_write(all_reduce_host(self.engine.wire_read(), self.group))
+            self.engine.wire_unpack()
         self.last_ms = 1e3 * (time.perf_counter() - t0)
         self.total_ms += self.last_ms
         self.n_calls += 1
@@ -117,6 +208,11 @@ def sharded_elbo_grad(engine, reducer, rank, world, row_begin=None, row_end=None
     row_begin = [0] * T if row_begin is None else list(row_begin)
     row_end = list(engine.N) if row_end is None else list(row_end)
     rb, re = shard_ranges(row_begin, row_end, rank, world)
+    if reducer is not None and reducer.mode == "native":
+        # the library holds the communicator: one call = begin -> all-reduce on the engine's stream -> finish
+        reducer.n_calls += 1
+        return engine.elbo_grad(want_dL_dS=want_dL_dS, row_begin=rb, row_end=re, **params)
     engine.step_begin(row_begin=rb, row_end=re, **params)
-    reducer()
+    if reducer is not None:
+        reducer()
     return engine.step_finish(want_dL_dS=want_dL_dS)

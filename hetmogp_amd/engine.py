@@ -244,6 +244,28 @@ class Engine(object):
         host = _f64(host)
         check(lib.hmogp_wire_write(self._h, _p(host)), self._h)
 
+    # ------------------------------------------------------------------------------------------ native exchange
+    def comm_init(self, nranks, rank, unique_id):
+        """Attach an RCCL communicator (collective: every rank, same `unique_id` from `comm_unique_id()` of ONE rank).
+        From then on `elbo_grad` is the row-sharded step: begin -> in-library all-reduce -> finish."""
+        uid = bytes(unique_id)
+        if len(uid) != _lib.COMM_ID_BYTES:
+            raise ValueError("unique_id must be %d bytes" % _lib.COMM_ID_BYTES)
+        buf = C.create_string_buffer(uid, _lib.COMM_ID_BYTES)
+        check(lib.hmogp_comm_init(self._h, int(nranks), int(rank), buf), self._h)
+
+    def comm_destroy(self):
+        check(lib.hmogp_comm_destroy(self._h), self._h)
+
+    def comm_info(self):
+        n, r = C.c_int32(), C.c_int32()
+        check(lib.hmogp_comm_info(self._h, C.byref(n), C.byref(r)), self._h)
+        return n.value, r.value
+
+    def step_exchange(self):
+        """Enqueue pack -> RCCL all-reduce -> unpack on the engine's stream (between step_begin and step_finish)."""
+        check(lib.hmogp_step_exchange(self._h), self._h)
+
     def step_finish(self, want_dL_dS=False):
         c, o = self._outputs(want_dL_dS)
         check(lib.hmogp_step_finish(self._h, C.byref(c)), self._h)
@@ -308,12 +330,24 @@ class Engine(object):
         return out
 
     def timings(self):
-        ms = np.zeros(8)
-        n = np.zeros(8, dtype=np.int64)
+        ms = np.zeros(_lib.NTIMINGS)
+        n = np.zeros(_lib.NTIMINGS, dtype=np.int64)
         check(lib.hmogp_last_timings(self._h, _p(ms), n.ctypes.data_as(_lib.c_int64_p)), self._h)
         names = ["total", "rbf_cross_cov", "forward_gemm", "rowstats_combine", "quadrature", "gram_gemm", "colstats_reduce",
-                 "mxm_algebra"]
+                 "mxm_algebra", "exchange"]
         return dict(zip(names, ms.tolist())), dict(zip(names, n.tolist()))
+
+
+def comm_available():
+    """True if the library can load librccl (needed only for multi-GPU runs)."""
+    return bool(lib.hmogp_comm_available())
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library: call on ONE rank, broadcast the bytes, pass them to Engine.comm_init."""
+    buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+    check(lib.hmogp_comm_unique_id(buf))
+    return buf.raw
 
 
 # ---------------------------------------------------------------------------------------------- building blocks

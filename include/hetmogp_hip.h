@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMOGP_ABI_VERSION 3
+#define HMOGP_ABI_VERSION 4
 
 /* likelihood ids (class names of /root/reference/likelihoods/<name>.py) */
 enum {
@@ -53,7 +53,8 @@ enum {
   HMOGP_E_NOT_PD = -3,      /* LinAlgError("not positive definite, even with jitter.") / non-positive
                                diagonal -- GPy jitchol, reached from util.py:198                    */
   HMOGP_E_SQI_UNSTABLE = -4,/* ValueError("Sqi: Cholesky representation unstable") svmogp_inf.py:126 */
-  HMOGP_E_STATE = -5        /* call order violated (finish without begin, data not set, ...)        */
+  HMOGP_E_STATE = -5,       /* call order violated (finish without begin, data not set, ...)        */
+  HMOGP_E_COMM = -6         /* RCCL not loadable / a collective failed (hmogp_comm_*); ABI version 4  */
 };
 
 /* output flags (hmogp_outputs.flags) */
@@ -190,6 +191,30 @@ int hmogp_wire_unpack(hmogp_handle h);
 int hmogp_wire_read(hmogp_handle h, double* host /* [count] */);
 int hmogp_wire_write(hmogp_handle h, const double* host /* [count] */);
 
+/* ---- the exchange step inside the library (ABI version 4) --------------------------------------------------------
+ * The reference is single-process (no distributed code at all); the contract is SURVEY.md 8(e): rows are
+ * sharded over one process per GPU and the additive bundle is sum-all-reduced ONCE per step.  With a communicator
+ * attached the library does that itself: wire pack -> ncclAllReduce(sum, float64, in place) -> wire unpack, all enqueued
+ * on the engine's own HIP stream between the row pass and the replicated post-processing -- no host synchronisation, no
+ * second library's stream.  librccl is resolved at run time (dlopen by soname: in a process that already holds one,
+ * e.g. PyTorch's, that copy is used), so single-GPU users do not need it.
+ *   hmogp_comm_available   1 if librccl could be loaded, else 0 (no handle needed; never fails)
+ *   hmogp_comm_unique_id   ncclGetUniqueId: ONE rank calls it and distributes the HMOGP_COMM_ID_BYTES bytes out of band
+ *                          (torch.distributed broadcast, MPI, a file ...)
+ *   hmogp_comm_init        ncclCommInitRank on the engine's device; collective: every rank calls it with the same id
+ *   hmogp_comm_destroy     ncclCommDestroy (also done by hmogp_destroy)
+ *   hmogp_comm_info        nranks / rank of the attached communicator (0 / -1 without one)
+ * With a communicator, hmogp_elbo_grad IS the row-sharded step (begin -> exchange -> finish, one call, one final host
+ * synchronisation); hmogp_step_exchange is the middle part for callers that keep the three-call form.  The exchange is
+ * category [8] of hmogp_last_timings.  A communicator of ONE rank runs the same three launches (used by the tests).   */
+#define HMOGP_COMM_ID_BYTES 128
+int hmogp_comm_available(void);
+int hmogp_comm_unique_id(void* id /* [HMOGP_COMM_ID_BYTES] */);
+int hmogp_comm_init(hmogp_handle h, int32_t nranks, int32_t rank, const void* id /* [HMOGP_COMM_ID_BYTES] */);
+int hmogp_comm_destroy(hmogp_handle h);
+int hmogp_comm_info(hmogp_handle h, int32_t* nranks, int32_t* rank);
+int hmogp_step_exchange(hmogp_handle h);
+
 /* ---- posterior / prediction (consumers: svmogp.py:238-251, 280-306) --------------------------------- */
 /* woodbury_vector[q] = Kuu^-1 m_q  [Q, M];  woodbury_inv[q] = Kuu^-1 - Kuu^-1 S_q Kuu^-1  [Q, M, M]
  * of the parameters of the last evaluation.                                                             */
@@ -231,8 +256,11 @@ int hmogp_qu_adadelta(hmogp_handle h, int32_t phase, double step_rate, double mo
  * out[0] whole evaluation, [1] K_uf construction (rbf_cross_cov; + window kernels in the opt-in mode), [2] forward
  * N x M x M contraction incl. its fused row-statistics epilogue (ONE kernel per launch, all latents of a task chunk),
  * [3] combine of the row-statistic partials, [4] quadrature, [5] weighted Gram contraction (ONE kernel per launch),
- * [6] column statistics + slab reductions, [7] replicated M x M algebra.  launches[i] = kernel launches behind out[i].  */
-int hmogp_last_timings(hmogp_handle h, double* out_ms8, int64_t* launches8);
+ * [6] column statistics + slab reductions, [7] replicated M x M algebra, [8] the in-library exchange step (pack + RCCL
+ * all-reduce + unpack; 0 without a communicator).  launches[i] = kernel launches behind out[i].  Both arrays hold
+ * HMOGP_NTIMINGS entries (8 before ABI version 4).                                                                  */
+#define HMOGP_NTIMINGS 9
+int hmogp_last_timings(hmogp_handle h, double* out_ms /* [HMOGP_NTIMINGS] */, int64_t* launches /* [HMOGP_NTIMINGS] or NULL */);
 
 /* ---- inner protocol, debug / parity mode (small N only) ------------------------------------------------ */
 /* The raw gradient dictionary SVMOGPInf.inference returns (svmogp_inf.py:107, built at :130-171) for the LAST finished

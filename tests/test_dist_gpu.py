@@ -56,6 +56,53 @@ def test_bundle_aliases_as_torch_tensor_and_rccl_allreduce():
         dist.destroy_process_group()
 
 
+def test_native_exchange_one_rank_communicator():
+    """The in-library exchange (hmogp_comm_init -> hmogp_elbo_grad = begin -> pack -> ncclAllReduce -> unpack -> finish, all on
+    the engine's stream) with a communicator of ONE rank: the same three launches as on N ranks, results bit-identical to the
+    plain call; the three-call form (step_begin / step_exchange / step_finish) too."""
+    import torch
+    import torch.distributed as dist
+    from hetmogp_amd.engine import Engine, comm_available, comm_unique_id
+    from hetmogp_amd import dist as hd
+    from hetmogp_amd._lib import HetMOGPError
+    assert comm_available()
+    specs, prm, X, Y = _case()
+    e = Engine(specs, 3, 64, 1)
+    e.set_data(X, Y)
+    full = e.elbo_grad(**prm)
+    assert e.timings()[0]["exchange"] == 0.0 and e.comm_info() == (0, -1)
+    with pytest.raises(HetMOGPError):
+        e.step_begin(**prm)
+        e.step_exchange()                                                # no communicator yet
+    e.comm_init(1, 0, comm_unique_id())                                  # no torch.distributed needed at all
+    assert e.comm_info() == (1, 0)
+    out = e.elbo_grad(**prm)
+    ms, nl = e.timings()
+    assert ms["exchange"] > 0.0 and nl["exchange"] == 3
+    for k in ("elbo", "g_m_u", "g_L_u", "g_Z", "g_W", "g_variance", "g_lengthscale"):
+        assert np.array_equal(np.asarray(out[k]), np.asarray(full[k])), k
+    e.step_begin(**prm)
+    e.step_exchange()
+    with pytest.raises(HetMOGPError):
+        e.step_exchange()                                                # once per step
+    out3 = e.step_finish()
+    assert np.array_equal(out3["g_L_u"], full["g_L_u"]) and out3["elbo"] == full["elbo"]
+    e.comm_destroy()
+    assert e.comm_info() == (0, -1)
+    # the same through the reducer inside a (one-rank) torch.distributed group: the id travels by dist.broadcast
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        red = hd.StatsReducer(e, device=0, mode="native")
+        assert red.mode == "native" and red.owns_comm and e.comm_info() == (1, 0)
+        out = hd.sharded_elbo_grad(e, red, 0, 1, **prm)
+        assert np.array_equal(out["g_L_u"], full["g_L_u"]) and e.timings()[0]["exchange"] > 0.0
+        red.close()
+        assert e.comm_info() == (0, -1)
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
@@ -148,7 +195,7 @@ def test_facade_distributed_rows_match_reference_fixture():
 
 
 # ------------------------------------------------------------------------------------------------ >= 2 GPUs: real RCCL
-def _nccl_worker(rank, world, port, q):
+def _nccl_worker(rank, world, port, q, mode=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, ROOT)
@@ -164,11 +211,18 @@ def _nccl_worker(rank, world, port, q):
     rb, re = hd.shard_ranges([0] * len(X), [x.shape[0] for x in X], rank, world)
     e = Engine(specs, 3, 64, 1, device=rank)                                  # one GPU per rank
     e.set_data([x[b:e_] for x, b, e_ in zip(X, rb, re)], [y[b:e_] for y, b, e_ in zip(Y, rb, re)])   # only its rows
-    red = hd.StatsReducer(e, device=rank)
-    assert red.mode == "device" and red.tensor.device.index == rank
+    red = hd.StatsReducer(e, device=rank, mode=mode)
+    if mode in (None, "native"):                      # the default on >= 2 ranks: the library's own communicator
+        assert red.mode == "native" and e.comm_info() == (world, rank)
+    else:
+        assert red.mode == mode and red.tensor.device.index == rank
     e.step_begin(**prm)
     red()
     out = e.step_finish()
+    if red.mode == "native":                          # and the one-call form
+        out1 = e.elbo_grad(**prm)
+        assert out1["elbo"] == out["elbo"] and np.array_equal(out1["g_L_u"], out["g_L_u"])
+        assert e.timings()[0]["exchange"] > 0.0
     ones = torch.ones(1, dtype=torch.float64, device="cuda")
     dist.all_reduce(ones)
     dist.barrier()
@@ -177,9 +231,11 @@ def _nccl_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_two_gpus_rccl_match_single_rank():
+@pytest.mark.parametrize("mode", [None, "device", "staged"])
+def test_two_ranks_two_gpus_rccl_match_single_rank(mode):
     """BASELINE config C4's mechanism on real hardware: one process per GPU, rows sharded, the wire bundle all-reduced by
-    RCCL in place on engine-owned HBM (device-mode StatsReducer).  Skipped on boxes with a single GPU."""
+    RCCL -- by the library's own communicator on the engine's stream (default, "native"), in place on engine-owned HBM
+    through torch ("device"), or host-staged.  Skipped on boxes with a single GPU."""
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 GPUs (the nccl backend refuses two ranks on one device)")
@@ -192,7 +248,7 @@ def test_two_ranks_two_gpus_rccl_match_single_rank():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=500) for _ in procs]
@@ -222,7 +278,8 @@ def test_bench_self_launches_two_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and sum(line["rows_per_rank"]) == 4 * 20000
-    assert line["allreduce_ms_per_step"] > 0.0
+    assert line["allreduce_ms_per_step"] > 0.0 and line["reducer_mode"] == "native"
+    assert set(line["exchange_modes_ms_per_step"]) >= {"native", "device"}
 
 
 def _facade_nccl_worker(rank, world, port, q):
@@ -245,7 +302,7 @@ def _facade_nccl_worker(rank, world, port, q):
         return orig(self, *a, **kw)
     sv.SVMOGP.__init__ = patched
     model = build_model(g)
-    assert model._dist[1].mode == "device" and model._engine is not None
+    assert model._dist[1].mode == "native" and model._engine is not None
     model.parameters_changed()
     dist.barrier()
     dist.destroy_process_group()
@@ -254,8 +311,8 @@ def _facade_nccl_worker(rank, world, port, q):
 
 @pytest.mark.timeout(600)
 def test_facade_distributed_two_gpus_rccl_matches_reference_fixture():
-    """SVMOGP(distributed=True) on two ranks, one GPU each, backend nccl (device defaults to LOCAL_RANK, device-mode
-    reducer on the wire buffer): every rank reproduces the reference's parameters_changed() fixture.  Skipped on 1-GPU boxes."""
+    """SVMOGP(distributed=True) on two ranks, one GPU each, backend nccl (device defaults to LOCAL_RANK, the library's
+    own RCCL communicator): every rank reproduces the reference's parameters_changed() fixture.  Skipped on 1-GPU boxes."""
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 GPUs")
