@@ -137,6 +137,7 @@ class SVMOGP(object):
         import os
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0")) if distributed else 0
+        self._device = int(device)
         self.name = name
         self.gradients_of_fixed = bool(gradients_of_fixed)
         self.batch_size = batch_size
@@ -435,12 +436,18 @@ class SVMOGP(object):
                                for q in range(self.num_latent_funcs)]
         return self.posteriors
 
-    def _raw_predict(self, Xnew, latent_function_ind=None, full_cov=False, kern=None):
-        """svmogp.py:219-253: posterior of the latent u_q at Xnew (mean, |variance|)."""
+    REFERENCE_ROUTE_MAX_ROWS = 8192      # `_raw_predict_f` factorises the N x N K_ff of a task's training inputs
+
+    def _raw_predict(self, Xnew, latent_function_ind=None, full_cov=False, kern=None, route="default"):
+        """svmogp.py:219-253: posterior of the latent u_q at Xnew (mean, |variance|).  route="reference" reproduces
+        `kern.K(self.Z, Xnew)` under GPy's input slicing, which hands the kernel the FIRST P columns of the M x (Q P)
+        inducing array -- latent 0's block whatever q is; the default uses block q (the two agree while Z is the tiled
+        initialisation of svmogp.py:52, i.e. always when Z is fixed)."""
         q = 0 if latent_function_ind is None else latent_function_ind
         kern = self.kern_list[q] if kern is None else kern
         post = self._ensure_posteriors()[q]
-        Zq = self.Z.values[:, q * self.Xdim:(q + 1) * self.Xdim]
+        b = 0 if route == "reference" else q
+        Zq = self.Z.values[:, b * self.Xdim:(b + 1) * self.Xdim]
         Kx = kern.K(Zq, np.asarray(Xnew, dtype=float).reshape(-1, self.Xdim))
         mu = Kx.T @ post.woodbury_vector
         if full_cov:
@@ -461,16 +468,83 @@ class SVMOGP(object):
         self._refresh()
         return self._engine.predict_f(np.asarray(Xnew, dtype=float).reshape(-1, self.Xdim))
 
-    def predictive(self, Xpred):
-        """svmogp.py:333-351: predictive mean / variance of every output at Xpred[t].  The reference routes q(f) through
-        `_raw_predict_f` (an O(N^3) regression on q(f) at ALL training inputs, svmogp.py:255-278); here q(f_d)(Xpred) comes
-        straight from q(u) (`calculate_q_f` at the new inputs, the `predictive_new` semantics) on the device."""
+    def _raw_predict_f(self, Xnew, output_function_ind=None, kern_list=None):
+        """svmogp.py:255-278, the route the reference's `predictive` / `negative_log_predictive` take: q(f_d) at the TRAINING
+        inputs of d's task (mean m_fd, full covariance S_fd, svmogp_inf.py:43-51) becomes a GPy `Posterior` -- an N x N
+        jitchol of K_ff -- and is regressed onto Xnew:  mu = K_x^T K_ff^-1 m_fd,  var = |diag K_xx - diag(K_x^T K_ff^-1 (K_ff -
+        S_fd) K_ff^-1 K_x)|.  O(N^3) time and O(N^2) memory, so it is limited to REFERENCE_ROUTE_MAX_ROWS training rows per
+        task.  It is a DIFFERENT estimator than `predictive_new` / `predict_f` (calculate_q_f at the new inputs): the two
+        agree only where q(f) at the training inputs determines q(f) at Xnew.  All products, the factorisation (GPy's
+        jitter ladder) and the covariances run on the device through the C-ABI building blocks; with
+        K_ff - S_fd = sum_q W_q[d]^2 K^_q (Kuu^-1 - Kuu^-1 S_q Kuu^-1) K^_q^T nothing but `woodbury_inv` of q(u) is needed."""
+        from .engine import rbf_cross_cov, gemm, jitchol_inv
+        d = 0 if output_function_ind is None else output_function_ind
+        kern_list = self.kern_list if kern_list is None else kern_list
+        t = int(self.Y_metadata["function_index"].flatten()[d])
+        X = self.Xmulti_all[t]
+        N, P = X.shape[0], self.Xdim
+        if N > self.REFERENCE_ROUTE_MAX_ROWS:
+            raise ValueError("_raw_predict_f factorises the %d x %d K_ff of task %d (svmogp.py:255-278): limited to %d rows; use "
+                             "predict_f / predictive_new / predictive(route='default')" % (N, N, t, self.REFERENCE_ROUTE_MAX_ROWS))
+        Xnew = np.asarray(Xnew, dtype=float).reshape(-1, P)
+        posts = self._ensure_posteriors()
+        dev = self._engine_device()
+        Kff, Dm, m = np.zeros((N, N)), np.zeros((N, N)), np.zeros((N, 1))
+        Kx, Kxx = np.zeros((N, Xnew.shape[0])), np.zeros(Xnew.shape[0])
+        for q, (kern, B) in enumerate(zip(kern_list, self.B_list)):
+            w = float(np.ravel(B.W.values)[d])
+            Bdd = w * w + float(np.ravel(B.kappa.values)[d])
+            var, ell = float(kern.variance[0]), float(kern.lengthscale[0])
+            Zq = self.Z.values[:, q * P:(q + 1) * P]
+            Kq = rbf_cross_cov(X, Zq, var, ell, device=dev)                        # k_q(X, Z_q), GPy rounding order
+            Kff += Bdd * rbf_cross_cov(X, X, var, ell, device=dev)                 # util.py:166-179
+            m += w * gemm(Kq, posts[q].woodbury_vector, device=dev)                # m_fd = sum_q w K^ Kuu^-1 m_q
+            Dm += (w * w) * gemm(gemm(Kq, posts[q].woodbury_inv, device=dev), Kq, transB=True, device=dev)
+            Kx += Bdd * rbf_cross_cov(X, Xnew, var, ell, device=dev)
+            Kxx += Bdd * var
+        _, Kffi, rung = jitchol_inv(Kff[None], device=dev)                         # GPy Posterior.K_chol = jitchol(K)
+        self.last_predict_rung = rung[0]
+        wv = gemm(Kffi[0], m, device=dev)                                          # woodbury_vector = K_ff^-1 m_fd
+        wi = gemm(gemm(Kffi[0], Dm, device=dev), Kffi[0], device=dev)              # woodbury_inv
+        mu = gemm(Kx, wv, transA=True, device=dev)
+        var = (Kxx - np.sum(gemm(wi, Kx, device=dev) * Kx, 0))[:, None]
+        return mu, np.abs(var)
+
+    _raw_predict_stochastic = _raw_predict_f                                       # svmogp.py:308-331: the same code
+
+    def _engine_device(self):
+        return getattr(self, "_device", 0)
+
+    def _predict_route(self, X_t, t, route):
+        """(m, |v|) of the functions of task t at X_t: [N, dim_f(t)]."""
+        cols = [d for d in range(self.num_output_funcs) if self.Y_metadata["function_index"].flatten()[d] == t]
+        if route == "reference":
+            mv = [self._raw_predict_f(X_t, output_function_ind=d) for d in cols]
+            return np.hstack([a for a, _ in mv]), np.hstack([b for _, b in mv])
+        if route != "default":
+            raise ValueError("route must be 'default' or 'reference'")
+        m, v = self.predict_f(X_t)
+        return m[:, cols], np.abs(v[:, cols])
+
+    def predictive(self, Xpred, route="default"):
+        """svmogp.py:333-351: predictive mean / variance of every output at Xpred[t].
+
+        route="default"    q(f_d)(Xpred) straight from q(u) -- `calculate_q_f` at the new inputs, i.e. the reference's OWN
+                           `predictive_new` semantics (svmogp.py:280-306) -- on the device, any N.  NOT what the reference's
+                           `predictive` returns: that one goes through `_raw_predict_f`.
+        route="reference"  the reference's route: `_raw_predict_f` per function (O(N^3) in the training rows of the task,
+                           limited to REFERENCE_ROUTE_MAX_ROWS), then `<likelihood>.predictive` with the Gauss-Hermite rule
+                           a trained reference model reads (Gamma / Beta: the cached 10-point rule, GPy `_gh_points` quirk)."""
         m_F, v_F = [], []
-        for t, lik in enumerate(self.likelihood.likelihoods_list):
-            m, v = self.predict_f(Xpred[t])
-            cols = [d for d in range(self.num_output_funcs) if self.Y_metadata["function_index"].flatten()[d] == t]
-            m_F.append(m[:, cols])
-            v_F.append(np.abs(v[:, cols]))
+        for t in range(len(self.likelihood.likelihoods_list)):
+            m, v = self._predict_route(Xpred[t], t, route)
+            m_F.append(m)
+            v_F.append(v)
+        if route == "reference":
+            from .engine import predictive as lik_predictive
+            out = [lik_predictive(l.name, m_F[t], v_F[t], gh_T=10 if l.name in ("Gamma", "Beta") else 0, **l.kwargs())
+                   for t, l in enumerate(self.likelihood.likelihoods_list)]
+            return [o[0] for o in out], [o[1] for o in out]
         return self.likelihood.predictive(m_F, v_F, self.Y_metadata)
 
     def natural_gradient_step(self, gamma=1.0):
@@ -483,15 +557,14 @@ class SVMOGP(object):
         self.parameters_changed()
         return self
 
-    def negative_log_predictive(self, Xtest, Ytest, num_samples=1000, seed=0):
-        """svmogp.py:353-370 (q(f) at the test inputs from `predict_f`, see `predictive`)."""
-        f_index = self.Y_metadata["function_index"].flatten()
+    def negative_log_predictive(self, Xtest, Ytest, num_samples=1000, seed=0, route="default"):
+        """svmogp.py:353-370.  q(f) at the test inputs: route="default" from `predict_f`, route="reference" through
+        `_raw_predict_f` as the reference does (see `predictive`)."""
         mu, vv = [], []
         for t in range(len(self.Ymulti_all)):
-            m, v = self.predict_f(Xtest[t])
-            cols = [d for d in range(self.num_output_funcs) if f_index[d] == t]
-            mu.append(m[:, cols])
-            vv.append(np.abs(v[:, cols]))
+            m, v = self._predict_route(Xtest[t], t, route)
+            mu.append(m)
+            vv.append(v)
         return self.likelihood.negative_log_predictive(Ytest, mu, vv, Y_metadata=self.Y_metadata, num_samples=num_samples,
                                                        seed=seed)
 

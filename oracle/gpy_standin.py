@@ -219,9 +219,19 @@ class RBF(object):
         r2 = np.clip(r2, 0, np.inf)
         return np.sqrt(r2)
 
+    def _slice(self, X):
+        """GPy's KernCallsViaSlicerMeta: every public kernel call sees X[:, active_dims] with active_dims =
+        arange(input_dim) (Kern.__init__ default).  Only matters where the reference hands a kernel MORE columns than
+        input_dim: `kern.K(self.Z, Xnew)` at svmogp.py:240 passes the whole M x (Q*P) inducing array, of which GPy keeps
+        the first P columns (the block of latent 0) whatever q is.  Restated from GPy 1.9.5, not in the tree."""
+        X = np.asarray(X)
+        return X[:, :self.input_dim] if X.ndim == 2 and X.shape[1] > self.input_dim else X
+
     def K(self, X, X2=None):
+        X = self._slice(X)
         if X2 is None:
             X2 = X
+        X2 = self._slice(X2)
         r = self._unscaled_dist(X, X2) / self.lengthscale
         return self.variance * np.exp(-0.5 * r ** 2)
 
@@ -315,10 +325,39 @@ class Coregionalize(object):
 
 
 class Posterior(object):
-    """Passive container (the real one is lazy; the ELBO path never reads it)."""
+    """GPy 1.9.5 `inference.latent_function_inference.posterior.Posterior` as the reference uses it (constructed from
+    mean / cov / K at svmogp_inf.py:48-51,181; read lazily by the predict methods, svmogp.py:238-251,267-276): nothing is
+    computed until a property is asked for.  `K_chol = jitchol(K)`; `woodbury_vector = dpotrs(K_chol, mean - prior_mean)`
+    (= K^-1 mean); `woodbury_inv[:, :, i] = K^-1 (K - cov)[:, :, i] K^-1` by two dpotrs per slice of the
+    `atleast_3d` difference -- so it is (N, N, 1) for a 2-D covariance.  Restated from GPy 1.9.5."""
+
+    rungs = None     # make_golden hooks a list in here to record the jitter rung every K_chol took
 
     def __init__(self, mean=None, cov=None, K=None, prior_mean=0, **kw):
         self.mean, self.covariance, self._K, self.prior_mean = mean, cov, K, prior_mean
+        self._K_chol = self._woodbury_vector = self._woodbury_inv = None
+
+    @property
+    def K_chol(self):
+        if self._K_chol is None:
+            self._K_chol = jitchol(self._K, _record=Posterior.rungs)
+        return self._K_chol
+
+    @property
+    def woodbury_vector(self):
+        if self._woodbury_vector is None:
+            self._woodbury_vector, _ = dpotrs(self.K_chol, self.mean - self.prior_mean)
+        return self._woodbury_vector
+
+    @property
+    def woodbury_inv(self):
+        if self._woodbury_inv is None:
+            B = np.atleast_3d(self._K) - np.atleast_3d(self.covariance)
+            self._woodbury_inv = np.empty_like(B)
+            for i in range(B.shape[-1]):
+                tmp, _ = dpotrs(self.K_chol, B[:, :, i])
+                self._woodbury_inv[:, :, i], _ = dpotrs(self.K_chol, tmp.T)
+        return self._woodbury_inv
 
 
 class LatentFunctionInference(object):

@@ -14,6 +14,11 @@ Fixture families:
   model_<case>.npz  G6  assembled parameter gradients from the reference's own
                         SVMOGP.parameters_changed (svmogp.py:85-166) run over the stand-in's
                         RESTATED GPy RBF gradient formulas ("GPy-unpinned").
+  mpred_<case>.npz  f2  model-level prediction through the reference's own SVMOGP methods (svmogp.py:219-351):
+                        predictive_new, _raw_predict_f, _raw_predict_stochastic, _raw_predict, predictive, at tiny N
+                        (the _raw_predict_f route factorises the N x N K_ff of the TRAINING inputs).  Relies on the
+                        stand-in's restated GPy `Posterior` (lazy woodbury_vector / woodbury_inv) and kernel input
+                        slicing ("GPy-unpinned"); the inputs are spaced so that no K_ff needs jitter (rungs recorded).
 """
 import json
 import os
@@ -330,6 +335,76 @@ def gen_model(stand, util, hl, svmogp, liks):
         print("model", tag, "ELBO", float(model.log_likelihood()))
 
 
+MPRED_CASES = [
+    # tag, base inference case (likelihood mix, M, Q, P, c), rows per task, new points per task
+    ("config2", 2, [14, 11, 12, 9], 7),
+    ("config1", 1, [13, 10, 12], 6),
+    ("config5_2d", 5, [16, 20], 9),
+]
+
+
+def spaced_inputs(rng, n, P, shift=0.0):
+    """n inputs in the unit cube whose mutual distances stay near the grid spacing: the N x N K_ff blocks the predict
+    routes factorise then need no jitter, so the fixture does not depend on a borderline ladder decision."""
+    if P == 1:
+        return (((np.arange(n) + 0.5 + shift) / n + 0.25 / n * (rng.rand(n) - 0.5)) % 1.0)[:, None]
+    g = int(np.ceil(n ** (1.0 / P)))
+    cells = np.stack(np.meshgrid(*[np.arange(g)] * P, indexing="ij"), -1).reshape(-1, P)[:n]
+    return ((cells + 0.5 + shift) / g + 0.25 / g * (rng.rand(n, P) - 0.5)) % 1.0
+
+
+def gen_model_predict(stand, util, hl, svmogp, liks):
+    for k, (tag, base, Ns, n_new) in enumerate(MPRED_CASES):
+        (_, specs, _, M, Q, P, cs, _, _) = INF_CASES[base]
+        rng = np.random.RandomState(600 + k)
+        c = build_case(rng, specs, Ns, M, Q, P, cs, False, False)
+        T = len(specs)
+        c["X"] = [spaced_inputs(rng, n, P) for n in Ns]
+        if P == 1:
+            c["X"] = [np.sort(x, axis=0) for x in c["X"]]
+        Xnew = [spaced_inputs(rng, n_new, P, shift=0.37) for _ in range(T)]
+        likelihood = hl.HetLikelihood([make_lik(liks, s) for s in specs])
+        Y_metadata = likelihood.generate_metadata()
+        Df = likelihood.num_output_functions(Y_metadata)
+        kern_list = util.latent_functions_prior(Q, lenghtscale=c["lengthscale"], variance=c["variance"], input_dim=P)
+        W_list = [c["W"][q][:, None].copy() for q in range(Q)]
+        np.random.seed(4321 + k)
+        import random
+        random.seed(77 + k)
+        model = svmogp.SVMOGP(X=c["X"], Y=c["Y"], Z=c["Z"][:, :P].copy(), kern_list=kern_list, likelihood=likelihood,
+                              Y_metadata=Y_metadata, batch_size=None, W_list=W_list)
+        model.q_u_means[...] = c["m_u"]
+        model.q_u_chols[...] = c["L_flat"]
+        model.Z[...] = c["Z"]                      # blocks differ per latent: _raw_predict's use of block 0 is visible
+        model.parameters_changed()
+        f_index = Y_metadata["function_index"].flatten()
+        rungs = []
+        stand.Posterior.rungs = rungs
+        out = {}
+        try:
+            for d in range(Df):
+                xn = Xnew[f_index[d]]
+                out["pn_m_%d" % d], out["pn_v_%d" % d] = model.predictive_new(xn, output_function_ind=d)
+                out["rf_m_%d" % d], out["rf_v_%d" % d] = model._raw_predict_f(xn, output_function_ind=d)
+            out["rs_m_0"], out["rs_v_0"] = model._raw_predict_stochastic(Xnew[f_index[0]], output_function_ind=0)
+            for q in range(Q):
+                out["ru_m_%d" % q], out["ru_v_%d" % q] = model._raw_predict(Xnew[0], latent_function_ind=q)
+            pm, pv = model.predictive(Xnew)
+        finally:
+            stand.Posterior.rungs = None
+        for t in range(T):
+            out["pm_%d" % t], out["pv_%d" % t] = np.asarray(pm[t]), np.asarray(pv[t])
+            out["X_%d" % t], out["Y_%d" % t], out["Xnew_%d" % t] = c["X"][t], c["Y"][t], Xnew[t]
+        np.savez_compressed(
+            os.path.join(OUT, "mpred_%s.npz" % tag), spec=json.dumps(specs), T=T, M=M, Q=Q, P=P, Df=Df, Z=c["Z"],
+            variance=c["variance"], lengthscale=c["lengthscale"], W=c["W"], kappa=np.zeros((Q, Df)), m_u=c["m_u"],
+            L_flat=c["L_flat"], f_index=f_index, d_index=Y_metadata["d_index"].flatten(), rungs=np.array(rungs),
+            batch_scale=np.ones(T),
+            elbo=np.asarray(model.log_likelihood()).reshape(1, 1), **out)
+        print("mpred", tag, "ELBO", float(model.log_likelihood()), "K_chol rungs", sorted(set(rungs)),
+              "max |predictive_new - raw_predict_f| d=0", float(np.max(np.abs(out["pn_m_0"] - out["rf_m_0"]))))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     stand, inf, util, hl, svmogp, liks = _import_reference()
@@ -338,6 +413,7 @@ def main():
     gen_cov(stand, util)
     gen_inference(stand, inf, util, hl, liks)
     gen_model(stand, util, hl, svmogp, liks)
+    gen_model_predict(stand, util, hl, svmogp, liks)
 
 
 if __name__ == "__main__":

@@ -456,6 +456,104 @@ def elbo_grad_literal(prm, prob, X, Y, batch_scale=None, forced_rungs=None, full
     return out
 
 
+# ===================================================================== prediction
+def gpy_posterior(mean, cov, K, forced_rung=None):
+    """GPy 1.9.5 `Posterior(mean, cov, K)` read through its lazy properties (SURVEY appendix A): K_chol = jitchol(K);
+    woodbury_vector = dpotrs(K_chol, mean) = K^-1 mean; woodbury_inv = K^-1 (K - cov) K^-1 by two dpotrs.  Returns
+    (woodbury_vector (N,1), woodbury_inv (N,N), rung)."""
+    Kc, rung = jitchol(K, forced_rung=forced_rung)
+    Kc = np.asfortranarray(Kc)
+    wv, _ = lapack.dpotrs(Kc, np.asarray(mean, float).reshape(-1, 1), lower=1)
+    tmp, _ = lapack.dpotrs(Kc, K - cov, lower=1)
+    wi, _ = lapack.dpotrs(Kc, tmp.T, lower=1)
+    return wv, wi, rung
+
+
+def q_f_full_literal(prm, prob, X, d, Luu):
+    """What inference() hands `Posterior` for output function d (svmogp_inf.py:43-51 with calculate_q_f :186-225):
+    mean m_fd (N,), the FULL covariance S_fd (N,N) (:219) and K_ff = sum_q B_q[d,d] k_q(X,X) (util.py:166-179)."""
+    Q, M, P = prob["Q"], prob["M"], prob["P"]
+    N = X.shape[0]
+    Kff = np.zeros((N, N))
+    m_fd = np.zeros(N)
+    S_fd = np.zeros((N, N))
+    for q in range(Q):
+        Zq = prm["Z"][:, q * P:(q + 1) * P]
+        Kq = prm["W"][q, d] * rbf_K(X, Zq, prm["variance"][q], prm["lengthscale"][q])
+        Kff += (prm["W"][q, d] ** 2 + prm["kappa"][q, d]) * rbf_K(X, X, prm["variance"][q], prm["lengthscale"][q])
+        L_q = flat_to_tril(prm["L_flat"][:, q], M)
+        R, _ = lapack.dpotrs(np.asfortranarray(Luu[q]), Kq.T, lower=1)
+        m_fd += R.T @ prm["m_u"][:, q]
+        S_fd += (R.T @ (L_q @ L_q.T)) @ R - Kq @ R
+    return m_fd, S_fd + Kff, Kff
+
+
+def _predict_from_posterior(prm, prob, Xbase, Xnew, d, wv, wi):
+    """The common tail of _raw_predict_f / predictive_new / _raw_predict_stochastic (svmogp.py:267-278)."""
+    Kx = np.zeros((Xbase.shape[0], Xnew.shape[0]))
+    Kxx = np.zeros(Xnew.shape[0])
+    for q in range(prob["Q"]):
+        Bdd = prm["W"][q, d] ** 2 + prm["kappa"][q, d]
+        Kx += Bdd * rbf_K(Xbase, Xnew, prm["variance"][q], prm["lengthscale"][q])
+        Kxx += Bdd * np.diag(rbf_K(Xnew, Xnew, prm["variance"][q], prm["lengthscale"][q]))
+    mu = Kx.T @ wv
+    var = (Kxx - np.sum((wi @ Kx) * Kx, 0))[:, None]
+    return mu, np.abs(var)
+
+
+def raw_predict_f_literal(prm, prob, X, Xnew, d, forced_rungs=None):
+    """SVMOGP._raw_predict_f (svmogp.py:255-278): q(f_d) at the TRAINING inputs of d's task is turned into a GPy Posterior
+    (an N x N factorisation of K_ff) and regressed onto Xnew.  This is the route the reference's `predictive` and
+    `negative_log_predictive` take (:333-370); it is NOT the same estimator as `predictive_new` / calculate_q_f at Xnew."""
+    _, Luu, _, _ = latent_covariances(prm, prob, forced_rungs)
+    Xt = X[prob["f_index"][d]]
+    m, S, Kff = q_f_full_literal(prm, prob, Xt, d, Luu)
+    wv, wi, _ = gpy_posterior(m, S, Kff)
+    return _predict_from_posterior(prm, prob, Xt, Xnew, d, wv, wi)
+
+
+def predictive_new_literal(prm, prob, Xnew, d, forced_rungs=None):
+    """SVMOGP.predictive_new (svmogp.py:280-306): the Posterior is built AT Xnew, so up to the N_new x N_new solve the
+    result is (m_fd(Xnew), |v_fd(Xnew)|) of calculate_q_f."""
+    _, Luu, _, _ = latent_covariances(prm, prob, forced_rungs)
+    m, S, Kff = q_f_full_literal(prm, prob, Xnew, d, Luu)
+    wv, wi, _ = gpy_posterior(m, S, Kff)
+    return _predict_from_posterior(prm, prob, Xnew, Xnew, d, wv, wi)
+
+
+def raw_predict_u_literal(prm, prob, Xnew, q, block0=True, forced_rungs=None):
+    """SVMOGP._raw_predict (svmogp.py:219-253), diagonal variance: the latent u_q at Xnew from posteriors[q] =
+    Posterior(mean=m_q, cov=S_q, K=Kuu_q) (svmogp_inf.py:181).  block0=True reproduces `kern.K(self.Z, Xnew)` under GPy's
+    input slicing: the kernel sees the first P columns of the M x (Q P) inducing array -- latent 0's block for every q
+    (identical to block q while Z is the tiled initialisation, svmogp.py:52); block0=False uses block q."""
+    P, M = prob["P"], prob["M"]
+    Kuu, _, _, _ = latent_covariances(prm, prob, forced_rungs)
+    L_q = flat_to_tril(prm["L_flat"][:, q], M)
+    wv, wi, _ = gpy_posterior(prm["m_u"][:, q], L_q @ L_q.T, Kuu[q],
+                              forced_rung=None if forced_rungs is None else forced_rungs[q])
+    b = 0 if block0 else q
+    Kx = rbf_K(prm["Z"][:, b * P:(b + 1) * P], Xnew, prm["variance"][q], prm["lengthscale"][q])
+    mu = Kx.T @ wv
+    var = (prm["variance"][q] - np.sum((wi @ Kx) * Kx, 0))[:, None]
+    return mu, np.abs(var)
+
+
+def predictive_literal(prm, prob, X, Xpred, trained=True):
+    """SVMOGP.predictive (svmogp.py:333-351): q(f) through `_raw_predict_f`, then `<likelihood>.predictive` per task
+    (het_likelihood.py:133-148).  trained=True: the model's likelihood instances have run var_exp, so Gamma / Beta
+    read their cached 10-point rule (quirk Q7)."""
+    m_out, v_out = [], []
+    for t, (name, kw) in enumerate(prob["specs"]):
+        ds = _task_functions(prob, t)
+        mv = [raw_predict_f_literal(prm, prob, X, Xpred[t], d) for d in ds]
+        m = np.hstack([a for a, _ in mv])
+        v = np.hstack([b for _, b in mv])
+        gh = 10 if (trained and name in ("Gamma", "Beta")) else None
+        mp, vp = lo.predictive(name, m, v, gh_T=gh, **kw)
+        m_out.append(mp), v_out.append(vp)
+    return m_out, v_out
+
+
 # ----------------------------------------------------------------------------- loaders
 def load_case(npz):
     """Rebuild (prm, prob, X, Y, batch_scale) from an `inf_*.npz` / `model_*.npz` golden fixture."""
