@@ -798,8 +798,19 @@ struct hmogp_engine {
         Scope sc(this, CAT_COLSTATS, 1, st2);
         ColBatch cb;
         cb.nq = Q, cb.sK = sK, cb.sA = M, cb.sV = ldn, cb.sZ = P, cb.sPart = nsp * clen, cb.sWin = 2 * ncb;
+        // Blocks of the column statistics in flight beside the weighted Gram.  The Gram's 112 allocated registers per lane
+        // leave room for one 64-register wave per SIMD, so these blocks run BESIDE two resident Gram blocks per CU and cost
+        // them almost nothing -- as long as they do not saturate HBM: one block per row split (3125 x 6 at the headline size)
+        // streams K^ and P~ at 4.5 TB/s for 8.7 ms, evicts the Gram's operand panels from the L2s and stretches it from
+        // 39.3 to 45.4 ms; 192 blocks take 32 ms of the Gram's 40 at 1.2 TB/s and stretch it to 39.9 (profiles/
+        // r03_colstats_cap.txt: step 126.8 -> 120.7 ms).  Bytes per Gram flop scale with 1 / M, so the cap does too.
+        static const int cap_env = [] {   // HMOGP_COLSTATS_CAP=<blocks in flight> (0 = one block per row split)
+          const char* e = getenv("HMOGP_COLSTATS_CAP");
+          return e ? atoi(e) : -1;
+        }();
+        const int cap = cap_env >= 0 ? cap_env : std::max(48, 196608 / std::max(1, M));
         launch_colstats(Kh.d() + off * M, Pt.d() + off * M, a.d(), valpha.d() + off, valpha0.d() + off, vbeta0.d() + off,
-                        X + off * P, P, dZ.d(), ldz, rows, M, 256, want_z, colpart.d() + slab_first * clen, st2, cw, &cb);
+                        X + off * P, P, dZ.d(), ldz, rows, M, 256, want_z, colpart.d() + slab_first * clen, st2, cw, &cb, cap);
       };
 
       {

@@ -74,7 +74,8 @@ void launch_windows(const double* X, long long N, int P, const double* Z, int ld
                     unsigned char* hit, hipStream_t s);
 void launch_colstats(const double* Kh, const double* Pt, const double* a, const double* alpha, const double* alpha0,
                      const double* beta0, const double* X, int P, const double* Z, int ldz, long long N, int M, int rows,
-                     bool want_z, double* partials, hipStream_t s, const int* colwin = nullptr, const ColBatch* batch = nullptr);
+                     bool want_z, double* partials, hipStream_t s, const int* colwin = nullptr, const ColBatch* batch = nullptr,
+                     int max_blocks = 0);
 void launch_reduce_rows(const double* partials, long long nrows, int len, const long long* off, double* dst, bool accumulate,
                         hipStream_t s);
 void launch_reduce_slabs(const double* slabs, int nslabs, long long stride, long long len, double* dst, bool accumulate,

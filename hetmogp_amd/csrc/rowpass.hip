@@ -344,11 +344,6 @@ __global__ __launch_bounds__(256) void colstats_kernel(const double* __restrict_
   if (c >= M) return;
   const bool two = (c + 1) < M;
   const bool vec = two && ((M & 1) == 0);
-  long long n0 = (long long)blockIdx.y * rows, n1 = min(N, n0 + rows);
-  if (colwin) {  // rows outside the exact-zero window of this 128-column block contribute exact zeros
-    n0 = max(n0, (long long)colwin[2 * (c >> 7)]);
-    n1 = min(n1, (long long)colwin[2 * (c >> 7) + 1]);
-  }
   double z0[P], z1[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) {
@@ -356,48 +351,59 @@ __global__ __launch_bounds__(256) void colstats_kernel(const double* __restrict_
     z1[p] = two ? Z[(long long)(c + 1) * ldz + p] : 0.0;
   }
   const double a0 = a[c], a1 = two ? a[c + 1] : 0.0;
-  double r0 = 0.0, r1 = 0.0, d0[P], d1[P];
+  // A block takes the row splits blockIdx.y, blockIdx.y + gridDim.y, ...: the grid may be CAPPED (launch_colstats) so that
+  // this HBM-bound pass occupies only a few CU slots at a time beside the FP64-MFMA Gram it runs next to -- a block that
+  // holds half a CU while it waits for HBM keeps a Gram block (whose registers fill the other half) from being scheduled.
+  const long long nsplit = (N + rows - 1) / rows;
+  for (long long sp = blockIdx.y; sp < nsplit; sp += gridDim.y) {
+    long long n0 = sp * rows, n1 = min(N, n0 + rows);
+    if (colwin) {  // rows outside the exact-zero window of this 128-column block contribute exact zeros
+      n0 = max(n0, (long long)colwin[2 * (c >> 7)]);
+      n1 = min(n1, (long long)colwin[2 * (c >> 7) + 1]);
+    }
+    double r0 = 0.0, r1 = 0.0, d0[P], d1[P];
 #pragma unroll
-  for (int p = 0; p < P; ++p) d0[p] = d1[p] = 0.0;
-  for (long long n = n0; n < n1; ++n) {
-    double k0, k1, q0 = 0.0, q1 = 0.0;
-    if (vec) {
-      const f64x2 kv = *reinterpret_cast<const f64x2*>(Kh + n * M + c);
-      k0 = kv.x, k1 = kv.y;
-      if (want_z) {
-        const f64x2 qv = *reinterpret_cast<const f64x2*>(Pt + n * M + c);
-        q0 = qv.x, q1 = qv.y;
+    for (int p = 0; p < P; ++p) d0[p] = d1[p] = 0.0;
+    for (long long n = n0; n < n1; ++n) {
+      double k0, k1, q0 = 0.0, q1 = 0.0;
+      if (vec) {
+        const f64x2 kv = *reinterpret_cast<const f64x2*>(Kh + n * M + c);
+        k0 = kv.x, k1 = kv.y;
+        if (want_z) {
+          const f64x2 qv = *reinterpret_cast<const f64x2*>(Pt + n * M + c);
+          q0 = qv.x, q1 = qv.y;
+        }
+      } else {
+        k0 = Kh[n * M + c];
+        k1 = two ? Kh[n * M + c + 1] : 0.0;
+        if (want_z) {
+          q0 = Pt[n * M + c];
+          q1 = two ? Pt[n * M + c + 1] : 0.0;
+        }
       }
-    } else {
-      k0 = Kh[n * M + c];
-      k1 = two ? Kh[n * M + c + 1] : 0.0;
+      const double al = alpha[n];
+      r0 += k0 * al;
+      r1 += k1 * al;
       if (want_z) {
-        q0 = Pt[n * M + c];
-        q1 = two ? Pt[n * M + c + 1] : 0.0;
+        const double al0 = alpha0[n], be0 = 2.0 * beta0[n];
+        const double e0 = (al0 * a0 + be0 * q0) * k0, e1 = (al0 * a1 + be0 * q1) * k1;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const double x = X[n * P + p];
+          d0[p] += e0 * (x - z0[p]);
+          d1[p] += e1 * (x - z1[p]);
+        }
       }
     }
-    const double al = alpha[n];
-    r0 += k0 * al;
-    r1 += k1 * al;
-    if (want_z) {
-      const double al0 = alpha0[n], be0 = 2.0 * beta0[n];
-      const double e0 = (al0 * a0 + be0 * q0) * k0, e1 = (al0 * a1 + be0 * q1) * k1;
+    // partial layout per row-split: [ r (M) | dZ (M*P) ]
+    double* out = partials + sp * ((long long)M * (1 + P));
+    out[c] = r0;
+    if (two) out[c + 1] = r1;
 #pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const double x = X[n * P + p];
-        d0[p] += e0 * (x - z0[p]);
-        d1[p] += e1 * (x - z1[p]);
-      }
+    for (int p = 0; p < P; ++p) {
+      out[M + (long long)c * P + p] = d0[p];
+      if (two) out[M + (long long)(c + 1) * P + p] = d1[p];
     }
-  }
-  // partial layout per row-split: [ r (M) | dZ (M*P) ]
-  double* out = partials + (long long)blockIdx.y * ((long long)M * (1 + P));
-  out[c] = r0;
-  if (two) out[c + 1] = r1;
-#pragma unroll
-  for (int p = 0; p < P; ++p) {
-    out[M + (long long)c * P + p] = d0[p];
-    if (two) out[M + (long long)(c + 1) * P + p] = d1[p];
   }
 }
 
@@ -796,10 +802,14 @@ void launch_log_predictive(int lik, int J, double param, long long N, int S, uns
 
 void launch_colstats(const double* Kh, const double* Pt, const double* a, const double* alpha, const double* alpha0,
                      const double* beta0, const double* X, int P, const double* Z, int ldz, long long N, int M, int rows,
-                     bool want_z, double* partials, hipStream_t s, const int* colwin, const ColBatch* batch) {
+                     bool want_z, double* partials, hipStream_t s, const int* colwin, const ColBatch* batch, int max_blocks) {
   if (N <= 0) return;
   ColBatch bt = batch ? *batch : ColBatch{};
   dim3 grid((M + 511) / 512, (unsigned)((N + rows - 1) / rows), batch ? batch->nq : 1);
+  if (max_blocks > 0) {   // cap the blocks in flight: each takes several row splits in turn
+    const long long per_y = (long long)grid.x * grid.z;
+    grid.y = (unsigned)std::max<long long>(1, std::min<long long>(grid.y, max_blocks / per_y));
+  }
   DISPATCH_P(P, hipLaunchKernelGGL((colstats_kernel<PP>), grid, dim3(256), 0, s, Kh, Pt, a, alpha, alpha0, beta0, X, Z, ldz,
                                    N, M, rows, want_z ? 1 : 0, partials, colwin, bt));
 }
