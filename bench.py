@@ -287,6 +287,8 @@ def main():
         print(json.dumps(line))
         sys.stdout.flush()
     if world > 1:
+        if reducer is not None:
+            reducer.close()                 # ncclCommDestroy of the library's own communicator, on every rank, before torch's
         dist.barrier()
         dist.destroy_process_group()
 

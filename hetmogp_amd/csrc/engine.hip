@@ -95,6 +95,11 @@ int lik_dimf(int lik, double param) {
 // enough blocks (lower tiles x ranges) for >= 8 rounds over the 256 CUs, at most KS_MAX slabs.
 constexpr int KS_MAX = 256;  // most row ranges (slabs) of the weighted Gram
 int gram_ksplit(long long n, int M) {
+  static const int forced = [] {   // HMOGP_GRAM_KSPLIT=<row ranges> (experiments; profiles/r03_gram_ksplit.txt: flat)
+    const char* e = getenv("HMOGP_GRAM_KSPLIT");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced > 0) return (int)std::max<long long>(1, std::min<long long>(forced, (n + 15) / 16));
   const int tiles = (M + 127) / 128, ntl = tiles * (tiles + 1) / 2;
   const long long ksteps = (n + 15) / 16;
   // enough blocks to fill the chip several times over, and row ranges of at most ~8192 rows (the tiles of one range drift

@@ -27,7 +27,16 @@ struct Tile {
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(NTH, 3) void gemm_small_kernel(GemmArgs g, int tiles_n, int a_vec, int b_vec) {
   __shared__ __attribute__((aligned(16))) Tile lds;
-  const int v = blockIdx.x, ti = v / tiles_n, tj = v - ti * tiles_n;
+  int ti, tj;
+  if (g.lower_only) {   // lower tiles only (tile_col <= tile_row), enumerated row by row: v = ti (ti + 1) / 2 + tj
+    const int v = blockIdx.x;
+    ti = (int)((sqrt(8.0 * (double)v + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= v) ++ti;
+    while (ti * (ti + 1) / 2 > v) --ti;
+    tj = v - ti * (ti + 1) / 2;
+  } else {
+    ti = blockIdx.x / tiles_n, tj = blockIdx.x - ti * tiles_n;
+  }
   const int i0 = ti * TM, j0 = tj * TN, batch = blockIdx.z;
   const long long ob = blockIdx.y;
   const double* __restrict__ A = g.A + (long long)batch * g.sA + ob * g.oA;
@@ -131,8 +140,9 @@ bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // Full 64 x 64 tiles, a k-extent that is a multiple of 16, no accumulation into C, no K split, no ragged last batch, no
 // row-pass extras.  Operands that are not 16-byte aligned (odd strides / offsets) are read with 8-byte loads.
-// lower_only is not honoured (every tile is computed: the callers that ask for it mirror the result anyway).
+// lower_only (square products): only the tiles on or below the diagonal are launched -- 136 of 256 at M = 1024.
 bool gemm_small_eligible(const GemmArgs& g) {
+  if (g.lower_only && g.M != g.N) return false;
   if (g.role != 0 || g.beta != 0.0 || g.ksplit != 1 || g.kscale || g.win || g.fs_part) return false;
   if ((g.M_last && g.M_last != g.M) || (g.N_last && g.N_last != g.N) || (g.K_last && g.K_last != g.K)) return false;
   if ((g.M % TM) || (g.N % TN) || (g.K % TK)) return false;
@@ -141,7 +151,7 @@ bool gemm_small_eligible(const GemmArgs& g) {
 
 void launch_gemm_small(const GemmArgs& g, hipStream_t stream) {
   const int tiles_m = g.M / TM, tiles_n = g.N / TN;
-  dim3 grid(tiles_m * tiles_n, g.nouter, g.nbatch);
+  dim3 grid(g.lower_only ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n, g.nouter, g.nbatch);
   const int a_vec = !((g.lda & 1) || (g.sA & 1) || (g.oA & 1) || !al16(g.A));
   const int b_vec = !((g.ldb & 1) || (g.sB & 1) || (g.oB & 1) || !al16(g.B));
   if (g.a_kmajor && g.b_kmajor)

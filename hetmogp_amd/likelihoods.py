@@ -48,9 +48,13 @@ class _Lik(object):
         drawn from NumPy's global generator when not given -- so `np.random.seed(k)` still makes a run reproducible, but
         the stream differs from the reference's (only the distribution is the same)."""
         from .engine import sample
-        if seed is None:
+        if seed is None:       # NB: one extra draw from NumPy's GLOBAL generator per call (shifts it relative to the reference)
             seed = int(np.random.randint(0, 2 ** 31 - 1))
-        return sample(self.name, F, seed=seed, **self.kwargs())
+        F = np.asarray(F, dtype=float)
+        y = sample(self.name, F, seed=seed, **self.kwargs())
+        if self.get_metadata()[1] == 1 and F.ndim == 2 and F.shape[1] > 1:
+            return y.reshape(F.shape)      # one-function likelihoods: every entry of F is a draw, shape kept (gaussian.py:36-39)
+        return y
 
 
 class Gaussian(_Lik):

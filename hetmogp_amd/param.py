@@ -3,6 +3,7 @@
 that basic slices write through to, `.fix()` / `.unfix()` / `.is_fixed`, and the Logexp positive transform paramz
 applies to `variance`, `lengthscale` and `kappa` in the optimiser's view.  paramz itself is not a dependency."""
 import re
+import weakref
 
 import numpy as np
 
@@ -30,13 +31,29 @@ class Param(np.ndarray):
         self.positive = getattr(obj, "positive", False)
 
     # paramz re-runs the model's parameters_changed() on every write to a parameter; here a write notifies the
-    # observers (the model marks itself dirty and re-evaluates lazily before the next read of a derived quantity)
+    # observers (the model marks itself dirty and re-evaluates lazily before the next read of a derived quantity).
+    # Writes that notify: item / slice assignment (`p[...] = v`, `p[i, j] = v`) and the in-place operators
+    # (`+= -= *= /= **= //= %=`).  Writes that go around this class -- `p.values[...] = v`, `np.copyto(p, v)`,
+    # `ufunc(..., out=p)`, a plain-ndarray view from `np.asarray(p)` -- do NOT: follow them with `model.touch()`.
+    # Observers that are bound methods are held weakly: a kernel object reused in a second model neither keeps the
+    # first model alive nor notifies a dead one.
     def add_observer(self, fn):
-        self._observers.append(fn)
+        try:
+            ref = weakref.WeakMethod(fn)
+        except TypeError:            # a plain function / lambda: held strongly
+            ref = (lambda f: (lambda: f))(fn)
+        self._observers.append(ref)
 
     def _notify(self):
-        for fn in self._observers:
-            fn(self)
+        dead = []
+        for ref in self._observers:
+            fn = ref()
+            if fn is None:
+                dead.append(ref)
+            else:
+                fn(self)
+        for ref in dead:
+            self._observers.remove(ref)
 
     def __setitem__(self, idx, val):
         np.ndarray.__setitem__(self, idx, val)
@@ -58,6 +75,15 @@ class Param(np.ndarray):
 
     def __itruediv__(self, o):
         return self._inplace(np.ndarray.__itruediv__, o)
+
+    def __ipow__(self, o):
+        return self._inplace(np.ndarray.__ipow__, o)
+
+    def __ifloordiv__(self, o):
+        return self._inplace(np.ndarray.__ifloordiv__, o)
+
+    def __imod__(self, o):
+        return self._inplace(np.ndarray.__imod__, o)
 
     def __getitem__(self, idx):
         out = np.ndarray.__getitem__(self, idx)

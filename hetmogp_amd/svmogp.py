@@ -91,6 +91,7 @@ class DeviceAdadelta(object):
                 self.sms *= d
                 self.sms += t2
                 eng.qu_adadelta(1, rate, mom, d, o)
+                m._qu_host_stale = True                            # (refreshed on the next READ of m.q_u_means / q_u_chols)
                 self.n_iter += 1
                 yield dict(n_iter=self.n_iter, gradient=g, step=self.step)
         finally:
@@ -107,8 +108,9 @@ class DeviceAdadelta(object):
         m = self.model
         if getattr(m, "_qu_on_device", False):
             mu, L = m._engine.qu_read()
-            np.asarray(m.q_u_means)[...] = mu
-            np.asarray(m.q_u_chols)[...] = L
+            m._qu_host_stale = False
+            np.asarray(m._q_u_means)[...] = mu
+            np.asarray(m._q_u_chols)[...] = L
             m._qu_on_device = False
             m._dirty = True
 
@@ -189,6 +191,8 @@ class SVMOGP(object):
         _, self.B_list = util.LCM(input_dim=self.Xdim, output_dim=self.num_output_funcs, rank=1,
                                   kernels_list=self.kern_list, W_list=self.W_list, kappa_list=self.kappa_list)
         M, Q = self.num_inducing, self.num_latent_funcs
+        self._qu_on_device = False                # True while a DeviceAdadelta loop owns q(u): see the q_u_means property
+        self._qu_host_stale = False
         self.q_u_means = Param("m_u", 2.5 * np.random.randn(M, Q), storage=pinned_empty((M, Q)))   # svmogp.py:66-67
         r, c = np.tril_indices(M)
         chols = np.zeros((M * (M + 1) // 2, Q))
@@ -203,13 +207,47 @@ class SVMOGP(object):
         self.forced_rung = None
         self.last = None
         self._dirty = False
-        self._qu_on_device = False                # True while a DeviceAdadelta loop owns q(u) (host arrays stale)
         for _, prm in self._named_params():       # a direct write to any parameter marks the model dirty (paramz would
             prm.add_observer(self._mark_dirty)    # re-run parameters_changed() at once; here it happens lazily, on the
         self.parameters_changed()                 # next read of a derived quantity)
 
     def _mark_dirty(self, _param=None):
         self._dirty = True
+
+    def touch(self):
+        """Mark the model dirty after a write that went around the parameter objects (`p.values[...] = v`, `np.copyto`,
+        `ufunc(out=p)`, a view from `np.asarray(p)`): paramz would have re-run parameters_changed() by itself; here the next
+        read of `log_likelihood()`, a gradient or a prediction re-evaluates."""
+        self._dirty = True
+
+    # q(u) is an attribute of the reference's model (svmogp.py:66-69) that callbacks and predict calls may read at any time.
+    # While a DeviceAdadelta loop owns it (hmogp_qu_*), the host arrays are refreshed from the device on READ -- as of the
+    # last evaluation, which is what the reference's model holds between climin iterations -- instead of after every
+    # iteration (a 12.6 MB copy at M = 1024, Q = 3, paid only by whoever looks).
+    def _qu_read_through(self):
+        if self._qu_on_device and self._qu_host_stale:
+            self._qu_host_stale = False
+            mu, L = self._engine.qu_read()
+            np.asarray(self._q_u_means)[...] = mu
+            np.asarray(self._q_u_chols)[...] = L
+
+    @property
+    def q_u_means(self):
+        self._qu_read_through()
+        return self._q_u_means
+
+    @q_u_means.setter
+    def q_u_means(self, p):
+        self._q_u_means = p
+
+    @property
+    def q_u_chols(self):
+        self._qu_read_through()
+        return self._q_u_chols
+
+    @q_u_chols.setter
+    def q_u_chols(self, p):
+        self._q_u_chols = p
 
     def _refresh(self):
         if self._dirty:

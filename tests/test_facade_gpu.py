@@ -286,3 +286,42 @@ def test_vem_stochastic_uses_device_optimizer_and_syncs_q_u():
     assert not model._qu_on_device and not np.array_equal(model.q_u_means.values, m0)
     e = float(model.log_likelihood()[0, 0])                           # dirty after the sync: re-evaluated on read
     assert np.isfinite(e) and np.all(np.isfinite(model.elbo[:12]))
+
+
+def test_q_u_read_mid_loop_sees_the_last_evaluation_and_observers_are_weak():
+    """while a DeviceAdadelta loop owns q(u), `model.q_u_means` / `q_u_chols` read THROUGH to the device (as of the
+    last evaluation) instead of showing the initial q(u); writes that bypass the Param class need `model.touch()`; a kernel
+    reused in a second model neither keeps the first alive nor notifies it."""
+    import gc
+    import weakref
+    from hetmogp_amd.util import Adadelta
+    g = np.load(os.path.join(GOLDEN, "model_config2_svi_E.npz"))
+    bs = int(g["batch_size"])
+    host, dev = build_model(g, bs), build_model(g, bs)
+    for m in (host, dev):
+        m[".*.lengthscale"].fix()
+        m[".*.kappa"].fix()
+    seen_host, seen_dev = [], []
+    oh = Adadelta(host.optimizer_array, host.stochastic_grad, step_rate=0.01, momentum=0.9)
+    oh.minimize_until(lambda i: seen_host.append(host.q_u_means.values.copy()) or i["n_iter"] >= 7)
+    od = dev.device_adadelta(step_rate=0.01, momentum=0.9)
+    od.minimize_until(lambda i: seen_dev.append(dev.q_u_means.values.copy()) or i["n_iter"] >= 7)
+    assert len(seen_host) == len(seen_dev) == 7
+    for a, b in zip(seen_host, seen_dev):
+        assert np.array_equal(a, b)                                    # what a callback sees mid-loop is the same q(u)
+    assert not np.array_equal(seen_dev[0], seen_dev[-1])
+    # a write around the Param class does not notify; touch() does
+    e0 = float(dev.log_likelihood()[0, 0])
+    dev.q_u_means.values[...] *= 1.01
+    assert float(dev.log_likelihood()[0, 0]) == e0
+    dev.touch()
+    assert float(dev.log_likelihood()[0, 0]) != e0
+    dev.q_u_means **= 1                                                # the added in-place operators notify
+    assert dev._dirty
+    # observers are weak references
+    kern = host.kern_list
+    ref = weakref.ref(host)
+    del host, oh
+    gc.collect()
+    assert ref() is None
+    kern[0].variance[...] = 0.7                                        # must not raise on the dead observer
