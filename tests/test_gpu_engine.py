@@ -463,8 +463,9 @@ def test_config5_like_2d_M2048_vs_oracle():
     assert want["rungs"] == [-1, -1]
     e = make_engine(prob, X, Y)
     out = run(e, prm)
+    lit = so.elbo_grad_literal(prm, prob, X, Y)       # yardstick: the oracle's literal (solve-based) restatement
     for k in KEYS:
-        assert rel(out[k], want[k]) < 1e-7, k
+        assert rel(out[k], want[k]) < min(1e-7, max(1e-8, 10.0 * rel(want[k], lit[k]))), (k, rel(want[k], lit[k]))
     g = np.stack(np.meshgrid(np.linspace(0, 1, 24), np.linspace(0, 1, 24), indexing="ij"), -1).reshape(-1, 2)
     m, v = e.predict_f(g)
     u = so.u_algebra(prm, prob)

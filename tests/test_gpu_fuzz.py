@@ -47,10 +47,15 @@ def _case(seed, ms, one_d):
     want = so.elbo_grad_fused(prm, prob, X, Y)
     e = make_engine(prob, X, Y, chunk_rows=int(rng.choice([1 << 20, 600, 256])), quirks=quirks)
     out = run(e, prm)
-    # 2-D grids of inducing points with jitter have cond(K_uu) up to ~1e6: parity there is conditioning-limited
+    # 2-D grids of inducing points with jitter have cond(K_uu) up to ~1e6: parity there is conditioning-limited.  The
+    # yardstick is the distance between the oracle's OWN two restatements -- the literal one (solves,
+    # the reference's operation order) and the fused one (explicit inverses, the engine's algebra): the engine may be no
+    # further from the fused restatement than 10x that, and never further than 2e-7.
     tol = 1e-8 if P == 1 else 2e-7
+    lit = so.elbo_grad_literal(prm, prob, X, Y) if (P > 1 and quirks == "reference" and min(Ns) > 0) else None
     for k in KEYS:
-        assert rel(out[k], want[k]) < tol, (k, M, P, Q, specs, Ns)
+        tk = tol if lit is None else min(tol, max(1e-8, 10.0 * rel(want[k], lit[k])))
+        assert rel(out[k], want[k]) < tk, (k, M, P, Q, specs, Ns, tk)
     # a minibatch: a random contiguous range of every task with the reference's batch scale (svmogp.py:101-105)
     rb = [int(rng.randint(0, n // 2 + 1)) for n in Ns]
     re = [int(min(n, b + max(1, n // 3))) if n else 0 for n, b in zip(Ns, rb)]
