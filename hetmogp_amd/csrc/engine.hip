@@ -308,9 +308,15 @@ struct hmogp_engine {
     }
   };
   void collect_spans() {
+    static const bool dbg = getenv("HMOGP_DEBUG_TIMELINE") != nullptr;   // start / end of every span relative to the step's start
     for (auto& s : spans) {
       float f = 0.f;
       if (hipEventElapsedTime(&f, s.a, s.b) == hipSuccess) ms[s.cat] += f;
+      if (dbg) {
+        float t0 = 0.f;
+        if (hipEventElapsedTime(&t0, ev_begin0, s.a) == hipSuccess)
+          std::fprintf(stderr, "[hmogp timeline] cat %d  start %9.3f ms  dur %9.3f ms\n", s.cat, t0, f);
+      }
     }
     spans.clear();
     pool_used = 0;
@@ -405,6 +411,22 @@ struct hmogp_engine {
       if (cus > 0 && cus < prop.multiProcessorCount) {
         std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0u);
         for (int i = 0; i < cus; ++i) mask[i / 32] |= 1u << (i % 32);
+        if (hipExtStreamCreateWithCUMask(&st2, (uint32_t)mask.size(), mask.data()) != hipSuccess) st2 = nullptr;
+      }
+      // HMOGP_ST2_FREE=<n> with HMOGP_ST2_LAYOUT=0|1 (experiment): leave n CUs of EVERY XCD out of the second stream's mask --
+      // a mask that drops whole XCDs unbalances kernels whose blocks are dealt round-robin over the XCDs.  Layout 0: mask bit
+      // i = CU i % 32 of XCD i / 32; layout 1: bit i = CU i / 8 of XCD i % 8.
+      const char* free_env = getenv("HMOGP_ST2_FREE");
+      const int nfree = free_env ? atoi(free_env) : 0;
+      if (!st2 && nfree > 0 && nfree < 32 && prop.multiProcessorCount == 256) {
+        const char* lay = getenv("HMOGP_ST2_LAYOUT");
+        const int layout = lay ? atoi(lay) : 0;
+        std::vector<uint32_t> mask(8, 0xFFFFFFFFu);
+        for (int x = 0; x < 8; ++x)
+          for (int c = 32 - nfree; c < 32; ++c) {
+            const int bit = layout == 0 ? x * 32 + c : c * 8 + x;
+            mask[bit / 32] &= ~(1u << (bit % 32));
+          }
         if (hipExtStreamCreateWithCUMask(&st2, (uint32_t)mask.size(), mask.data()) != hipSuccess) st2 = nullptr;
       }
       if (!st2) HIP_TRY(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, lo));
@@ -723,7 +745,11 @@ struct hmogp_engine {
       // On the side stream the construction is cut into launches of KUF_CHUNK_ROWS rows (~70 us each): a kernel that fills
       // every CU for a millisecond stalls every launch of the latency-bound chains on the other streams until it has
       // drained (stream priorities notwithstanding); between short launches they slip in.
-      const long long step = (stream != st && !use_windows) ? KUF_CHUNK_ROWS : sg.n;
+      static const long long chunk_env = [] {   // HMOGP_KUF_CHUNK=<rows per launch on the side stream> (experiment)
+        const char* e = getenv("HMOGP_KUF_CHUNK");
+        return e ? atoll(e) : 0LL;
+      }();
+      const long long step = (stream != st && !use_windows) ? (chunk_env > 0 ? chunk_env : KUF_CHUNK_ROWS) : sg.n;
       for (long long r = 0; r < sg.n; r += step)
         launch_rbf(Xs + r * P, P, std::min(step, sg.n - r), P, dZ.d(), ldz, M, 0.0, 1.0, Kh.d() + (sg.off + r) * M, false, stream,
                    rw, false, &rbt);
@@ -813,7 +839,8 @@ struct hmogp_engine {
           const char* e = getenv("HMOGP_COLSTATS_CAP");
           return e ? atoi(e) : -1;
         }();
-        const int cap = cap_env >= 0 ? cap_env : std::max(48, 196608 / std::max(1, M));
+        // (exact-zero windows: the banded Gram is short; the cap was sized for the dense one)
+        const int cap = cap_env >= 0 ? cap_env : (use_windows ? 0 : std::max(48, 196608 / std::max(1, M)));
         launch_colstats(Kh.d() + off * M, Pt.d() + off * M, a.d(), valpha.d() + off, valpha0.d() + off, vbeta0.d() + off,
                         X + off * P, P, dZ.d(), ldz, rows, M, 256, want_z, colpart.d() + slab_first * clen, st2, cw, &cb, cap);
       };
