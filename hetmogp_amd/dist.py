@@ -59,19 +59,23 @@ def all_agree(ok, group=None, device=0):
     return bool(int(t.item()) == 1)
 
 
-def attach_native_comm(engine, group=None, device=0):
+def attach_native_comm(engine, group=None, device=0, api=None):
     """Give `engine` its own RCCL communicator spanning the ranks of `group` (hmogp_comm_init): rank 0 draws the
     ncclUniqueId through the library, torch.distributed only carries those 128 bytes.  Collective; returns True on
-    every rank or False on every rank (then no rank keeps a communicator)."""
+    every rank or False on every rank (then no rank keeps a communicator).  `api` = (comm_available, comm_unique_id)
+    replaces the library's entry points (tests of the negotiation without a GPU)."""
     import torch
     import torch.distributed as dist
-    from .engine import comm_available, comm_unique_id
-    from . import _lib
+    if api is None:
+        from .engine import comm_available, comm_unique_id
+    else:
+        comm_available, comm_unique_id = api
+    id_bytes = 128                                                     # HMOGP_COMM_ID_BYTES
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if not all_agree(comm_available(), group, device):
         return False
     dev = _flag_device(group, device)
-    uid = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+    uid = torch.zeros(id_bytes, dtype=torch.uint8, device=dev)
     ok = True
     if rank == 0:
         try:
@@ -109,7 +113,7 @@ class StatsReducer(object):
     the step.  `last_ms` = host wall milliseconds of the last exchange (for "native": host time to enqueue it; the device
     time is category "exchange" of Engine.timings()), `n_calls` = exchanges so far."""
 
-    def __init__(self, engine, device=0, mode=None, group=None):
+    def __init__(self, engine, device=0, mode=None, group=None, native_api=None):
         import torch
         import torch.distributed as dist
         self.engine, self.group = engine, group
@@ -135,7 +139,7 @@ class StatsReducer(object):
                 if all_agree(have, group, self.device):                     # the caller attached one on every rank
                     self.mode = "native"
                 elif not have and all_agree(engine.comm_info()[0] == 0, group, self.device) and \
-                        attach_native_comm(engine, group, self.device):
+                        attach_native_comm(engine, group, self.device, native_api):
                     self.owns_comm = True
                     self.mode = "native"
             elif cand == "device":

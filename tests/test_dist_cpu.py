@@ -82,3 +82,117 @@ def test_two_rank_gloo_allreduce_matches_single_process():
         for a, b in ((gZ, want["g_Z"]), (gL, want["g_L_u"]), (gW, want["g_W"])):
             assert np.max(np.abs(a - b)) <= 1e-9 * np.max(np.abs(b))
     assert abs(res[0][1] - res[1][1]) == 0.0 or abs(res[0][1] - res[1][1]) < 1e-9 * abs(res[0][1])
+
+
+class _FakeEngine(object):
+    """Host-only stand-in with the engine's exchange surface (wire buffer in NumPy) -- the negotiation logic of
+    StatsReducer / attach_native_comm is what is under test, not the device."""
+
+    def __init__(self, rank, fail_init_on=None):
+        self.rank, self.fail_init_on = rank, fail_init_on
+        self.wire = np.arange(10, dtype=np.float64) * (rank + 1)
+        self.comm, self.destroyed, self.exchanged = (0, -1), 0, 0
+
+    def wire_buffer(self):
+        return 0, self.wire.size
+
+    def wire_pack(self):
+        pass
+
+    def wire_unpack(self):
+        pass
+
+    def wire_read(self):
+        return self.wire.copy()
+
+    def wire_write(self, v):
+        self.wire[...] = v
+
+    def comm_info(self):
+        return self.comm
+
+    def comm_init(self, nranks, rank, uid):
+        assert len(uid) == 128
+        if self.fail_init_on == rank:
+            raise RuntimeError("simulated ncclCommInitRank failure")
+        self.comm = (nranks, rank)
+
+    def comm_destroy(self):
+        self.destroyed += 1
+        self.comm = (0, -1)
+
+    def step_exchange(self):
+        self.exchanged += 1
+
+
+def _negotiation_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    import torch.distributed as dist
+    spec = importlib.util.spec_from_file_location("hm_dist", os.path.join(ROOT, "hetmogp_amd", "dist.py"))
+    hd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hd)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    res["agree_all_true"] = hd.all_agree(True)
+    res["agree_one_false"] = hd.all_agree(rank != 1)
+    # default under gloo: host-staged all-reduce of the wire buffer
+    e = _FakeEngine(rank)
+    red = hd.StatsReducer(e)
+    res["mode_default"] = red.mode
+    red()
+    res["wire_sum"] = e.wire.copy()
+    api = (lambda: True, lambda: bytes(range(128)))
+    # native, every rank succeeds: the engine keeps its communicator, the exchange is the engine's
+    e2 = _FakeEngine(rank)
+    red2 = hd.StatsReducer(e2, mode="native", native_api=api)
+    red2()
+    res["native_ok"] = (red2.mode, e2.comm, e2.exchanged, red2.owns_comm)
+    red2.close()
+    res["native_closed"] = (e2.comm, e2.destroyed)
+    # native, rank 1 fails inside comm_init: EVERY rank must give up together, and the rank that succeeded drops its communicator
+    e3 = _FakeEngine(rank, fail_init_on=1)
+    try:
+        hd.StatsReducer(e3, mode="native", native_api=api)
+        res["native_partial"] = "no error"
+    except RuntimeError as exc:
+        res["native_partial"] = ("raised", e3.comm, e3.destroyed, "every rank" in str(exc))
+    # library unavailable on one rank only
+    api_half = (lambda: rank == 0, lambda: bytes(range(128)))
+    e4 = _FakeEngine(rank)
+    try:
+        hd.StatsReducer(e4, mode="native", native_api=api_half)
+        res["native_unavailable"] = "no error"
+    except RuntimeError:
+        res["native_unavailable"] = ("raised", e4.comm)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, res))
+
+
+@pytest.mark.timeout(300)
+def test_reducer_mode_negotiation_is_collective():
+    """ADVICE r2 / VERDICT r2 item 4c: the exchange mode is agreed by a MIN all-reduce of a flag -- ranks either all take a mode
+    or all give it up; a rank whose hmogp_comm_init succeeded while another's failed drops its communicator."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_negotiation_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        r = res[rank]
+        assert r["agree_all_true"] is True and r["agree_one_false"] is False
+        assert r["mode_default"] == "host"
+        assert np.array_equal(r["wire_sum"], np.arange(10) * 3.0)                 # (rank 0: x1) + (rank 1: x2)
+        assert r["native_ok"] == ("native", (2, rank), 1, True)
+        assert r["native_closed"] == ((0, -1), 1)
+        assert r["native_partial"][0] == "raised" and r["native_partial"][1] == (0, -1) and r["native_partial"][3]
+        assert r["native_unavailable"] == ("raised", (0, -1))
+    assert res[0]["native_partial"][2] == 1 and res[1]["native_partial"][2] == 0   # only the rank that had one destroyed it
