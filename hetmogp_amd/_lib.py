@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhetmogp_hip.so")
+LIB_PATH = os.environ.get("HMOGP_LIB_PATH") or os.path.join(_HERE, "libhetmogp_hip.so")   # (override: A/B experiments)
 
 ABI_VERSION = 4
 # likelihood ids (class names of the reference's likelihoods/<name>.py)

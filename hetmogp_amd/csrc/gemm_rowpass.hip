@@ -170,7 +170,10 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
     // Fused row statistics (GemmArgs::fs_*): lane (lr, lk) owns row rl = wm*64 + a*16 + lr and the column quads
     // wn*32 + b*16 + 4*lk + (0..3), b < 2, of slice a; it re-reads exactly its own 8 values of the K^ tile per slice
     // (L2/MALL-warm) with LDS-DMA loads (global_load_lds_dwordx4: lane l's 16 bytes land at base + 16*l) into a
-    // wave-private double buffer, slice a+1 in flight while slice a is consumed -- no VGPRs, no block barriers.
+    // wave-private double buffer -- no VGPRs, no block barriers.  Slices 0 and 1 are issued up front, slice a + 2 as soon as
+    // slice a has been consumed (into the buffer it frees): every slice but the first has two consumption periods to land
+    // in.  The waits count on loads returning in order: s_waitcnt vmcnt(4) with [slice a | stores | slice a + 1] outstanding
+    // can only be satisfied once slice a has landed (were one of its 4 loads outstanding, so were all 4 of slice a + 1).
     const int P = g.fs_P;
     const bool hyper = g.fs_hyper != 0;
     constexpr int NCH = 2 * NB, WSTAGE = 2 * NCH * 128;
@@ -190,6 +193,7 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
                                          (void __attribute__((address_space(3)))*)(dst + c * 128), 16, 0, 0);
     };
     issue(0);
+    issue(1);
     {
       const double inv_l = 1.0 / g.fs_ell[batch];
       for (int e = t; e < 4 * 128; e += NT) {
@@ -202,8 +206,8 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // slice a has landed (and the previous partial stores)
-      if (a < 3) issue(a + 1);
+      if (a < 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // slice a has landed; slice a + 1 may still be in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int rl = wm * 64 + a * 16 + lr;
       double sp = 0.0, sc = 0.0, spt = 0.0, sct = 0.0;
 #pragma unroll
@@ -254,6 +258,10 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
         const long long ss = (long long)NWN * tiles_n * M;
         o[0] = sp, o[ss] = sc;
         if (hyper) o[2 * ss] = spt, o[3 * ss] = sct;
+      }
+      if (a < 2) {                                   // slice a is consumed: its buffer takes slice a + 2
+        asm volatile("" ::: "memory");
+        issue(a + 2);
       }
     }
     if (!g.store_c) return;
