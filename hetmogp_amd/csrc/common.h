@@ -71,6 +71,7 @@ struct GemmArgs {
   long long sSplit = 0;
   int a_kmajor = 0, b_kmajor = 1;
   int lower_only = 0;
+  int diag_balance = 1;  // role 2: balance the diagonal tiles' sub-tiles over the physical SIMDs of the CU (gemm_rowpass.hip)
   int role = 0;  // 0 generic, 1 forward contraction, 2 weighted Gram (names the kernel instantiation for profiles)
   // role 1 only -- row statistics fused into the epilogue while the P~ tile is still in registers (replaces a separate
   // pass over K^ and P~):  for every row n of the tile and this block's 128 columns j

@@ -899,6 +899,11 @@ struct hmogp_engine {
         g.lower_only = 1;
         g.ksplit = ksplit, g.sSplit = MM;
         g.role = 2;
+        static const int bal = [] {   // HMOGP_DIAG_BALANCE=0: static sub-tile assignment on the diagonal tiles (A/B runs)
+          const char* e = getenv("HMOGP_DIAG_BALANCE");
+          return e ? atoi(e) : 1;
+        }();
+        g.diag_balance = bal;
         g.win = cw, g.win_stride = 2 * ncb;
         {
           Scope sc(this, CAT_GRAM, 1);

@@ -33,7 +33,8 @@ __device__ __forceinline__ int diag_wn(int w) { return (0x7E84 >> (2 * w)) & 3; 
 
 // One 128 x 128 tile of the contraction: main loop + epilogue (everything the kernel does once it knows its tile).
 template <int ROLE>
-__device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int ti, int tj, int split, Tile& lds, double* epi_a) {
+__device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int ti, int tj, int split, Tile& lds, double* epi_a,
+                                             int* hwinfo = nullptr) {
   const int batch = blockIdx.z;
   const int M = g.M, N = g.N, K = g.K;
   const int i0 = ti * BM, j0 = tj * BN;
@@ -55,14 +56,20 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
   const int lr = lane & 15, lk = lane >> 4;
   int wm = w >> 2, wn = w & 3;
   unsigned sub = 0xFFu;                                         // bit a*2 + b: sub-tile (a, b) of the wave tile is computed
-  if (ROLE == 2 && ti == tj && g.lower_only) {
-    wm = diag_wm(w), wn = diag_wn(w);
-    sub = 0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-        if (wn * NB + b <= wm * 4 + a) sub |= 1u << (a * NB + b);
+  const bool diag = ROLE == 2 && ti == tj && g.lower_only;
+  // Diagonal tiles: the four (w, w + 4) wave pairs carry 8, 8, 10, 10 of the 36 needed sub-tiles, and a pair shares a SIMD,
+  // so ONE block loads the CU's four SIMDs 8 : 8 : 10 : 10.  Two blocks are resident per CU: the one in the upper wave slots
+  // takes the pair types rotated by two (10 : 10 : 8 : 8 by PHYSICAL SIMD), which makes it 18 on every SIMD -- 9/16 of a
+  // full tile's MFMA time instead of 10/16.  HW_REG_HW_ID (tools/probes/probe_hwid.hip, gfx950): bits 5:4 = SIMD, bits 3:0 =
+  // wave slot on that SIMD (this kernel's 4 waves per SIMD sit in slots {0,1} / {2,3} by block).  Only the BALANCE depends on
+  // that reading: which wave computes which sub-tile does not change any value, and if the pairs are not found on four
+  // distinct SIMDs the static assignment is used.
+  if (diag && hwinfo) {
+    if (lane == 0) {
+      const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+      hwinfo[w] = (int)((hw >> 4) & 3u);
+      if (w == 0) hwinfo[8] = (int)((hw >> 1) & 1u);                              // upper or lower pair of wave slots
+    }
   }
   // The forward contraction accumulates the TRANSPOSED sub-tiles (MFMA operands swapped, B fragment columns permuted): lane
   // (lr, lk) register r of acc[a][b] holds P~[wm*64 + a*16 + lr][wn*32 + b*16 + 4*lk + r] -- a lane owns 4 adjacent columns
@@ -157,6 +164,27 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
     if (kbeg + BK < kend) load(kbeg + BK);
   }
   __syncthreads();
+  if (diag) {
+    int role = w;                                               // static assignment: pair type w & 3, half w >> 2
+    if (hwinfo) {
+      bool ok = true;
+      unsigned seen = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ok = ok && hwinfo[i] == hwinfo[i + 4];
+        seen |= 1u << hwinfo[i];
+      }
+      if (ok && seen == 0xFu) role = ((hwinfo[w] + 2 * hwinfo[8]) & 3) + (w & 4);
+    }
+    role = __builtin_amdgcn_readfirstlane(role);
+    wm = diag_wm(role), wn = diag_wn(role);
+    sub = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if (wn * NB + b <= wm * 4 + a) sub |= 1u << (a * NB + b);
+  }
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     if (k0 + BK < kend) stage(cur ^ 1);
     if (k0 + 2 * BK < kend) load(k0 + 2 * BK);
@@ -292,7 +320,8 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
 }
 
 template <int ROLE, bool PAIR>
-__device__ __forceinline__ void rowpass_block(const GemmArgs& g, int tiles_n, int ntiles, Tile& lds, double* epi_a) {
+__device__ __forceinline__ void rowpass_block(const GemmArgs& g, int tiles_n, int ntiles, Tile& lds, double* epi_a,
+                                              int* hwinfo = nullptr) {
 
   // ---- which tile / batch / k-range (block b is observed to run on XCD b % 8: speed only) ----------------------------
   int v = blockIdx.x, split = 0;
@@ -336,7 +365,7 @@ __device__ __forceinline__ void rowpass_block(const GemmArgs& g, int tiles_n, in
     ti = v / tcols;
     tj = v - ti * tcols;
   }
-  rowpass_tile<ROLE>(g, tiles_n, ti, tj, split, lds, epi_a);
+  rowpass_tile<ROLE>(g, tiles_n, ti, tj, split, lds, epi_a, hwinfo);
   // Triangular fold (b_tri > 0, the E-step's / predict_f's forward): the k-loop of column tile j starts at j, so the tiles of
   // a row panel do 8, 7, ... 1 eighths of a full tile's work.  In paired mode a block takes column tiles j and
   // tiles_n - 1 - j one after the other: every block does (tiles_n + 1) / tiles_n of a full tile -- equal durations.
@@ -351,7 +380,8 @@ template <int ROLE>
 __global__ __launch_bounds__(NT, 4) void rowpass_gemm_kernel(GemmArgs g, int tiles_n, int ntiles) {
   __shared__ __attribute__((aligned(16))) Tile lds;
   __shared__ __attribute__((aligned(16))) double epi_a[ROLE == 1 ? 128 : 2];
-  rowpass_block<ROLE, false>(g, tiles_n, ntiles, lds, epi_a);
+  __shared__ int hwinfo[ROLE == 2 ? 16 : 1];
+  rowpass_block<ROLE, false>(g, tiles_n, ntiles, lds, epi_a, (ROLE == 2 && g.diag_balance) ? hwinfo : nullptr);
 }
 // the forward contraction against the triangular fold of C, two column tiles per block (see rowpass_block)
 __global__ __launch_bounds__(NT, 4) void rowpass_fold_pair_kernel(GemmArgs g, int tiles_n, int ntiles) {
