@@ -845,7 +845,8 @@ struct hmogp_engine {
           return e ? atoi(e) : -1;
         }();
         // (exact-zero windows: the banded Gram is short; the cap was sized for the dense one)
-        const int cap = cap_env >= 0 ? cap_env : (use_windows ? 0 : std::max(48, 196608 / std::max(1, M)));
+        // (P > 1: more arithmetic per byte -- a block streams 4.8 instead of 6.3 GB/s at P = 2 -- so proportionally more of them)
+        const int cap = cap_env >= 0 ? cap_env : (use_windows ? 0 : std::max(48, (int)(196608.0 * (1.0 + 0.35 * (P - 1)) / std::max(1, M))));
         launch_colstats(Kh.d() + off * M, Pt.d() + off * M, a.d(), valpha.d() + off, valpha0.d() + off, vbeta0.d() + off,
                         X + off * P, P, dZ.d(), ldz, rows, M, 256, want_z, colpart.d() + slab_first * clen, st2, cw, &cb, cap);
       };

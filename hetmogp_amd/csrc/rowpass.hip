@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void quad_kernel(QuadArgs a) {
 
 // ---- colstats: thread = 2 columns, block = 512 columns x `rows` rows ----------------------------------------
 template <int P>
-__global__ __launch_bounds__(256) void colstats_kernel(const double* __restrict__ Kh, const double* __restrict__ Pt,
+__global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restrict__ Kh, const double* __restrict__ Pt,
                                                        const double* __restrict__ a, const double* __restrict__ alpha,
                                                        const double* __restrict__ alpha0, const double* __restrict__ beta0,
                                                        const double* __restrict__ X, const double* __restrict__ Z, int ldz,
