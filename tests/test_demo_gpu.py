@@ -20,3 +20,45 @@ def test_notebook_demo_vem_improves_elbo(capsys):
     assert "VE-step" in out and "VM-step" in out            # util.vem_algorithm reports every half-step, like the reference
     trace = [float(l.split("ELBO = [")[1].rstrip("]\n")) for l in out.splitlines() if "ELBO = [" in l]
     assert len(trace) == 10 and all(b >= a - 1e-6 * abs(a) for a, b in zip(trace, trace[1:]))   # monotone VEM
+
+
+def test_plain_c_program_through_the_abi_matches_the_ctypes_binding(tmp_path):
+    """The boundary is a C ABI: examples/c_abi_demo.c (gcc, include/hetmogp_hip.h, no Python) must print the same ELBO and
+    gradients as the ctypes binding on the same arrays, and its one-rank native exchange must be bit-identical."""
+    import subprocess
+    import numpy as np
+    from hetmogp_amd.engine import Engine
+    exe = str(tmp_path / "c_abi_demo")
+    subprocess.run(["gcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_demo.c"), "-o", exe,
+                    "-L" + os.path.join(ROOT, "hetmogp_amd"), "-lhetmogp_hip", "-Wl,-rpath," + os.path.join(ROOT, "hetmogp_amd"),
+                    "-lm"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    vals = {}
+    for line in r.stdout.splitlines():
+        tok = line.split()
+        if tok and tok[0] in ("elbo", "g_variance", "g_lengthscale"):
+            vals[tok[0]] = [float(x) for x in tok[1:]]
+        elif tok and tok[0].startswith("g_m_u"):
+            vals["mix"] = [float(tok[1]), float(tok[3]), float(tok[5])]
+    assert "native exchange: identical 1" in r.stdout
+    # the same arrays in NumPy
+    M, Q, N0, N1 = 16, 2, 400, 300
+    i0, i1 = np.arange(N0), np.arange(N1)
+    X0, X1 = (i0 + 0.5) / N0, (i1 + 0.25) / N1
+    Y0 = np.sin(7.0 * X0) + 0.25 * np.cos(31.0 * i0)
+    Y1 = (np.sin(5.0 * X1) + 0.3 * np.cos(17.0 * i1) > 0.0).astype(float)
+    m = np.arange(M)[:, None]
+    q = np.arange(Q)[None, :]
+    Z = np.repeat(m / (M - 1.0), Q, axis=1)
+    m_u = 0.5 * np.sin(1.0 + 3.0 * m + q)
+    rr, cc = np.tril_indices(M)
+    L_flat = np.where((rr == cc)[:, None], 1.0, 0.02 * np.cos(1.0 + rr[:, None] + 2.0 * cc[:, None] + q))
+    e = Engine([("Gaussian", {"sigma": 0.5}), ("Bernoulli", {})], Q, M, 1)
+    e.set_data([X0[:, None], X1[:, None]], [Y0, Y1])
+    out = e.elbo_grad(Z=Z, m_u=m_u, L_flat=L_flat, variance=[0.5, 0.7], lengthscale=[0.08, 0.11],
+                      W=[[0.9, -0.4], [0.3, 0.8]], kappa=np.zeros((2, 2)))
+    tol = 1e-12         # same library, same inputs up to libm's last bit in sin / cos on the two sides
+    assert abs(vals["elbo"][0] - out["elbo"]) <= tol * abs(out["elbo"])
+    assert np.allclose(vals["g_variance"], out["g_variance"], rtol=1e-10) and np.allclose(vals["g_lengthscale"], out["g_lengthscale"], rtol=1e-10)
+    assert np.allclose(vals["mix"], [out["g_m_u"].ravel()[0], out["g_L_u"].ravel()[5], out["g_Z"].ravel()[3]], rtol=1e-9, atol=1e-12)
