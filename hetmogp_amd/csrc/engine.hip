@@ -278,6 +278,7 @@ struct hmogp_engine {
   double ms[NCAT] = {0};
   long long launches[NCAT] = {0};
   hipEvent_t ev_begin0 = nullptr, ev_begin1 = nullptr, ev_fin0 = nullptr, ev_fin1 = nullptr;
+  bool st2_masked = false;    // the second stream leaves a few CUs of every XCD to the latency-bound chains (HMOGP_ST2_FREE)
   hipStream_t st2 = nullptr;  // second stream, LOW priority: bandwidth-bound work beside the main stream (K_uf prefetch, colstats)
   hipStream_t st3 = nullptr;  // third stream, HIGH priority like the main one: the q(u)-only chains (S, S^-1; dL/dL, D2H)
   hipEvent_t ev_fork = nullptr, ev_gsk = nullptr, ev_zero = nullptr, ev_info = nullptr, ev_S = nullptr, ev_join = nullptr, ev_col = nullptr, ev_kuf = nullptr, ev_params = nullptr,
@@ -425,14 +426,15 @@ struct hmogp_engine {
       const int nfree = free_env ? atoi(free_env) : 0;
       if (!st2 && nfree > 0 && nfree < 32 && prop.multiProcessorCount == 256) {
         const char* lay = getenv("HMOGP_ST2_LAYOUT");
-        const int layout = lay ? atoi(lay) : 0;
+        const int layout = lay ? atoi(lay) : 1;
+        st2_masked = true;
         std::vector<uint32_t> mask(8, 0xFFFFFFFFu);
         for (int x = 0; x < 8; ++x)
           for (int c = 32 - nfree; c < 32; ++c) {
             const int bit = layout == 0 ? x * 32 + c : c * 8 + x;
             mask[bit / 32] &= ~(1u << (bit % 32));
           }
-        if (hipExtStreamCreateWithCUMask(&st2, (uint32_t)mask.size(), mask.data()) != hipSuccess) st2 = nullptr;
+        if (hipExtStreamCreateWithCUMask(&st2, (uint32_t)mask.size(), mask.data()) != hipSuccess) st2 = nullptr, st2_masked = false;
       }
       if (!st2) HIP_TRY(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, lo));
       HIP_TRY(hipStreamCreateWithPriority(&st3, hipStreamNonBlocking, hi));
@@ -754,7 +756,7 @@ struct hmogp_engine {
         const char* e = getenv("HMOGP_KUF_CHUNK");
         return e ? atoll(e) : 0LL;
       }();
-      const long long step = (stream != st && !use_windows) ? (chunk_env > 0 ? chunk_env : KUF_CHUNK_ROWS) : sg.n;
+      const long long step = (stream != st && !use_windows) ? (chunk_env > 0 ? chunk_env : (st2_masked ? 100000LL : KUF_CHUNK_ROWS)) : sg.n;
       for (long long r = 0; r < sg.n; r += step)
         launch_rbf(Xs + r * P, P, std::min(step, sg.n - r), P, dZ.d(), ldz, M, 0.0, 1.0, Kh.d() + (sg.off + r) * M, false, stream,
                    rw, false, &rbt);
