@@ -279,7 +279,8 @@ def test_bench_self_launches_two_ranks():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and sum(line["rows_per_rank"]) == 4 * 20000
     assert line["allreduce_ms_per_step"] > 0.0 and line["reducer_mode"] == "native"
-    assert set(line["exchange_modes_ms_per_step"]) >= {"native", "device"}
+    assert "native" in line["exchange_modes_ms_per_step"]          # ("device" is timed too wherever torch can alias the buffer)
+    assert len(line["replicated_ms_per_rank"]) == 2
 
 
 def _facade_nccl_worker(rank, world, port, q):
