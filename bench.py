@@ -139,10 +139,12 @@ def main():
     reducer = hdist.StatsReducer(eng, device=local_rank) if world > 1 else None
 
     def step(red=reducer):
-        # world > 1, default: the engine holds its own RCCL communicator ("native") and hmogp_elbo_grad IS the sharded step
+        # world > 1, default: the engine holds its own RCCL communicator ("native") and hmogp_elbo_grad_sharded IS the step
         # (row pass -> pack / ncclAllReduce / unpack on the engine's stream -> replicated finish, one host sync at the end)
-        if world == 1 or red.mode == "native":
+        if world == 1:
             return eng.elbo_grad(**prm)
+        if red.mode == "native":
+            return eng.elbo_grad(sharded=True, **prm)
         eng.step_begin(**prm)
         red()
         return eng.step_finish()

@@ -78,7 +78,7 @@ int main(void) {
     const double elbo_plain = elbo, g5 = g_L_u[5];
     CHECK(hmogp_comm_unique_id(id));
     CHECK(hmogp_comm_init(h, 1, 0, id));
-    CHECK(hmogp_elbo_grad(h, &prm, &out));
+    CHECK(hmogp_elbo_grad_sharded(h, &prm, &out));
     double ms[HMOGP_NTIMINGS];
     CHECK(hmogp_last_timings(h, ms, NULL));
     printf("native exchange: identical %d, %.3f ms on the engine's stream\n", elbo == elbo_plain && g_L_u[5] == g5, ms[8]);

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMOGP_LIB_PATH") or os.path.join(_HERE, "libhetmogp_hip.so")   # (override: A/B experiments)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 # likelihood ids (class names of the reference's likelihoods/<name>.py)
 LIK_GAUSSIAN, LIK_BERNOULLI, LIK_HETGAUSSIAN, LIK_CATEGORICAL, LIK_POISSON, LIK_EXPONENTIAL, LIK_GAMMA, LIK_BETA = range(8)
 LIK_IDS_BY_NAME = dict(Gaussian=0, Bernoulli=1, HetGaussian=2, Categorical=3, Poisson=4, Exponential=5, Gamma=6, Beta=7)
@@ -74,6 +74,7 @@ EXPORTS = {
     "hmogp_comm_destroy": (C.c_int, [C.c_void_p]),
     "hmogp_comm_info": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),
     "hmogp_step_exchange": (C.c_int, [C.c_void_p]),
+    "hmogp_elbo_grad_sharded": (C.c_int, [C.c_void_p, C.POINTER(Params), C.POINTER(Outputs)]),
     "hmogp_stats_read": (C.c_int, [C.c_void_p, c_double_p]),
     "hmogp_stats_write": (C.c_int, [C.c_void_p, c_double_p]),
     "hmogp_wire_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_int64_p]),

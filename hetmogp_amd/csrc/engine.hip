@@ -18,8 +18,36 @@
 #include <string>
 #include <vector>
 
+#include <chrono>
+#include <thread>
+
 #include <dlfcn.h>
-#include <rccl/rccl.h>   // types and prototypes only: the library is resolved at run time (dlopen), see RcclApi
+#include <hip/hip_runtime.h>
+// RCCL is a RUN-TIME dependency only (dlopen, see RcclApi): the few types and constants of its C API this file needs are
+// declared here, so the single-GPU library builds on a ROCm install without the rccl development headers.  Where the header
+// exists the local declarations are checked against it.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+}
+namespace hm_nccl {
+struct UniqueId { char internal[128]; };
+enum : int { Success = 0, InProgress = 7, DataDouble = 8, OpSum = 0 };
+using GetUniqueId = int (*)(UniqueId*);
+using CommInitRank = int (*)(ncclComm_t*, int, UniqueId, int);
+using CommDestroy = int (*)(ncclComm_t);
+using CommAbort = int (*)(ncclComm_t);
+using CommGetAsyncError = int (*)(ncclComm_t, int*);
+using AllReduce = int (*)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t);
+using GetErrorString = const char* (*)(int);
+}  // namespace hm_nccl
+#if defined(__has_include)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+static_assert(sizeof(ncclUniqueId) == sizeof(hm_nccl::UniqueId), "ncclUniqueId size");
+static_assert((int)ncclSuccess == hm_nccl::Success && (int)ncclInProgress == hm_nccl::InProgress &&
+              (int)ncclDouble == hm_nccl::DataDouble && (int)ncclSum == hm_nccl::OpSum, "RCCL enum values");
+#endif
+#endif
 
 #include "../../include/hetmogp_hip.h"
 #include "common.h"
@@ -188,11 +216,13 @@ void jitchol_batched(const double* Kuu, double* Luu, int Q, int M, const double*
 // bundles one) dlopen() by soname returns THAT copy, so the library owns exactly one RCCL per process.
 struct RcclApi {
   void* lib = nullptr;
-  decltype(&ncclGetUniqueId) getUniqueId = nullptr;
-  decltype(&ncclCommInitRank) commInitRank = nullptr;
-  decltype(&ncclCommDestroy) commDestroy = nullptr;
-  decltype(&ncclAllReduce) allReduce = nullptr;
-  decltype(&ncclGetErrorString) getErrorString = nullptr;
+  hm_nccl::GetUniqueId getUniqueId = nullptr;
+  hm_nccl::CommInitRank commInitRank = nullptr;
+  hm_nccl::CommDestroy commDestroy = nullptr;
+  hm_nccl::CommAbort commAbort = nullptr;                   // optional (old builds): the watchdog degrades to an error return
+  hm_nccl::CommGetAsyncError commGetAsyncError = nullptr;   // optional
+  hm_nccl::AllReduce allReduce = nullptr;
+  hm_nccl::GetErrorString getErrorString = nullptr;
   std::string why;
   bool ok() const { return lib != nullptr; }
 };
@@ -212,6 +242,8 @@ RcclApi& rccl() {
     a.commDestroy = (decltype(a.commDestroy))dlsym(a.lib, "ncclCommDestroy");
     a.allReduce = (decltype(a.allReduce))dlsym(a.lib, "ncclAllReduce");
     a.getErrorString = (decltype(a.getErrorString))dlsym(a.lib, "ncclGetErrorString");
+    a.commAbort = (decltype(a.commAbort))dlsym(a.lib, "ncclCommAbort");
+    a.commGetAsyncError = (decltype(a.commGetAsyncError))dlsym(a.lib, "ncclCommGetAsyncError");
     if (!a.getUniqueId || !a.commInitRank || !a.commDestroy || !a.allReduce || !a.getErrorString) {
       a.why = "librccl is missing one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce";
       a.lib = nullptr;
@@ -222,8 +254,8 @@ RcclApi& rccl() {
 }
 #define RCCL_TRY(expr)                                                                               \
   do {                                                                                               \
-    ncclResult_t _r = (expr);                                                                        \
-    if (_r != ncclSuccess)                                                                           \
+    int _r = (expr);                                                                                 \
+    if (_r != hm_nccl::Success)                                                                           \
       throw EngineError{HMOGP_E_COMM, std::string("RCCL: ") + rccl().getErrorString(_r) + " in " #expr}; \
   } while (0)
 
@@ -339,7 +371,7 @@ struct hmogp_engine {
     RcclApi& r = rccl();
     if (!r.ok()) throw EngineError{HMOGP_E_COMM, "librccl not available: " + r.why};
     HIP_TRY(hipSetDevice(device));
-    ncclUniqueId uid;
+    hm_nccl::UniqueId uid;
     std::memcpy(&uid, id, sizeof uid);
     wire.ensure(sizeof(double) * nwire, true);   // allocated (and zeroed) before the first collective, outside any timing
     RCCL_TRY(r.commInitRank(&comm, nranks, uid, rank));
@@ -352,6 +384,46 @@ struct hmogp_engine {
     (void)rccl().commDestroy(comm);
     comm = nullptr, comm_ranks = 1, comm_rank = 0;
   }
+  // A rank that cannot contribute to the step's collective (its row pass failed: HIP OOM, bad row range, E_STATE ...) ABORTS
+  // the communicator, so that the peers' ncclAllReduce ends with an error instead of blocking for ever; the engine
+  // is left without a communicator (hmogp_comm_info: 0 ranks) and every later sharded call fails with HMOGP_E_STATE.
+  void comm_abort() {
+    if (!comm) return;
+    RcclApi& r = rccl();
+    if (r.commAbort) (void)r.commAbort(comm);
+    else (void)r.commDestroy(comm);
+    comm = nullptr, comm_ranks = 1, comm_rank = 0;
+  }
+  // Wait for the engine's stream while a collective is in flight: the torch path this replaces has a watchdog, RCCL alone has
+  // none.  Polls the stream, the communicator's asynchronous error state and a deadline (HMOGP_COMM_TIMEOUT_S, default 600 s;
+  // 0 = wait for ever); on either failure the communicator is aborted and HMOGP_E_COMM is reported.
+  void wait_exchanged() {
+    static const double limit_s = [] {
+      const char* e = getenv("HMOGP_COMM_TIMEOUT_S");
+      return e ? atof(e) : 600.0;
+    }();
+    RcclApi& r = rccl();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long long spin = 0;; ++spin) {
+      const hipError_t q = hipStreamQuery(st);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) throw HipError{q, "hipStreamQuery(st)", __FILE__, __LINE__};
+      if ((spin & 1023) == 1023 && comm) {
+        int async = hm_nccl::Success;
+        if (r.commGetAsyncError && r.commGetAsyncError(comm, &async) == hm_nccl::Success && async != hm_nccl::Success &&
+            async != hm_nccl::InProgress) {
+          comm_abort();
+          throw EngineError{HMOGP_E_COMM, std::string("RCCL: asynchronous error in the exchange step: ") + r.getErrorString(async)};
+        }
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (limit_s > 0.0 && el > limit_s) {
+          comm_abort();
+          throw EngineError{HMOGP_E_COMM, "the exchange step did not complete within HMOGP_COMM_TIMEOUT_S (a peer rank is missing?): communicator aborted"};
+        }
+        if (el > 0.05) std::this_thread::sleep_for(std::chrono::microseconds(200));
+      }
+    }
+  }
   // pack -> ncclAllReduce(sum, fp64, in place on the wire buffer) -> unpack, all ENQUEUED on the engine's stream: no host
   // synchronisation, no other library's stream.  The wire format holds the lower triangles of H_q only (12.7 MB instead
   // of 25.2 MB at M = 1024, Q = 3).
@@ -362,7 +434,7 @@ struct hmogp_engine {
     HIP_TRY(hipSetDevice(device));
     Scope sc(this, CAT_EXCHANGE, 3);
     launch_wire_copy(stats.d(), wire.d(), NG, Q, M, per_q, 0, st);
-    RCCL_TRY(rccl().allReduce(wire.p, wire.p, (size_t)nwire, ncclDouble, ncclSum, comm, st));
+    RCCL_TRY(rccl().allReduce(wire.p, wire.p, (size_t)nwire, hm_nccl::DataDouble, hm_nccl::OpSum, comm, st));
     launch_wire_copy(stats.d(), wire.d(), NG, Q, M, per_q, 1, st);
     exchanged = true;
   }
@@ -1034,6 +1106,7 @@ struct hmogp_engine {
     if (out->g_L_u && !qu) std::memset(out->g_L_u, 0, sizeof(double) * Mtri * Q);
     if (out->dL_dS) HIP_TRY(hipMemcpyAsync(out->dL_dS, dLdS.p, sizeof(double) * MM * Q, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(ev_fin1, st));
+    if (exchanged && comm) wait_exchanged();          // a collective is in flight: watchdog instead of a blind wait
     HIP_TRY(hipStreamSynchronize(st));
     collect_spans();
     float f0 = 0.f, f1 = 0.f;
@@ -1444,8 +1517,8 @@ int hmogp_comm_unique_id(void* id128) {
   return guarded(nullptr, [&] {
     RcclApi& r = rccl();
     if (!r.ok()) throw EngineError{HMOGP_E_COMM, "librccl not available: " + r.why};
-    static_assert(sizeof(ncclUniqueId) == HMOGP_COMM_ID_BYTES, "ncclUniqueId size");
-    ncclUniqueId uid;
+    static_assert(sizeof(hm_nccl::UniqueId) == HMOGP_COMM_ID_BYTES, "ncclUniqueId size");
+    hm_nccl::UniqueId uid;
     RCCL_TRY(r.getUniqueId(&uid));
     std::memcpy(id128, &uid, sizeof uid);
   });
@@ -1480,9 +1553,23 @@ int hmogp_step_finish(hmogp_handle h, hmogp_outputs* out) {
 
 int hmogp_elbo_grad(hmogp_handle h, const hmogp_params* p, hmogp_outputs* out) {
   if (!h) return HMOGP_E_INVALID;
-  return guarded(h, [&] {
+  return guarded(h, [&] {       // single device, NEVER a collective -- also with a communicator attached (debug / parity calls)
     h->begin(p, false);
-    if (h->comm) h->exchange();   // row-sharded run: the one collective of the path, enqueued between the two halves
+    h->finish(out);
+  });
+}
+
+int hmogp_elbo_grad_sharded(hmogp_handle h, const hmogp_params* p, hmogp_outputs* out) {
+  if (!h) return HMOGP_E_INVALID;
+  return guarded(h, [&] {
+    if (!h->comm) throw EngineError{HMOGP_E_STATE, "hmogp_elbo_grad_sharded without a communicator (hmogp_comm_init)"};
+    try {
+      h->begin(p, false);
+      h->exchange();            // the one collective of the path, enqueued between the two halves on the engine's stream
+    } catch (...) {
+      h->comm_abort();          // this rank cannot contribute: the peers must fail, not hang
+      throw;
+    }
     h->finish(out);
   });
 }

@@ -59,6 +59,19 @@ def all_agree(ok, group=None, device=0):
     return bool(int(t.item()) == 1)
 
 
+def agree_min_max(value, group=None, device=0):
+    """(min, max) of an integer over the ranks of `group`: two all-reduces issued unconditionally by every rank."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return int(value), int(value)
+    lo = torch.tensor([int(value)], dtype=torch.int32, device=_flag_device(group, device))
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return int(lo.item()), int(hi.item())
+
+
 def attach_native_comm(engine, group=None, device=0, api=None):
     """Give `engine` its own RCCL communicator spanning the ranks of `group` (hmogp_comm_init): rank 0 draws the
     ncclUniqueId through the library, torch.distributed only carries those 128 bytes.  Collective; returns True on
@@ -110,8 +123,8 @@ class StatsReducer(object):
 
     `mode=None` picks the best mode EVERY rank can do: each candidate is probed locally and the outcome is agreed on with
     a MIN all-reduce of a flag (`all_agree`), so ranks cannot diverge; nothing is decided by catching an exception inside
-    the step.  `last_ms` = host wall milliseconds of the last exchange (for "native": host time to enqueue it; the device
-    time is category "exchange" of Engine.timings()), `n_calls` = exchanges so far."""
+    the step.  `last_ms` = host wall milliseconds of the last exchange (for "native": the DEVICE time of pack + all-reduce + unpack,
+    category "exchange" of Engine.timings(), also when the step went through `sharded_elbo_grad`'s fused call), `n_calls` = exchanges so far."""
 
     def __init__(self, engine, device=0, mode=None, group=None, native_api=None):
         import torch
@@ -135,13 +148,21 @@ class StatsReducer(object):
                 if not dist.is_initialized():
                     raise RuntimeError("StatsReducer(mode='native') needs an initialised torch.distributed group to carry "
                                        "the ncclUniqueId (or attach the communicator yourself: Engine.comm_init)")
-                have = engine.comm_info()[0] == self.world
-                if all_agree(have, group, self.device):                     # the caller attached one on every rank
+                # Collective-safe: EVERY rank issues the same two flag reductions whatever its local state is,
+                # and the branch is taken on the AGREED values only.  state 2 = a communicator spanning the group is already
+                # attached, 1 = none attached (one can be created), 0 = something else (wrong size): not usable.
+                n_attached = engine.comm_info()[0]
+                state = 2 if n_attached == self.world else (1 if n_attached == 0 else 0)
+                lo, hi = agree_min_max(state, group, self.device)
+                if lo == 2:                                                  # the caller attached one on every rank
                     self.mode = "native"
-                elif not have and all_agree(engine.comm_info()[0] == 0, group, self.device) and \
-                        attach_native_comm(engine, group, self.device, native_api):
-                    self.owns_comm = True
-                    self.mode = "native"
+                elif lo == 1 and hi == 1:                                    # nobody has one: create it (collective)
+                    if attach_native_comm(engine, group, self.device, native_api):
+                        self.owns_comm = True
+                        self.mode = "native"
+                elif mode == "native":                                       # mixed states: same verdict on every rank
+                    raise RuntimeError("StatsReducer(mode='native'): communicators are attached on some ranks only "
+                                       "(states %d..%d); attach on all ranks or on none" % (lo, hi))
             elif cand == "device":
                 # The engine allocates with the HIP runtime of the process, torch wraps the pointer: aliasing works on the
                 # configurations tested (tests/test_dist_gpu.py) but neither library promises it -- probe it with a real
@@ -214,8 +235,11 @@ def sharded_elbo_grad(engine, reducer, rank, world, row_begin=None, row_end=None
     rb, re = shard_ranges(row_begin, row_end, rank, world)
     if reducer is not None and reducer.mode == "native":
         # the library holds the communicator: one call = begin -> all-reduce on the engine's stream -> finish
+        out = engine.elbo_grad(want_dL_dS=want_dL_dS, row_begin=rb, row_end=re, sharded=True, **params)
+        reducer.last_ms = float(engine.timings()[0].get("exchange", 0.0))   # device time of pack + all-reduce + unpack
+        reducer.total_ms += reducer.last_ms
         reducer.n_calls += 1
-        return engine.elbo_grad(want_dL_dS=want_dL_dS, row_begin=rb, row_end=re, **params)
+        return out
     engine.step_begin(row_begin=rb, row_end=re, **params)
     if reducer is not None:
         reducer()

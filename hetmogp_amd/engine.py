@@ -194,12 +194,15 @@ class Engine(object):
         return res
 
     # ------------------------------------------------------------------------------------------ hot path
-    def elbo_grad(self, want_dL_dS=False, **params):
+    def elbo_grad(self, want_dL_dS=False, sharded=False, **params):
         """One ``parameters_changed()``: returns dict(elbo, KL, kl [Q], g_m_u, g_L_u, g_variance, g_lengthscale, g_W,
-        g_kappa, g_Z, rungs, v_negative[, dL_dS])."""
+        g_kappa, g_Z, rungs, v_negative[, dL_dS]).  `sharded=True` = hmogp_elbo_grad_sharded: the row-sharded step of a
+        multi-GPU run (begin on this rank's rows -> in-library all-reduce -> finish), COLLECTIVE over the ranks of the
+        communicator attached with `comm_init`; the default never communicates."""
         p, keep = self._params(**params)
         c, o = self._outputs(want_dL_dS, skip_qu=params.get("m_u") is None)
-        check(lib.hmogp_elbo_grad(self._h, C.byref(p), C.byref(c)), self._h)
+        fn = lib.hmogp_elbo_grad_sharded if sharded else lib.hmogp_elbo_grad
+        check(fn(self._h, C.byref(p), C.byref(c)), self._h)
         return self._wrap(o)
 
     def step_begin(self, **params):
@@ -247,7 +250,7 @@ class Engine(object):
     # ------------------------------------------------------------------------------------------ native exchange
     def comm_init(self, nranks, rank, unique_id):
         """Attach an RCCL communicator (collective: every rank, same `unique_id` from `comm_unique_id()` of ONE rank).
-        From then on `elbo_grad` is the row-sharded step: begin -> in-library all-reduce -> finish."""
+        From then on `elbo_grad(sharded=True)` is the row-sharded step: begin -> in-library all-reduce -> finish."""
         uid = bytes(unique_id)
         if len(uid) != _lib.COMM_ID_BYTES:
             raise ValueError("unique_id must be %d bytes" % _lib.COMM_ID_BYTES)
@@ -338,6 +341,21 @@ class Engine(object):
         return dict(zip(names, ms.tolist())), dict(zip(names, n.tolist()))
 
 
+_DEFAULT_DEVICE = 0
+
+
+def set_default_device(device):
+    """HIP device of the stand-alone building blocks below (var_exp, predictive, sample, gemm ...) when they are called
+    without `device=`: a rank of a multi-GPU run sets it to its LOCAL_RANK once (SVMOGP(distributed=True) does), so that
+    likelihood-level helpers never land on GPU 0 from every rank."""
+    global _DEFAULT_DEVICE
+    _DEFAULT_DEVICE = int(device)
+
+
+def _resolve_device(device):
+    return _DEFAULT_DEVICE if device is None else int(device)
+
+
 def comm_available():
     """True if the library can load librccl (needed only for multi-GPU runs)."""
     return bool(lib.hmogp_comm_available())
@@ -351,8 +369,9 @@ def comm_unique_id():
 
 
 # ---------------------------------------------------------------------------------------------- building blocks
-def rbf_cross_cov(X, Z, variance, lengthscale, device=0, exact=True):
+def rbf_cross_cov(X, Z, variance, lengthscale, device=None, exact=True):
     """K = k(X, Z).  exact=True: GPy's rounding order (the K_uu variant); exact=False: the hot-path K_uf variant."""
+    device = _resolve_device(device)
     X, Z = _f64(X), _f64(Z)
     X = X.reshape(X.shape[0], -1)
     Z = Z.reshape(Z.shape[0], -1)
@@ -362,7 +381,8 @@ def rbf_cross_cov(X, Z, variance, lengthscale, device=0, exact=True):
     return K
 
 
-def jitchol_inv(A, forced_rung=None, device=0):
+def jitchol_inv(A, forced_rung=None, device=None):
+    device = _resolve_device(device)
     A = _f64(A)
     Q, M = A.shape[0], A.shape[1]
     L, Ai = np.zeros_like(A), np.zeros_like(A)
@@ -373,14 +393,16 @@ def jitchol_inv(A, forced_rung=None, device=0):
     return L, Ai, [int(r) for r in rung]
 
 
-def potri(L, device=0):
+def potri(L, device=None):
+    device = _resolve_device(device)
     L = _f64(L)
     out = np.zeros_like(L)
     check(lib.hmogp_potri(device, _p(L), L.shape[0], L.shape[1], _p(out)))
     return out
 
 
-def gemm(A, B, transA=False, transB=False, alpha=1.0, beta=0.0, C0=None, device=0):
+def gemm(A, B, transA=False, transB=False, alpha=1.0, beta=0.0, C0=None, device=None):
+    device = _resolve_device(device)
     A, B = _f64(A), _f64(B)
     M, K = (A.shape[1], A.shape[0]) if transA else A.shape
     N = B.shape[0] if transB else B.shape[1]
@@ -390,7 +412,8 @@ def gemm(A, B, transA=False, transB=False, alpha=1.0, beta=0.0, C0=None, device=
     return Cm
 
 
-def var_exp(name, y, m, v, device=0, quirks="reference", **kw):
+def var_exp(name, y, m, v, device=None, quirks="reference", **kw):
+    device = _resolve_device(device)
     y, m, v = _f64(y).reshape(-1), _f64(m), _f64(v)
     J = lik_dim_f(name, **kw)
     m, v = m.reshape(-1, J), v.reshape(-1, J)
@@ -400,8 +423,9 @@ def var_exp(name, y, m, v, device=0, quirks="reference", **kw):
     return ve, dm, dv
 
 
-def predictive(name, m, v, gh_T=0, device=0, **kw):
+def predictive(name, m, v, gh_T=0, device=None, **kw):
     """`<likelihood>.predictive(m, v)`: predictive mean / variance of y (N, dim_p)."""
+    device = _resolve_device(device)
     m, v = _f64(m), _f64(v)
     J = lik_dim_f(name, **kw)
     m, v = m.reshape(-1, J), v.reshape(-1, J)
@@ -412,8 +436,9 @@ def predictive(name, m, v, gh_T=0, device=0, **kw):
     return mean, var
 
 
-def log_predictive_rows(name, y, m, v, num_samples=1000, seed=0, device=0, **kw):
+def log_predictive_rows(name, y, m, v, num_samples=1000, seed=0, device=None, **kw):
     """Per-row Monte-Carlo log predictive density: -log S + logsumexp_s log p(y_n | f_s), f_s ~ N(m_n, diag v_n)."""
+    device = _resolve_device(device)
     y, m, v = _f64(y).reshape(-1), _f64(m), _f64(v)
     J = lik_dim_f(name, **kw)
     m, v = m.reshape(-1, J), v.reshape(-1, J)
@@ -423,8 +448,9 @@ def log_predictive_rows(name, y, m, v, num_samples=1000, seed=0, device=0, **kw)
     return out
 
 
-def sample(name, F, seed=0, device=0, **kw):
+def sample(name, F, seed=0, device=None, **kw):
     """One draw y ~ p(y | F[n]) per row on the device (the reference's `<likelihood>.samples`): returns (N, 1)."""
+    device = _resolve_device(device)
     J = lik_dim_f(name, **kw)
     F = _f64(F).reshape(-1, J)
     Y = np.zeros(F.shape[0])

@@ -140,6 +140,8 @@ class SVMOGP(object):
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0")) if distributed else 0
         self._device = int(device)
+        from .engine import set_default_device
+        set_default_device(self._device)           # stand-alone likelihood helpers (predictive, samples ...) follow the model
         self.name = name
         self.gradients_of_fixed = bool(gradients_of_fixed)
         self.batch_size = batch_size
@@ -486,12 +488,16 @@ class SVMOGP(object):
         post = self._ensure_posteriors()[q]
         b = 0 if route == "reference" else q
         Zq = self.Z.values[:, b * self.Xdim:(b + 1) * self.Xdim]
-        Kx = kern.K(Zq, np.asarray(Xnew, dtype=float).reshape(-1, self.Xdim))
-        mu = Kx.T @ post.woodbury_vector
+        from .engine import gemm
+        dev = self._engine_device()
+        Kx = kern.K(Zq, np.asarray(Xnew, dtype=float).reshape(-1, self.Xdim))       # on the device (hmogp_rbf_cross_cov)
+        wv = np.asarray(post.woodbury_vector, dtype=float).reshape(Kx.shape[0], -1)
+        mu = gemm(Kx, wv, transA=True, device=dev)                                  # every product: hmogp_gemm_f64 (FP64 MFMA)
+        WK = gemm(np.asarray(post.woodbury_inv, dtype=float), Kx, device=dev)
         if full_cov:
-            var = kern.K(Xnew) - Kx.T @ post.woodbury_inv @ Kx
+            var = kern.K(Xnew) - gemm(Kx, WK, transA=True, device=dev)
         else:
-            var = (kern.Kdiag(Xnew) - np.sum((post.woodbury_inv @ Kx) * Kx, 0))[:, None]
+            var = (kern.Kdiag(Xnew) - np.sum(WK * Kx, 0))[:, None]
         return mu, np.abs(var)
 
     def predictive_new(self, Xnew, output_function_ind=None, kern_list=None):
@@ -580,7 +586,8 @@ class SVMOGP(object):
             v_F.append(v)
         if route == "reference":
             from .engine import predictive as lik_predictive
-            out = [lik_predictive(l.name, m_F[t], v_F[t], gh_T=10 if l.name in ("Gamma", "Beta") else 0, **l.kwargs())
+            out = [lik_predictive(l.name, m_F[t], v_F[t], gh_T=10 if l.name in ("Gamma", "Beta") else 0,
+                                  device=self._engine_device(), **l.kwargs())
                    for t, l in enumerate(self.likelihood.likelihoods_list)]
             return [o[0] for o in out], [o[1] for o in out]
         return self.likelihood.predictive(m_F, v_F, self.Y_metadata)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMOGP_ABI_VERSION 4
+#define HMOGP_ABI_VERSION 5
 
 /* likelihood ids (class names of /root/reference/likelihoods/<name>.py) */
 enum {
@@ -204,8 +204,14 @@ int hmogp_wire_write(hmogp_handle h, const double* host /* [count] */);
  *   hmogp_comm_init        ncclCommInitRank on the engine's device; collective: every rank calls it with the same id
  *   hmogp_comm_destroy     ncclCommDestroy (also done by hmogp_destroy)
  *   hmogp_comm_info        nranks / rank of the attached communicator (0 / -1 without one)
- * With a communicator, hmogp_elbo_grad IS the row-sharded step (begin -> exchange -> finish, one call, one final host
- * synchronisation); hmogp_step_exchange is the middle part for callers that keep the three-call form.  The exchange is
+ * hmogp_elbo_grad_sharded (ABI v5) IS the row-sharded step: begin on this rank's rows -> exchange -> finish, one call, one
+ * final host synchronisation; COLLECTIVE -- every rank of the communicator must call it.  hmogp_elbo_grad itself never
+ * communicates, also with a communicator attached (ABI v4 keyed the collective on the communicator's presence: a debug
+ * call on one rank would then block its peers).  hmogp_step_exchange is the middle part for callers that keep the
+ * three-call form.  Failure semantics: a rank whose row pass fails before it could contribute ABORTS the communicator
+ * (ncclCommAbort) so that the peers' collective ends with HMOGP_E_COMM instead of blocking; while a collective is in
+ * flight the final wait polls ncclCommGetAsyncError and a deadline (environment HMOGP_COMM_TIMEOUT_S, default 600,
+ * 0 = none) and aborts the communicator on either.  After an abort hmogp_comm_info reports 0 ranks.  The exchange is
  * category [8] of hmogp_last_timings.  A communicator of ONE rank runs the same three launches (used by the tests).   */
 #define HMOGP_COMM_ID_BYTES 128
 int hmogp_comm_available(void);
@@ -214,6 +220,7 @@ int hmogp_comm_init(hmogp_handle h, int32_t nranks, int32_t rank, const void* id
 int hmogp_comm_destroy(hmogp_handle h);
 int hmogp_comm_info(hmogp_handle h, int32_t* nranks, int32_t* rank);
 int hmogp_step_exchange(hmogp_handle h);
+int hmogp_elbo_grad_sharded(hmogp_handle h, const hmogp_params* p, hmogp_outputs* out);
 
 /* ---- posterior / prediction (consumers: svmogp.py:238-251, 280-306) --------------------------------- */
 /* woodbury_vector[q] = Kuu^-1 m_q  [Q, M];  woodbury_inv[q] = Kuu^-1 - Kuu^-1 S_q Kuu^-1  [Q, M, M]

@@ -14,6 +14,9 @@ Fixture families:
   model_<case>.npz  G6  assembled parameter gradients from the reference's own
                         SVMOGP.parameters_changed (svmogp.py:85-166) run over the stand-in's
                         RESTATED GPy RBF gradient formulas ("GPy-unpinned").
+  ref_<case>.npz    N1  REAL-SIZE runs of the reference's own SVMOGP.parameters_changed + SVMOGPInf.inference (C1 exactly:
+                        N_t = 1000, M = 50, Q = 2; multi-tile M = 128 / 144 / 160): ELBO, KL, q(f_d), dL_dmu_u, dL_dL_u, dL_dKmm
+                        and the assembled parameter gradients; the Q*Df dense M x N `dL_dKmn` blocks are NOT stored (size).
   mpred_<case>.npz  f2  model-level prediction through the reference's own SVMOGP methods (svmogp.py:219-351):
                         predictive_new, _raw_predict_f, _raw_predict_stochastic, _raw_predict, predictive, at tiny N
                         (the _raw_predict_f route factorises the N x N K_ff of the TRAINING inputs).  Relies on the
@@ -405,15 +408,112 @@ def gen_model_predict(stand, util, hl, svmogp, liks):
               "max |predictive_new - raw_predict_f| d=0", float(np.max(np.abs(out["pn_m_0"] - out["rf_m_0"]))))
 
 
+# ----------------------------------------------------------------------- N1: the reference itself at real sizes
+C4_MIX = [("HetGaussian", {}), ("Categorical", {"K": 5}), ("Beta", {}), ("Exponential", {}), ("Gaussian", {"sigma": 0.5}),
+          ("Bernoulli", {}), ("Poisson", {}), ("Gamma", {})]
+H_MIX = [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {}), ("Poisson", {}), ("Gamma", {})]
+REF_CASES = [
+    # tag, likelihood specs, N_t, M, Q, P, c (lengthscale / inducing spacing), batch_size (None = full batch), vem_step
+    ("c1_exact", [("HetGaussian", {}), ("Bernoulli", {}), ("Categorical", {"K": 3})], [1000, 1000, 1000], 50, 2, 1,
+     (0.8, 1.2), None, True),                                   # BASELINE config 1 at its exact size (README.md:31)
+    ("h_mix_M128", H_MIX, [400, 383, 417, 350], 128, 3, 1, (0.8, 1.0, 1.3), None, True),   # specialised 128-tile kernels
+    ("c4_mix_M160", C4_MIX, [230, 200, 217, 160, 256, 190, 240, 129], 160, 4, 1, (0.8, 1.0, 1.3, 1.1), None, True),
+    ("c5_2d_M144", [("Categorical", {"K": 4}), ("Gaussian", {"sigma": 0.5})], [420, 500], 144, 2, 2, (0.9, 1.2), None, True),
+    ("h_mix_M128_svi_M", H_MIX, [400, 383, 417, 350], 128, 3, 1, (0.8, 1.0, 1.3), 96, False),  # minibatch M-step, scales
+]
+
+
+def gen_reference_real_sizes(stand, inf, util, hl, svmogp, liks):
+    """Row N1 of VERDICT r3: the reference's own `SVMOGP.parameters_changed` (svmogp.py:85-166) and
+    `SVMOGPInf.inference` (svmogp_inf.py:23-109) run at BASELINE config 1's real size and at multi-tile M."""
+    import random
+    import time
+    for k, (tag, specs, Ns, M, Q, P, cs, batch_size, vem_step) in enumerate(REF_CASES):
+        rng = np.random.RandomState(700 + k)
+        c = build_case(rng, specs, Ns, M, Q, P, cs, False, False)
+        T = len(specs)
+        likelihood = hl.HetLikelihood([make_lik(liks, s) for s in specs])
+        Y_metadata = likelihood.generate_metadata()
+        Df = likelihood.num_output_functions(Y_metadata)
+        kern_list = util.latent_functions_prior(Q, lenghtscale=c["lengthscale"], variance=c["variance"], input_dim=P)
+        W_list = [c["W"][q][:, None].copy() for q in range(Q)]
+        np.random.seed(2468 + k)
+        random.seed(135 + k)
+        model = svmogp.SVMOGP(X=c["X"], Y=c["Y"], Z=c["Z"][:, :P].copy(), kern_list=kern_list, likelihood=likelihood,
+                              Y_metadata=Y_metadata, batch_size=batch_size, W_list=W_list)
+        model.q_u_means[...] = c["m_u"]
+        model.q_u_chols[...] = c["L_flat"]
+        model.Z[...] = c["Z"]
+        model.vem_step = vem_step
+        captured = {}
+        real_inference = model.inference_method.inference
+
+        def spy(*a, **kw):
+            r = real_inference(*a, **kw)
+            captured["elbo"], captured["grads"] = r[0], r[1]
+            return r
+        model.inference_method.inference = spy
+        t0 = time.time()
+        model.parameters_changed()
+        dt = time.time() - t0
+        model.inference_method.inference = real_inference
+        grads = captured["grads"]
+        Xb, Yb = model.Xmulti, model.Ymulti
+        Kuu, Luu, Kuui = util.latent_funs_cov(c["Z"], kern_list)
+        p_U = inf.pu(Kuu=Kuu, Luu=Luu, Kuui=Kuui)
+        q_U = inf.qu(mu_u=c["m_u"], chols_u=c["L_flat"])
+        f_index = Y_metadata["function_index"].flatten()
+        out = {}
+        for d in range(Df):
+            Xt = Xb[f_index[d]]
+            qf = model.inference_method.calculate_q_f(X=Xt, Z=c["Z"], q_U=q_U, p_U=p_U, kern_list=kern_list,
+                                                      B=model.B_list, M=M, N=Xt.shape[0], Q=Q, D=Df, d=d)
+            out["m_fd_%d" % d] = qf.m_fd
+            out["v_fd_%d" % d] = qf.v_fd
+        out["KL"] = np.asarray(model.inference_method.calculate_KL(q_U=q_U, p_U=p_U, M=M, Q=Q)).reshape(1, 1)
+        for q in range(Q):
+            if batch_size is not None:      # full batch: identical to g_m_u / g_L_u below (svmogp.py:111-112), not stored twice
+                out["dL_dmu_u_%d" % q] = grads["dL_dmu_u"][q]
+                out["dL_dL_u_%d" % q] = grads["dL_dL_u"][q]
+            if M <= 128 and batch_size is None:   # larger M: pinned through g_Z / g_variance / g_lengthscale (size)
+                out["dL_dKmm_%d" % q] = grads["dL_dKmm"][q]
+            for d in range(Df):      # row sums of the un-stored dL_dKmn blocks (M,) and the dL_dKdiag vectors' sums: cheap pins
+                out["dL_dKmn_rowsum_%d_%d" % (q, d)] = np.sum(grads["dL_dKmn"][q][d], axis=1)
+                out["dL_dKdiag_sum_%d_%d" % (q, d)] = np.sum(grads["dL_dKdiag"][q][d])
+        for t in range(T):
+            out["Xall_%d" % t], out["Yall_%d" % t] = c["X"][t], c["Y"][t]
+            out["Xbatch_%d" % t], out["Ybatch_%d" % t] = Xb[t], Yb[t]
+        np.savez_compressed(
+            os.path.join(OUT, "ref_%s.npz" % tag), spec=json.dumps(specs), T=T, M=M, Q=Q, P=P, Df=Df,
+            Z=c["Z"], variance=c["variance"], lengthscale=c["lengthscale"], W=c["W"], W0=c["W"],
+            kappa=np.zeros((Q, Df)), m_u=c["m_u"], L_flat=c["L_flat"], stochastic=int(batch_size is not None),
+            batch_size=-1 if batch_size is None else batch_size, vem_step=int(vem_step),
+            batch_scale=np.array(model.batch_scale), f_index=f_index, d_index=Y_metadata["d_index"].flatten(),
+            elbo=np.asarray(model.log_likelihood()).reshape(1, 1), elbo_inference=np.asarray(captured["elbo"]).reshape(1, 1),
+            g_m_u=np.asarray(model.q_u_means.gradient), g_L_u=np.asarray(model.q_u_chols.gradient),
+            g_Z=np.asarray(model.Z.gradient),
+            g_variance=np.array([float(np.ravel(kq.variance.gradient)[0]) for kq in kern_list]),
+            g_lengthscale=np.array([float(np.ravel(kq.lengthscale.gradient)[0]) for kq in kern_list]),
+            g_W=np.stack([np.ravel(B.W.gradient) for B in model.B_list]),
+            g_kappa=np.stack([np.ravel(B.kappa.gradient) for B in model.B_list]),
+            reference_seconds=dt, **out)
+        print("ref", tag, "ELBO", float(model.log_likelihood()), "reference parameters_changed: %.2f s" % dt,
+              "cond(Kuu)", ["%.1e" % np.linalg.cond(Kuu[q]) for q in range(Q)])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     stand, inf, util, hl, svmogp, liks = _import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "ref":          # only the real-size family (the others are unchanged)
+        gen_reference_real_sizes(stand, inf, util, hl, svmogp, liks)
+        return
     gen_likelihoods(liks)
     gen_predictive(liks)
     gen_cov(stand, util)
     gen_inference(stand, inf, util, hl, liks)
     gen_model(stand, util, hl, svmogp, liks)
     gen_model_predict(stand, util, hl, svmogp, liks)
+    gen_reference_real_sizes(stand, inf, util, hl, svmogp, liks)
 
 
 if __name__ == "__main__":

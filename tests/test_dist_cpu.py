@@ -166,6 +166,22 @@ def _negotiation_worker(rank, world, port, q):
         res["native_unavailable"] = "no error"
     except RuntimeError:
         res["native_unavailable"] = ("raised", e4.comm)
+    # a communicator already attached on SOME ranks only -- every rank must issue the same collectives and reach
+    # the same verdict (no hang, no mixed modes); the pre-attached communicator is left to its owner
+    e5 = _FakeEngine(rank)
+    if rank == 0:
+        e5.comm = (world, 0)
+    try:
+        hd.StatsReducer(e5, mode="native", native_api=api)
+        res["native_mixed"] = "no error"
+    except RuntimeError as exc:
+        res["native_mixed"] = ("raised", e5.comm, e5.destroyed, "some ranks only" in str(exc))
+    # ... and attached on EVERY rank by the caller: taken as is, not owned
+    e6 = _FakeEngine(rank)
+    e6.comm = (world, rank)
+    red6 = hd.StatsReducer(e6, mode="native", native_api=api)
+    res["native_preattached"] = (red6.mode, red6.owns_comm)
+    res["agree_min_max"] = hd.agree_min_max(rank + 3)
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, res))
@@ -195,4 +211,7 @@ def test_reducer_mode_negotiation_is_collective():
         assert r["native_closed"] == ((0, -1), 1)
         assert r["native_partial"][0] == "raised" and r["native_partial"][1] == (0, -1) and r["native_partial"][3]
         assert r["native_unavailable"] == ("raised", (0, -1))
+        assert r["native_mixed"] == ("raised", (2, 0) if rank == 0 else (0, -1), 0, True)
+        assert r["native_preattached"] == ("native", False)
+        assert r["agree_min_max"] == (3, 4)
     assert res[0]["native_partial"][2] == 1 and res[1]["native_partial"][2] == 0   # only the rank that had one destroyed it

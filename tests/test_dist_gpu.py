@@ -57,7 +57,7 @@ def test_bundle_aliases_as_torch_tensor_and_rccl_allreduce():
 
 
 def test_native_exchange_one_rank_communicator():
-    """The in-library exchange (hmogp_comm_init -> hmogp_elbo_grad = begin -> pack -> ncclAllReduce -> unpack -> finish, all on
+    """The in-library exchange (hmogp_comm_init -> hmogp_elbo_grad_sharded = begin -> pack -> ncclAllReduce -> unpack -> finish, all on
     the engine's stream) with a communicator of ONE rank: the same three launches as on N ranks, results bit-identical to the
     plain call; the three-call form (step_begin / step_exchange / step_finish) too."""
     import torch
@@ -76,7 +76,9 @@ def test_native_exchange_one_rank_communicator():
         e.step_exchange()                                                # no communicator yet
     e.comm_init(1, 0, comm_unique_id())                                  # no torch.distributed needed at all
     assert e.comm_info() == (1, 0)
-    out = e.elbo_grad(**prm)
+    plain = e.elbo_grad(**prm)                                           # never a collective, communicator or not (ABI v5)
+    assert e.timings()[0]["exchange"] == 0.0 and np.array_equal(plain["g_L_u"], full["g_L_u"])
+    out = e.elbo_grad(sharded=True, **prm)
     ms, nl = e.timings()
     assert ms["exchange"] > 0.0 and nl["exchange"] == 3
     for k in ("elbo", "g_m_u", "g_L_u", "g_Z", "g_W", "g_variance", "g_lengthscale"):
@@ -87,6 +89,13 @@ def test_native_exchange_one_rank_communicator():
         e.step_exchange()                                                # once per step
     out3 = e.step_finish()
     assert np.array_equal(out3["g_L_u"], full["g_L_u"]) and out3["elbo"] == full["elbo"]
+    # a rank that cannot contribute aborts its communicator, so that its peers fail instead of blocking
+    with pytest.raises(ValueError):
+        e.elbo_grad(sharded=True, **dict(prm, row_begin=[0] * len(X), row_end=[x.shape[0] + 1 for x in X]))
+    assert e.comm_info() == (0, -1)
+    with pytest.raises(HetMOGPError):
+        e.elbo_grad(sharded=True, **prm)                                 # no communicator any more: E_STATE, not a hang
+    e.comm_init(1, 0, comm_unique_id())
     e.comm_destroy()
     assert e.comm_info() == (0, -1)
     # the same through the reducer inside a (one-rank) torch.distributed group: the id travels by dist.broadcast

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, elementwise_excess
 
 pytestmark = pytest.mark.gpu
 
@@ -56,6 +56,9 @@ def test_parameters_changed_matches_reference(tag):
     assert rel(np.stack([B.W.gradient.ravel() for B in model.B_list]), g["g_W"]) < 1e-8
     assert rel(np.stack([B.kappa.gradient.ravel() for B in model.B_list]), g["g_kappa"]) < 1e-8
     assert np.allclose(model.batch_scale, g["batch_scale"])
+    for got, key in ((model.q_u_means.gradient, "g_m_u"), (model.q_u_chols.gradient, "g_L_u"), (model.Z.gradient, "g_Z"),
+                     (np.stack([B.W.gradient.ravel() for B in model.B_list]), "g_W")):
+        assert elementwise_excess(got, g[key]) <= 1.0, (key, "element-wise 1e-5")
 
 
 def test_optimizer_view_and_fd_of_objective():

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, elementwise_excess
 
 pytestmark = pytest.mark.gpu
 
@@ -53,6 +53,7 @@ def test_engine_vs_reference_parameters_changed(path):
     assert out["rungs"] == [-1] * prob["Q"]
     for k in KEYS:
         assert rel(out[k], g[k]) < TOL, k
+        assert elementwise_excess(out[k], g[k]) <= 1.0, (k, "element-wise 1e-5")
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "inf_*.npz"))), ids=os.path.basename)
@@ -76,6 +77,7 @@ def test_engine_vs_reference_inference(path):
     want = so.assemble_literal(prm, prob, X, grads)
     for k in KEYS[1:]:
         assert rel(out[k], want[k]) < TOL, k
+        assert elementwise_excess(out[k], want[k]) <= 1.0, (k, "element-wise 1e-5")
     # q(f) through the prediction entry point at the training inputs (svmogp_inf.py:212-218)
     for t in range(prob["T"]):
         m, v = e.predict_f(X[t])
@@ -83,6 +85,8 @@ def test_engine_vs_reference_inference(path):
             if prob["f_index"][d] == t:
                 assert rel(m[:, d], g["m_fd_%d" % d][:, 0]) < TOL
                 assert rel(v[:, d], g["v_fd_%d" % d][:, 0]) < TOL
+                assert elementwise_excess(m[:, d], g["m_fd_%d" % d][:, 0]) <= 1.0
+                assert elementwise_excess(v[:, d], g["v_fd_%d" % d][:, 0]) <= 1.0
 
 
 def synth(seed, specs, Ns, M, Q, P, cs):

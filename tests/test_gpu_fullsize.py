@@ -13,6 +13,8 @@ the whole evaluation, through size-independent properties:
 import numpy as np
 import pytest
 
+from conftest import elementwise_excess
+
 pytestmark = pytest.mark.gpu
 
 KEYS = ["elbo", "g_m_u", "g_L_u", "g_variance", "g_lengthscale", "g_W", "g_kappa", "g_Z"]
@@ -26,13 +28,13 @@ def rel(a, b):
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300))
 
 
-def check_config(specs, N, M, Q, window, seed, pools, exact_zero=True, oracle_tol=1e-8):
+def check_config(specs, N, M, Q, window, seed, pools, exact_zero=True, oracle_tol=1e-8, P=1, calibrate=False):
     from hetmogp_amd.engine import Engine
     from hetmogp_amd.synthetic import make_case
     from oracle import svmogp_oracle as so
     T = len(specs)
-    prm, X, Y = make_case(specs, [N] * T, M=M, Q=Q, P=1, seed=seed)
-    e = Engine(specs, Q, M, 1)
+    prm, X, Y = make_case(specs, [N] * T, M=M, Q=Q, P=P, seed=seed)
+    e = Engine(specs, Q, M, P)
     e.set_data(X, Y)
     full = e.elbo_grad(**prm)
     assert np.isfinite(full["elbo"]) and not full["v_negative"] and full["rungs"] == [-1] * Q
@@ -51,22 +53,28 @@ def check_config(specs, N, M, Q, window, seed, pools, exact_zero=True, oracle_to
     for k in KEYS:
         assert rel(both[k], full[k]) < 1e-9, ("shards", k, rel(both[k], full[k]))
     # oracle parity on the LAST `window` rows of every task
-    prob = so.make_problem(specs, Q, M, 1)
-    want = so.elbo_grad_fused(prm, prob, [x[N - window:] for x in X], [y[N - window:] for y in Y])
+    prob = so.make_problem(specs, Q, M, P)
+    Xw, Yw = [x[N - window:] for x in X], [y[N - window:] for y in Y]
+    want = so.elbo_grad_fused(prm, prob, Xw, Yw)
+    lit = so.elbo_grad_literal(prm, prob, Xw, Yw) if calibrate else None
     got = e.elbo_grad(row_begin=[N - window] * T, row_end=[N] * T, **prm)
     for k in KEYS:
-        assert rel(got[k], want[k]) < oracle_tol, ("oracle window", k, rel(got[k], want[k]))
+        tol = oracle_tol
+        if calibrate:      # conditioning-limited shapes (2-D, M = 2048): the yardstick is the distance between the oracle's own
+            tol = min(1e-7, max(oracle_tol, 10.0 * rel(want[k], lit[k])))      # literal (solve-based) and fused restatements
+        assert rel(got[k], want[k]) < tol, ("oracle window", k, rel(got[k], want[k]))
+        assert elementwise_excess(got[k], want[k]) <= 1.0, ("oracle window, element-wise 1e-5", k)
     e.close()
     # chunk invariance: `pools` pools instead of one
     total = N * T
-    e2 = Engine(specs, Q, M, 1, chunk_rows=(total + pools - 1) // pools + 17)
+    e2 = Engine(specs, Q, M, P, chunk_rows=(total + pools - 1) // pools + 17)
     e2.set_data(X, Y)
     chunked = e2.elbo_grad(**prm)
     for k in KEYS:
         assert rel(chunked[k], full[k]) < 1e-9, ("pools", k, rel(chunked[k], full[k]))
     e2.close()
     if exact_zero:
-        e3 = Engine(specs, Q, M, 1, exact_zero_windows=True)
+        e3 = Engine(specs, Q, M, P, exact_zero_windows=True)
         e3.set_data(X, Y)
         ez = e3.elbo_grad(**prm)
         for k in KEYS:
@@ -91,3 +99,55 @@ def test_C4_rank_share_full_size():
     """One rank's share of C4: 8 tasks x 125 000 rows, Q = 4, Df = 14 (HetGaussian, Categorical(5), Beta, ...): the K^ / P~
     workspaces hold 4 x 1e6 x 1024 = 4.1e9 elements each -- element indices beyond 2^32."""
     check_config(C4_SPECS, 125000, 1024, 4, window=1000, seed=20260933, pools=2, exact_zero=False)
+
+
+@pytest.mark.timeout(900)
+def test_C5_full_size():
+    """C5: T=2 [Categorical(4), Gaussian], 2-D inputs, N_t = 50 000, M = 2048 (46 x 46 grid cut to 2048), Q = 2 -- 16 x 16 GEMM
+    tiles, 64 factorisation panels, the P = 2 variants of rbf / colstats.  Oracle parity on the last 1500 rows of both tasks."""
+    check_config([("Categorical", {"K": 4}), ("Gaussian", {"sigma": 0.5})], 50000, 2048, 2, window=1500, seed=20260934,
+                 pools=2, exact_zero=False, P=2, calibrate=True)
+
+
+@pytest.mark.timeout(900)
+def test_C3_full_size_minibatches_of_resident_million():
+    """C3: N_all = 1 000 000 rows per task RESIDENT (hmogp_set_task_data once), SVI minibatches = contiguous row ranges of it
+    (util.py:52-72), batch_scale = N_all / N_batch (svmogp.py:89-90).  Minibatches near the END of the resident arrays (offsets
+    ~990 000, different per task, and the short last slice) against the NumPy oracle on exactly those rows; the same rows
+    uploaded alone to a second engine give the same numbers; E-step (q(u) group only) and M-step gating; repeatability."""
+    from hetmogp_amd import _lib
+    from hetmogp_amd.engine import Engine
+    from hetmogp_amd.synthetic import make_case
+    from oracle import svmogp_oracle as so
+    T, N, M, Q, B = 4, 1000000, 1024, 3, 8192
+    prm, X, Y = make_case(H_SPECS, [N] * T, M=M, Q=Q, P=1, seed=20260932)
+    prob = so.make_problem(H_SPECS, Q, M, 1)
+    e = Engine(H_SPECS, Q, M, 1)
+    e.set_data(X, Y)
+    for rb, re_ in (([990000 - 1000 * t for t in range(T)], [990000 - 1000 * t + B for t in range(T)]),
+                    ([N - 5632] * T, [N] * T)):                      # 1e6 = 122 * 8192 + 576: also a short ragged slice
+        bs = [N / float(b - a) for a, b in zip(rb, re_)]
+        Xb, Yb = [x[a:b] for x, a, b in zip(X, rb, re_)], [y[a:b] for y, a, b in zip(Y, rb, re_)]
+        want = so.elbo_grad_fused(prm, prob, Xb, Yb, bs)
+        got = e.elbo_grad(row_begin=rb, row_end=re_, batch_scale=bs, **prm)
+        assert got["rungs"] == [-1] * Q and not got["v_negative"]
+        for k in KEYS:
+            assert rel(got[k], want[k]) < 1e-8, ("minibatch vs oracle", k, rel(got[k], want[k]))
+            assert elementwise_excess(got[k], want[k]) <= 1.0, ("minibatch vs oracle, element-wise 1e-5", k)
+        again = e.elbo_grad(row_begin=rb, row_end=re_, batch_scale=bs, **prm)
+        for k in KEYS:
+            assert np.array_equal(np.asarray(got[k]), np.asarray(again[k])), k
+        e2 = Engine(H_SPECS, Q, M, 1)
+        e2.set_data(Xb, Yb)
+        alone = e2.elbo_grad(batch_scale=bs, **prm)
+        for k in KEYS:
+            assert rel(alone[k], got[k]) < 1e-11, ("resident slice vs own upload", k)
+        e2.close()
+        est = e.elbo_grad(row_begin=rb, row_end=re_, batch_scale=bs, group_mask=_lib.GROUP_QU, **prm)
+        mst = e.elbo_grad(row_begin=rb, row_end=re_, batch_scale=bs, group_mask=_lib.GROUP_HYPER | _lib.GROUP_Z, **prm)
+        for k in ("elbo", "g_m_u", "g_L_u"):
+            assert rel(est[k], got[k]) < 1e-9, ("E-step", k)      # (the E-step's forward runs against the triangular fold of C)
+        for k in ("elbo", "g_variance", "g_lengthscale", "g_W", "g_kappa", "g_Z"):
+            assert rel(mst[k], got[k]) < 1e-9, ("M-step", k)
+        assert not np.any(est["g_Z"]) and not np.any(mst["g_m_u"])
+    e.close()
