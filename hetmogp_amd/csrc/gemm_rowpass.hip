@@ -133,25 +133,25 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
     *reinterpret_cast<f64x2*>(sb) = f64x2{rb[0], rb[1]};
     *reinterpret_cast<f64x2*>(sb + 64) = f64x2{rb[2], rb[3]};
   };
-  auto mma = [&](int buf) {
+  // MFMA operands ("fragments") of one k4-step: 4 A values + NB B values per lane, read from the LDS images into register set s
+  double fa[2][4], fb[2][NB];
+  auto frag = [&](int buf, int kk, int s) {
+    const double* fpa = (ROLE == 1) ? &lds.a[buf][(wm * 64 + lr) * RM_LD + kk * 4 + lk] : &lds.a[buf][(kk * 4 + lk) * KM_LD + wm * 64 + lr];
+    const double* fpb = &lds.b[buf][(kk * 4 + lk) * KM_LD + wn * WN + blr];
 #pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      const double* fpa = (ROLE == 1) ? &lds.a[buf][(wm * 64 + lr) * RM_LD + kk * 4 + lk] : &lds.a[buf][(kk * 4 + lk) * KM_LD + wm * 64 + lr];
-      const double* fpb = &lds.b[buf][(kk * 4 + lk) * KM_LD + wn * WN + blr];
-      double fa[4], fb[NB];
+    for (int i = 0; i < 4; ++i) fa[s][i] = fpa[i * 16 * (ROLE == 1 ? RM_LD : 1)];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = fpa[i * 16 * (ROLE == 1 ? RM_LD : 1)];
+    for (int i = 0; i < NB; ++i) fb[s][i] = fpb[i * 16];
+  };
+  auto mm8 = [&](int s) {
 #pragma unroll
-      for (int i = 0; i < NB; ++i) fb[i] = fpb[i * 16];
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          if (ROLE == 2 && !((sub >> (a * NB + b)) & 1u)) continue;   // wave-uniform (scalar) guard; all set off the diagonal
-          acc[a][b] = SWAP ? __builtin_amdgcn_mfma_f64_16x16x4f64(fb[b], fa[a], acc[a][b], 0, 0, 0)
-                           : __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
-        }
-    }
+      for (int b = 0; b < NB; ++b) {
+        if (ROLE == 2 && !((sub >> (a * NB + b)) & 1u)) continue;   // wave-uniform (scalar) guard; all set off the diagonal
+        acc[a][b] = SWAP ? __builtin_amdgcn_mfma_f64_16x16x4f64(fb[s][b], fa[s][a], acc[a][b], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f64_16x16x4f64(fa[s][a], fb[s][b], acc[a][b], 0, 0, 0);
+      }
   };
 
   // Software pipeline: the operands of step k + 1 are in registers when step k starts; they are staged into the other LDS
@@ -185,13 +185,65 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
       for (int b = 0; b < NB; ++b)
         if (wn * NB + b <= wm * 4 + a) sub |= 1u << (a * NB + b);
   }
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    if (k0 + BK < kend) stage(cur ^ 1);
+  // [r4] Main loop with the fragments ONE k4-step AHEAD OF THE MFMAs AND CARRIED ACROSS THE BARRIER: the fragments of the next
+  // tile's first k4-step are read right behind the barrier, in front of the last 8 MFMAs of the current tile, and the staging
+  // of step k + 1 / the global loads of step k + 2 sit behind the first 8 MFMAs -- a wave never waits for LDS (or for the
+  // ds_write -> ds_read turn-around at the top of a step) without 8 MFMAs of its own in flight.  Ablation of the bare loop
+  // (tools/probes/probe_gemm_abl.hip, profiles/r04_gemm_ablation.txt): 66.3 -> 70.8 TFLOP/s; the same loop without any
+  // barrier (racy) 72.5, MFMAs alone in this tile structure 73.6.  Same operations on the same values in the same order per
+  // accumulator: results are bit-identical to the round-3 loop.
+  // The Gram keeps the round-3 loop (fragments read inside the step): the carried fragments cost 12 registers, the Gram's 112
+  // allocated registers are what lets the column statistics run BESIDE it (one 64-register guest wave per SIMD), and alone it
+  // gains nothing (62.2 -> 62.3 TFLOP/s; in the step 39.4 -> 42.9 ms without the guest).
+  const bool live = ROLE == 1 || sub != 0;                     // (waves of a diagonal tile without a sub-tile idle through it)
+  if (ROLE == 2) {
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      if (k0 + BK < kend) stage(cur ^ 1);
+      if (k0 + 2 * BK < kend) load(k0 + 2 * BK);
+      if (live) {
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+          frag(cur, kk, 0);
+          mm8(0);
+        }
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  if (ROLE == 1 && kbeg < kend) frag(0, 0, 0);
+#define HM_SB __builtin_amdgcn_sched_barrier(0)
+  for (int k0 = kbeg; ROLE == 1 && k0 < kend; k0 += BK) {
+    const bool more = k0 + BK < kend;
+    if (live) {
+      frag(cur, 1, 1);
+      HM_SB;
+      mm8(0);
+      HM_SB;
+    }
+    if (more) stage(cur ^ 1);
     if (k0 + 2 * BK < kend) load(k0 + 2 * BK);
-    if (ROLE == 1 || sub) mma(cur);
+    HM_SB;
+    if (live) {
+      frag(cur, 2, 0);
+      HM_SB;
+      mm8(1);
+      HM_SB;
+      frag(cur, 3, 1);
+      HM_SB;
+      mm8(0);
+      HM_SB;
+    }
     __syncthreads();
+    if (live) {
+      if (more) frag(cur ^ 1, 0, 0);
+      HM_SB;
+      mm8(1);
+      HM_SB;
+    }
     cur ^= 1;
   }
+#undef HM_SB
 
   // ---- epilogue: D fragment of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg --------------------------
   if (ROLE == 1 && fs_part) {
