@@ -313,6 +313,7 @@ struct hmogp_engine {
   bool st2_masked = false;    // the second stream leaves a few CUs of every XCD to the latency-bound chains (HMOGP_ST2_FREE)
   hipStream_t st2 = nullptr;  // second stream, LOW priority: bandwidth-bound work beside the main stream (K_uf prefetch, colstats)
   hipStream_t st3 = nullptr;  // third stream, HIGH priority like the main one: the q(u)-only chains (S, S^-1; dL/dL, D2H)
+  hipEvent_t ev_qu = nullptr;   // behind an in-place update of the resident q(u) (hmogp_qu_natgrad)
   hipEvent_t ev_fork = nullptr, ev_gsk = nullptr, ev_zero = nullptr, ev_info = nullptr, ev_S = nullptr, ev_join = nullptr, ev_col = nullptr, ev_kuf = nullptr, ev_params = nullptr,
              ev_ua = nullptr;
 
@@ -442,7 +443,8 @@ struct hmogp_engine {
   ~hmogp_engine() {
     comm_destroy();
     for (auto e : pool) (void)hipEventDestroy(e);
-    for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_gsk, ev_zero, ev_info, ev_S, ev_join, ev_col, ev_kuf, ev_params, ev_ua})
+    if (h_info2) (void)hipHostFree(h_info2);
+    for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_gsk, ev_zero, ev_info, ev_S, ev_join, ev_col, ev_kuf, ev_params, ev_ua, ev_qu})
       if (e) (void)hipEventDestroy(e);
     if (hstage) (void)hipHostFree(hstage);
     if (h_info) (void)hipHostFree(h_info);
@@ -511,8 +513,10 @@ struct hmogp_engine {
       if (!st2) HIP_TRY(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, lo));
       HIP_TRY(hipStreamCreateWithPriority(&st3, hipStreamNonBlocking, hi));
     }
-    for (hipEvent_t* e : {&ev_fork, &ev_gsk, &ev_zero, &ev_info, &ev_S, &ev_join, &ev_col, &ev_kuf, &ev_params, &ev_ua})
+    for (hipEvent_t* e : {&ev_fork, &ev_gsk, &ev_zero, &ev_info, &ev_S, &ev_join, &ev_col, &ev_kuf, &ev_params, &ev_ua, &ev_qu})
       HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev_qu, st));
+    HIP_TRY(hipEventRecord(ev_join, st));
     for (hipEvent_t* e : {&ev_begin0, &ev_begin1, &ev_fin0, &ev_fin1}) HIP_TRY(hipEventCreate(e));
     f_index.assign(c->f_index, c->f_index + Df);
     d_index.assign(c->d_index, c->d_index + Df);
@@ -647,6 +651,7 @@ struct hmogp_engine {
     HIP_TRY(hipMemcpyAsync(dell.p, h_ell.data(), sizeof(double) * Q, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dW.p, h_W.data(), sizeof(double) * Q * Df, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dkap.p, h_kap.data(), sizeof(double) * Q * Df, hipMemcpyHostToDevice, st));
+    if (resident) HIP_TRY(hipStreamWaitEvent(st3, ev_qu, 0));   // an in-place natural-gradient update of the resident q(u)
     HIP_TRY(hipEventRecord(ev_params, st));   // what the second stream has to wait for before it reads Z / the hypers
   }
 
@@ -1298,38 +1303,66 @@ struct hmogp_engine {
   // north-star names it, the reference has none):  S^-1 <- S^-1 - 2 gamma dL/dS ;  S^-1 m <- S^-1 m + gamma (dL/dm -
   // 2 dL/dS m) ;  then m and L = chol(S) are recovered.  Requires the q(u) group in the last evaluation's mask.
   bool have_qu_grads = false;
-  void natgrad_step(double gamma, double* m_out, double* L_flat_out) {
+  DevBuf ng_t1, ng_t2, ng_th, ng_mnew, ng_mq, ng_lflat;
+  int* h_info2 = nullptr;   // page-locked: the two factorisations' info words of a natural-gradient step
+  // Core of the natural-gradient step: leaves the new m_u ([M, Q], the layout of dmu) in ng_mq and the new packed Cholesky
+  // factor in ng_lflat; throws HMOGP_E_NOT_PD (nothing modified) when the step leaves the positive-definite cone.  ONE host
+  // synchronisation (the two info words) at the end; everything else is enqueued back to back on the engine's stream.
+  void natgrad_core(double gamma) {
     if (!evaluated || !have_qu_grads) throw EngineError{HMOGP_E_STATE, "natural-gradient step needs a finished evaluation with the q(u) group"};
-    if (!m_out || !L_flat_out || !(gamma > 0.0)) throw EngineError{HMOGP_E_INVALID, "bad natural-gradient arguments"};
+    if (!(gamma > 0.0)) throw EngineError{HMOGP_E_INVALID, "bad natural-gradient arguments"};
     HIP_TRY(hipSetDevice(device));
     const long long Mtri = (long long)M * (M + 1) / 2;
-    DevBuf t1, t2, th, mnew, mq, lflat;
-    for (DevBuf* b : {&t1, &t2, &th, &mnew}) b->ensure(sizeof(double) * Q * M);
-    mq.ensure(sizeof(double) * M * Q), lflat.ensure(sizeof(double) * Mtri * Q);
-    std::vector<int> info(Q);
-    launch_natgrad_prec(Sqi.d(), dLdS.d(), gamma, HK.d(), Q, M, st);                 // Lambda = new precision
-    launch_gemv_batched(Sqi.d(), dmu.d(), t1.d(), Q, M, 1, Q, st);                   // S^-1 m
-    launch_gemv_batched(dLdS.d(), dmu.d(), t2.d(), Q, M, 1, Q, st);                  // dL/dS m
-    launch_natgrad_theta1(t1.d(), t2.d(), gmu.d(), gamma, th.d(), Q, M, st);
+    for (DevBuf* b : {&ng_t1, &ng_t2, &ng_th, &ng_mnew}) b->ensure(sizeof(double) * Q * M);
+    ng_mq.ensure(sizeof(double) * M * Q), ng_lflat.ensure(sizeof(double) * Mtri * Q);
+    if (!h_info2) HIP_TRY(hipHostMalloc((void**)&h_info2, sizeof(int) * 2 * HMOGP_MAXQ, hipHostMallocDefault));
+    HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));                                     // the q(u) tail of the evaluation (third stream)
+    launch_natgrad_prec(Sqi.d(), dLdS.d(), gamma, HK.d(), Q, M, st);                 // Lambda = S^-1 - 2 gamma dL/dS: new precision
+    launch_gemv_batched(Sqi.d(), dmu.d(), ng_t1.d(), Q, M, 1, Q, st);                // S^-1 m
+    launch_gemv_batched(dLdS.d(), dmu.d(), ng_t2.d(), Q, M, 1, Q, st);               // dL/dS m
+    launch_natgrad_theta1(ng_t1.d(), ng_t2.d(), gmu.d(), gamma, ng_th.d(), Q, M, st);
     HIP_TRY(hipMemcpyAsync(G.p, HK.p, sizeof(double) * (long long)M * M * Q, hipMemcpyDeviceToDevice, st));
     launch_potrf_batched(G.d(), Q, M, dinfo.as<int>(), dscr.d(), st);                // Lambda = R R^T
-    HIP_TRY(hipMemcpyAsync(info.data(), dinfo.p, sizeof(int) * Q, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    for (int q = 0; q < Q; ++q)
-      if (info[q] != 0) throw EngineError{HMOGP_E_NOT_PD, "natural-gradient step leaves the positive-definite cone (reduce gamma)"};
+    HIP_TRY(hipMemcpyAsync(h_info2, dinfo.p, sizeof(int) * Q, hipMemcpyDeviceToHost, st));
+    // (speculative, like the K_uu chain of an evaluation: a failed factorisation makes the launches below no-ops on garbage
+    //  that is never committed)
     launch_trtri_batched(G.d(), tmpA.d(), tmpB.d(), Q, M, st);
     launch_ltl_batched(tmpA.d(), GSK.d(), Q, M, st);                                 // S_new = Lambda^-1
-    launch_gemv_batched(GSK.d(), th.d(), mnew.d(), Q, M, M, 1, st);                  // m_new = S_new theta1
+    launch_gemv_batched(GSK.d(), ng_th.d(), ng_mnew.d(), Q, M, M, 1, st);            // m_new = S_new theta1
     launch_potrf_batched(GSK.d(), Q, M, dinfo.as<int>(), dscr.d(), st);              // L_new = chol(S_new)
-    HIP_TRY(hipMemcpyAsync(info.data(), dinfo.p, sizeof(int) * Q, hipMemcpyDeviceToHost, st));
-    launch_pack_tril(GSK.d(), lflat.d(), Q, M, 1.0, st);
-    launch_scatter_mq(mnew.d(), mq.d(), Q, M, st);
-    HIP_TRY(hipMemcpyAsync(m_out, mq.p, sizeof(double) * M * Q, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(L_flat_out, lflat.p, sizeof(double) * Mtri * Q, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_info2 + HMOGP_MAXQ, dinfo.p, sizeof(int) * Q, hipMemcpyDeviceToHost, st));
+    launch_pack_tril(GSK.d(), ng_lflat.d(), Q, M, 1.0, st);
+    launch_scatter_mq(ng_mnew.d(), ng_mq.d(), Q, M, st);
     HIP_TRY(hipStreamSynchronize(st));
-    for (int q = 0; q < Q; ++q)
-      if (info[q] != 0) throw EngineError{HMOGP_E_NOT_PD, "natural-gradient step: new covariance not positive definite"};
-    evaluated = false;  // HK/G/GSK scratch was reused: posterior/predict need a fresh evaluation
+    // (a failed step has only written scratch -- HK, G, GSK, tmpA, tmpB -- none of which is an input of the step: the caller
+    //  may retry with a smaller gamma straight away, no new evaluation needed)
+    for (int q = 0; q < Q; ++q) {
+      if (h_info2[q] != 0) throw EngineError{HMOGP_E_NOT_PD, "natural-gradient step leaves the positive-definite cone (reduce gamma)"};
+      if (h_info2[HMOGP_MAXQ + q] != 0) throw EngineError{HMOGP_E_NOT_PD, "natural-gradient step: new covariance not positive definite"};
+    }
+    evaluated = false;  // q(u) moves on: posterior / predict / another step need a fresh evaluation
+  }
+  // Natural-gradient update of q(u_q) = N(m_q, S_q) from the gradients of the last evaluation (the
+  // north-star names it, the reference has none):  S^-1 <- S^-1 - 2 gamma dL/dS ;  S^-1 m <- S^-1 m + gamma (dL/dm -
+  // 2 dL/dS m) ;  then m and L = chol(S) are recovered.  Requires the q(u) group in the last evaluation's mask.
+  void natgrad_step(double gamma, double* m_out, double* L_flat_out) {
+    if (!m_out || !L_flat_out) throw EngineError{HMOGP_E_INVALID, "bad natural-gradient arguments"};
+    natgrad_core(gamma);
+    const long long Mtri = (long long)M * (M + 1) / 2;
+    HIP_TRY(hipMemcpyAsync(m_out, ng_mq.p, sizeof(double) * M * Q, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(L_flat_out, ng_lflat.p, sizeof(double) * Mtri * Q, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  // The same step on the DEVICE-RESIDENT q(u) (hmogp_qu_load): m_u / L_flat are updated in place in HBM, nothing but the two
+  // info words crosses PCIe -- the natural-gradient SVI loop (E-steps) without moving 2 x 12.6 MB per iteration.
+  void qu_natgrad(double gamma) {
+    if (!qu_resident) throw EngineError{HMOGP_E_STATE, "no resident q(u) (hmogp_qu_load)"};
+    natgrad_core(gamma);
+    const long long Mtri = (long long)M * (M + 1) / 2;
+    HIP_TRY(hipMemcpyAsync(dmu.p, ng_mq.p, sizeof(double) * M * Q, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dLflat.p, ng_lflat.p, sizeof(double) * Mtri * Q, hipMemcpyDeviceToDevice, st));
+    // (no synchronisation: the next evaluation reads q(u) on streams ordered behind this one -- see upload_params)
+    HIP_TRY(hipEventRecord(ev_qu, st));
   }
 
   void predict_f(const double* Xnew, long long Nnew, double* m, double* v) {
@@ -1603,6 +1636,11 @@ int hmogp_debug_raw_grads(hmogp_handle h, double* dL_dKmm, double* dL_dKmn, doub
 int hmogp_natgrad_step(hmogp_handle h, double gamma, double* m_u_new, double* L_flat_new) {
   if (!h) return HMOGP_E_INVALID;
   return guarded(h, [&] { h->natgrad_step(gamma, m_u_new, L_flat_new); });
+}
+
+int hmogp_qu_natgrad(hmogp_handle h, double gamma) {
+  if (!h) return HMOGP_E_INVALID;
+  return guarded(h, [&] { h->qu_natgrad(gamma); });
 }
 
 int hmogp_predict_f(hmogp_handle h, const double* Xnew, int64_t Nnew, double* m, double* v) {

@@ -305,6 +305,11 @@ class Engine(object):
         check(lib.hmogp_qu_read(self._h, _p(m), _p(L)), self._h)
         return m, L
 
+    def qu_natgrad(self, gamma=1.0):
+        """Natural-gradient step on the DEVICE-RESIDENT q(u) (hmogp_qu_natgrad): in place in HBM, from the gradients of the
+        last evaluation.  Raises LinAlgError (HMOGP_E_NOT_PD) with q(u) untouched when gamma is too large."""
+        check(lib.hmogp_qu_natgrad(self._h, float(gamma)), self._h)
+
     def qu_adadelta(self, phase, step_rate, momentum, decay, offset):
         check(lib.hmogp_qu_adadelta(self._h, int(phase), float(step_rate), float(momentum), float(decay), float(1 - decay),
                                     float(offset)), self._h)

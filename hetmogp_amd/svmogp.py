@@ -124,6 +124,76 @@ class DeviceAdadelta(object):
             it.close()
 
 
+class DeviceNatGrad(DeviceAdadelta):
+    """The SVI loop with the NATURAL-GRADIENT update of q(u) the north-star names (the reference has none: it feeds the
+    Euclidean gradients of svmogp_inf.py:168-178 to Adadelta).  Same iteration protocol and 4 x E / 1 x M gating as
+    DeviceAdadelta (svmogp.py:188-199); what differs is the E-step: q(u) -- resident in HBM -- takes
+        S_q^-1 <- S_q^-1 - 2 gamma dL/dS_q ,  S_q^-1 m_q <- S_q^-1 m_q + gamma (dL/dm_q - 2 dL/dS_q m_q)
+    on the device (`hmogp_qu_natgrad`: in place, no host copy of q(u)), the remaining free parameters keep their Adadelta
+    recurrence on the host and only move on M-steps (their E-step gradients are gated to zero by the reference's own
+    logic).  A step that would leave the positive-definite cone is retried with gamma halved (q(u) untouched by a failed
+    step); `gamma_used` records the last accepted value."""
+
+    def __init__(self, model, gamma=0.1, step_rate=1.0, decay=0.9, momentum=0.0, offset=1e-4):
+        DeviceAdadelta.__init__(self, model, step_rate=step_rate, decay=decay, momentum=momentum, offset=offset)
+        self.gamma = float(gamma)
+        self.gamma_used = float(gamma)
+        self.rejected = 0
+
+    def __iter__(self):
+        m, eng = self.model, self.model._engine
+        try:
+            while True:
+                d, o, mom, rate = self.decay, self.offset, self.momentum, self.step_rate
+                step1 = self.step * mom
+                self.wrt -= step1
+                m.set_data(*m.new_batch())                         # stochastic_grad, svmogp.py:188-199
+                self._set_small()
+                e_step = bool(m.vem_step)
+                m.parameters_changed()
+                g = self._small_gradient()
+                if m.vem_step:
+                    if m.ve_count > 2:
+                        m.ve_count, m.vem_step = 0, False
+                    else:
+                        m.ve_count += 1
+                else:
+                    m.vem_step = True
+                t1 = g * g
+                t1 *= (1 - d)
+                self.gms *= d
+                self.gms += t1
+                t1 = np.sqrt(self.sms + o)
+                t1 /= np.sqrt(self.gms + o)
+                t1 *= g
+                t1 *= rate
+                self.wrt -= t1
+                self.step = step1 + t1
+                t2 = self.step * self.step
+                t2 *= (1 - d)
+                self.sms *= d
+                self.sms += t2
+                if e_step:                                          # the evaluation carried the q(u) group
+                    gam = self.gamma
+                    for _ in range(8):
+                        try:
+                            eng.qu_natgrad(gam)
+                            self.gamma_used = gam
+                            break
+                        except np.linalg.LinAlgError:
+                            self.rejected += 1
+                            gam *= 0.5
+                    m._qu_host_stale = True
+                    m._dirty = True
+                self.n_iter += 1
+                yield dict(n_iter=self.n_iter, gradient=g, step=self.step, gamma=self.gamma_used)
+        finally:
+            try:
+                self.finish()
+            except Exception:
+                pass
+
+
 class SVMOGP(object):
     def __init__(self, X, Y, Z, kern_list, likelihood, Y_metadata, name="SVMOGP", batch_size=None, W_list=None,
                  device=None, chunk_rows=0, exact_zero_windows=False, distributed=False, quirks="reference",
@@ -363,6 +433,13 @@ class SVMOGP(object):
         if not self.stochastic or self._dist is not None or self.q_u_means.is_fixed or self.q_u_chols.is_fixed:
             return None
         return DeviceAdadelta(self, step_rate=step_rate, decay=decay, momentum=momentum, offset=offset)
+
+    def device_natgrad(self, gamma=0.1, step_rate=1.0, decay=0.9, momentum=0.0, offset=1e-4):
+        """The SVI loop with natural-gradient E-steps on the device-resident q(u) (DeviceNatGrad); None when it does not
+        apply (same conditions as `device_adadelta`)."""
+        if not self.stochastic or self._dist is not None or self.q_u_means.is_fixed or self.q_u_chols.is_fixed:
+            return None
+        return DeviceNatGrad(self, gamma=gamma, step_rate=step_rate, decay=decay, momentum=momentum, offset=offset)
 
     def callback(self, i, max_iter, verbose=True, verbose_plot=False):
         """svmogp.py:201-217."""

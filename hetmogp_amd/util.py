@@ -156,13 +156,17 @@ def _apply_half_step(model, frozen, released, optZ, non_chained):
 
 
 def vem_algorithm(model, stochastic=False, vem_iters=None, step_rate=None, verbose=False, optZ=True, verbose_plot=False,
-                  non_chained=True, device_optimizer=True):
+                  non_chained=True, device_optimizer=True, qu_optimizer="adadelta", natgrad_gamma=0.1):
     """Variational EM driver with the signature of util.py:284-331.  Batch mode alternates L-BFGS-B over q(u) (VE) and
     over the hyper-parameters (VM) following VEM_SCHEDULE, at most 100 iterations each, and reports the ELBO after every
     half-step; stochastic mode runs Adadelta (momentum 0.9) on `model.stochastic_grad` for `vem_iters` iterations.
     lengthscale and kappa start frozen; kappa is never released.  `device_optimizer` (stochastic mode, no reference
     equivalent): keep q(u) and its Adadelta state in HBM (`SVMOGP.device_adadelta`); the iterates are bit-identical to
-    the host optimiser's."""
+    the host optimiser's.  `qu_optimizer="natgrad"` (stochastic mode, no reference equivalent; the north-star names it): the
+    E-steps move q(u) by NATURAL-gradient steps of size `natgrad_gamma` on the device-resident q(u) (`hmogp_qu_natgrad`)
+    instead of Adadelta on its Euclidean gradient; the hyper-parameters keep Adadelta on the M-steps."""
+    if qu_optimizer not in ("adadelta", "natgrad"):
+        raise ValueError("qu_optimizer must be 'adadelta' or 'natgrad'")
     vem_iters = 5 if vem_iters is None else vem_iters
     _GROUPS["lengthscale"](model).fix()
     _GROUPS["kappa"](model).fix()
@@ -177,10 +181,15 @@ def vem_algorithm(model, stochastic=False, vem_iters=None, step_rate=None, verbo
     rate = 0.01 if step_rate is None else step_rate
     model.elbo = np.empty((vem_iters + 1, 1))
     stop = partial(model.callback, max_iter=vem_iters, verbose=verbose, verbose_plot=verbose_plot)
-    make = getattr(model, "device_adadelta", None) if device_optimizer else None
-    if make is not None:
-        optimizer = make(step_rate=rate, momentum=0.9)
-    else:
+    optimizer = None
+    if qu_optimizer == "natgrad":
+        make = getattr(model, "device_natgrad", None)
+        optimizer = make(gamma=natgrad_gamma, step_rate=rate, momentum=0.9) if make is not None else None
+        if optimizer is None:
+            raise ValueError("qu_optimizer='natgrad' needs a stochastic, single-process model with a free q(u)")
+    elif device_optimizer and getattr(model, "device_adadelta", None) is not None:
+        optimizer = model.device_adadelta(step_rate=rate, momentum=0.9)      # None when it does not apply
+    if optimizer is None:
         optimizer = Adadelta(model.optimizer_array, model.stochastic_grad, step_rate=rate, momentum=0.9)
     optimizer.minimize_until(stop)
     return model

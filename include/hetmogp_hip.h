@@ -234,8 +234,14 @@ int hmogp_predict_f(hmogp_handle h, const double* Xnew, int64_t Nnew, double* m,
 /* From the gradients of the LAST finished evaluation (its group_mask must include HMOGP_GROUP_QU):
  *   S_q^-1 <- S_q^-1 - 2 gamma dL/dS_q ;  S_q^-1 m_q <- S_q^-1 m_q + gamma (dL/dm_q - 2 dL/dS_q m_q)
  * returns the new m_u [M, Q] and L_flat [M(M+1)/2, Q] (Cholesky of the new S_q, GPy packing).  HMOGP_E_NOT_PD if
- * the step leaves the positive-definite cone.  Invalidates posterior_u / predict_f until the next evaluation.   */
+ * the step leaves the positive-definite cone (nothing is modified: retry with a smaller gamma).  A successful step
+ * invalidates posterior_u / predict_f until the next evaluation.                                                       */
 int hmogp_natgrad_step(hmogp_handle h, double gamma, double* m_u_new, double* L_flat_new);
+/* The same step applied IN PLACE to the device-resident q(u) of hmogp_qu_load (ABI v5): nothing but two info words crosses
+ * PCIe; the next evaluation (m_u = L_flat = NULL) sees the updated q(u).  HMOGP_E_NOT_PD leaves the resident q(u) and the
+ * gradients of the last evaluation untouched (the step only wrote scratch), so the caller can retry at once with a smaller
+ * gamma.  After a successful step posterior_u / predict_f / another step need a new evaluation (HMOGP_E_STATE otherwise).  */
+int hmogp_qu_natgrad(hmogp_handle h, double gamma);
 
 /* ---- device-resident q(u) and its Adadelta state: the SVI loop without moving 2 x 12.6 MB per iteration ------ */
 /* The reference's stochastic driver (util.py:321-329) runs climin.Adadelta over the flat optimiser vector, 98 % of which

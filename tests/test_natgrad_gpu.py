@@ -1,0 +1,114 @@
+"""GPU: the natural-gradient update of q(u) (north-star) on the DEVICE-RESIDENT q(u) -- hmogp_qu_natgrad --
+at the headline M = 1024.  The reference has no such step (it hands the Euclidean gradients of svmogp_inf.py:168-178 to
+Adadelta), so these are property tests:
+  * conjugate one-step optimum: Gaussian likelihoods and ONE latent GP make q(u)'s optimum closed-form; one natural-gradient
+    step of size 1 lands on it (gradients vanish to rounding) from any starting point;
+  * the in-place device step equals the host-returning step (hmogp_natgrad_step) bit for bit;
+  * monotone ELBO for gamma <= 0.1 on the headline likelihood mix (non-conjugate), q(u) never leaving the device;
+  * a step that would leave the positive-definite cone fails with LinAlgError and leaves q(u) untouched; a retry with a
+    smaller gamma needs no new evaluation;
+  * the facade's SVI loop with qu_optimizer="natgrad" (vem_algorithm) runs and improves the ELBO."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300))
+
+
+def _case(specs, N, M, Q, seed):
+    from hetmogp_amd.synthetic import make_case
+    prm, X, Y = make_case(specs, [N] * len(specs), M=M, Q=Q, P=1, seed=seed)
+    return prm, X, Y
+
+
+def test_conjugate_one_step_optimum_M1024_device_resident():
+    from hetmogp_amd.engine import Engine
+    from hetmogp_amd import _lib
+    specs = [("Gaussian", {"sigma": 0.5}), ("Gaussian", {"sigma": 1.0})]
+    M, Q = 1024, 1
+    prm, X, Y = _case(specs, 6000, M, Q, 101)
+    e = Engine(specs, Q, M, 1)
+    e.set_data(X, Y)
+    out0 = e.elbo_grad(**prm)
+    small = {k: v for k, v in prm.items() if k not in ("m_u", "L_flat")}
+    # host-returning step from the same evaluation (the reference point) ...
+    m1, L1 = e.natgrad_step(1.0)
+    # ... and the in-place step on the resident copy
+    e.qu_load(prm["m_u"], prm["L_flat"])
+    res0 = e.elbo_grad(m_u=None, L_flat=None, **small)
+    assert res0["elbo"] == out0["elbo"]
+    e.qu_natgrad(1.0)
+    m1d, L1d = e.qu_read()
+    assert np.array_equal(m1d, m1) and np.array_equal(L1d, L1)
+    out1 = e.elbo_grad(m_u=None, L_flat=None, group_mask=_lib.GROUP_QU, **small)
+    assert out1["elbo"] > out0["elbo"]
+    chk = e.elbo_grad(m_u=m1, L_flat=L1, **small)            # gradients at the new point through the host path
+    scale = max(np.max(np.abs(out0["g_m_u"])), np.max(np.abs(out0["g_L_u"])))
+    assert np.max(np.abs(chk["g_m_u"])) < 1e-6 * scale and np.max(np.abs(chk["g_L_u"])) < 1e-6 * scale
+    assert rel(chk["elbo"], out1["elbo"]) < 1e-12
+    # a second full step stays at the optimum
+    e.qu_load(m1, L1)
+    e.elbo_grad(m_u=None, L_flat=None, **small)
+    e.qu_natgrad(1.0)
+    m2, L2 = e.qu_read()
+    assert rel(m2, m1) < 1e-6 and rel(L2, L1) < 1e-6
+    e.close()
+
+
+def test_monotone_elbo_headline_mix_M1024_and_rejected_steps():
+    from hetmogp_amd.engine import Engine
+    specs = [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {}), ("Poisson", {}), ("Gamma", {})]
+    M, Q = 1024, 3
+    prm, X, Y = _case(specs, 4096, M, Q, 102)
+    small = {k: v for k, v in prm.items() if k not in ("m_u", "L_flat")}
+    e = Engine(specs, Q, M, 1)
+    e.set_data(X, Y)
+    e.qu_load(prm["m_u"], prm["L_flat"])
+    prev = e.elbo_grad(m_u=None, L_flat=None, **small)["elbo"]
+    for gamma in (0.1, 0.1, 0.05, 0.1):
+        e.qu_natgrad(gamma)
+        cur = e.elbo_grad(m_u=None, L_flat=None, **small)["elbo"]
+        assert cur > prev, (gamma, cur, prev)
+        prev = cur
+    # an absurd step leaves the cone: LinAlgError, resident q(u) untouched, immediate retry works
+    before = e.qu_read()
+    with pytest.raises(np.linalg.LinAlgError):
+        e.qu_natgrad(1e6)
+    after = e.qu_read()
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    e.qu_natgrad(0.05)                                           # no new evaluation in between
+    assert e.elbo_grad(m_u=None, L_flat=None, **small)["elbo"] > prev
+    with pytest.raises(Exception):
+        e.qu_natgrad(0.05)
+        e.qu_natgrad(0.05)                                       # two steps from one evaluation: E_STATE
+    e.close()
+
+
+def test_facade_svi_loop_with_natural_gradient_e_steps():
+    import hetmogp_amd as H
+    from hetmogp_amd.kern import RBF
+    specs = [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {}), ("Poisson", {})]
+    M, Q, N, B = 128, 2, 4000, 500
+    prm, X, Y = _case(specs, N, M, Q, 103)
+
+    def build():
+        lik = H.HetLikelihood([H.Gaussian(sigma=0.5), H.Bernoulli(), H.Poisson()])
+        np.random.seed(3)
+        kern = [RBF(1, variance=float(prm["variance"][q]), lengthscale=float(prm["lengthscale"][q])) for q in range(Q)]
+        return H.SVMOGP(X=X, Y=[y.reshape(-1, 1) for y in Y], Z=prm["Z"][:, :1].copy(), kern_list=kern, likelihood=lik,
+                        Y_metadata=lik.generate_metadata(), batch_size=B)
+    m_ng = build()
+    H.vem_algorithm(m_ng, stochastic=True, vem_iters=40, step_rate=0.01, qu_optimizer="natgrad", natgrad_gamma=0.1)
+    m_ad = build()
+    H.vem_algorithm(m_ad, stochastic=True, vem_iters=40, step_rate=0.01)
+    e_ng, e_ad = m_ng.elbo[:40, 0], m_ad.elbo[:40, 0]
+    assert np.all(np.isfinite(e_ng)) and np.all(np.isfinite(e_ad))
+    # natural-gradient E-steps climb much faster than Adadelta on the Euclidean gradient of q(u) from the same start
+    assert np.mean(e_ng[-8:]) > np.mean(e_ng[:8]) and np.mean(e_ng[-8:]) > np.mean(e_ad[-8:])
+    # q(u) came back to the host arrays when the loop ended and the model evaluates consistently from them
+    m_ng.parameters_changed()
+    assert np.isfinite(m_ng.log_likelihood()[0, 0])
