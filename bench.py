@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--latents", type=int, default=3, help="Q (headline: 3)")
     ap.add_argument("--cpu-sample-rows", type=int, default=20000, help="rows per task of the larger CPU-baseline sample")
     ap.add_argument("--cpu-literal-budget", type=float, default=70.0, help="seconds the literal-reference baseline may use")
+    ap.add_argument("--cpu-full-budget", type=float, default=240.0,
+                    help="run ONE true full-size step of CPU baseline B if the two-sample prediction is below this many seconds")
     ap.add_argument("--no-other-configs", action="store_true", help="skip C1 / C2 / C3 / C4-share / C5 (N=1 only)")
     ap.add_argument("--other-steps", type=int, default=5, help="timed steps per other configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -416,18 +418,30 @@ def cpu_baselines(args, eng, prm, X, Y, N, M, Q, P):
     t2, ts2 = _median_time(lambda: run_b(ns2), reps_b)
     per_row = max((t2 - t1) / (T * (ns2 - ns1)), 0.0) if ns2 > ns1 else t2 / (T * ns2)
     fixed = max(t1 - per_row * T * ns1, 0.0)
-    full = fixed + per_row * T * N
+    full_extrapolated = fixed + per_row * T * N
+    # [r4] ONE TRUE FULL-SIZE STEP of baseline B (all N rows of every task), timed; the two-sample split above stays as a
+    # cross-check (`extrapolated_s`).  Skipped only when the prediction exceeds the budget (tiny hosts).
+    full_measured = None
+    if N > ns2 and full_extrapolated <= args.cpu_full_budget:
+        t0f = time.perf_counter()
+        run_b(N)
+        full_measured = time.perf_counter() - t0f
+    full = full_measured if full_measured is not None else full_extrapolated
     flops_sample = 3.0 * T * ns2 * Q * M * M + 20.0 * Q * M ** 3
+    flops_full = 3.0 * T * N * Q * M * M + 20.0 * Q * M ** 3
     res = {"cpu_baseline": {
-        "value": 1.0 / full, "unit": "steps/s", "cores": min(ncpu, workers * blas_per_worker), "host_cores": ncpu, "kind": "port",
+        "value": 1.0 / full, "unit": "steps/s", "full_step_measured": full_measured is not None,
+        "full_step_s": full_measured, "extrapolated_s": full_extrapolated,
+        "full_step_gflops": (flops_full / full_measured / 1e9) if full_measured else None, "cores": min(ncpu, workers * blas_per_worker), "host_cores": ncpu, "kind": "port",
         "blas": blas, "threads": threads, "row_shard_workers": workers, "blas_threads_per_worker": blas_per_worker,
         "gflops": flops_sample / t2 / 1e9, "host_dgemm_gflops": host_dgemm_gflops,
         "frac_of_host_dgemm": flops_sample / t2 / 1e9 / host_dgemm_gflops,
         "fixed_s": fixed, "per_row_s": per_row, "reps": reps_b,
         "sample": "baseline B: oracle.svmogp_oracle u_algebra + local_stats + finish (NumPy + %s, fp64; rows sharded over %d "
                   "worker threads x %d BLAS threads) on the first %d and %d of %d rows of each of the %d tasks, M=%d, Q=%d: "
-                  "median of %d steps = %.2f s and %.2f s -> %.3f s independent of the rows + %.3e s per row; full step = "
-                  "fixed + per_row * %d rows.  The same host runs a plain %d^3 dgemm at %.0f GFLOP/s: the port reaches %.1f %% "
+                  "median of %d steps = %.2f s and %.2f s -> %.3f s independent of the rows + %.3e s per row (cross-check: "
+                  "fixed + per_row * %d rows); `value` = 1 / (ONE measured full-size step of all rows, full_step_s) when "
+                  "full_step_measured.  The same host runs a plain %d^3 dgemm at %.0f GFLOP/s: the port reaches %.1f %% "
                   "of that (NumPy element-wise passes and small per-shard GEMMs), so GPU/B overstates the hardware ratio"
                   % (blas, workers, blas_per_worker, ns1, ns2, N, T, M, Q, reps_b, t1, t2, fixed, per_row, T * N, nd,
                      host_dgemm_gflops, 100.0 * flops_sample / t2 / 1e9 / host_dgemm_gflops),
@@ -485,6 +499,66 @@ def _dominant(cat):
     return k, cat[k]
 
 
+def _config_roofline(rows, Q, M, cat, tag):
+    """FP64-MFMA roofline of a configuration's dominant contraction from the HIP-event spans of this run: the forward
+    P~ = K^ C_q (2 rows Q M^2 algorithmic flops per launch, one launch per step) unless the weighted Gram takes longer
+    (rows Q M^2, lower tiles).  `rocprof` names the committed rocprofv3 summaries of the same workload
+    (tools/profile_configs.sh -> tools/summarize_profile.py), whose average kernel durations must agree."""
+    fwd, gram = cat.get("forward_gemm", 0.0), cat.get("gram_gemm", 0.0)
+    if fwd <= 0.0 and gram <= 0.0:
+        return None
+    if fwd >= gram:
+        kern, fl, t = "rowpass_gemm_kernel<1> / gemm_f64_kernel (forward P~ = K^ C_q)", 2.0 * rows * Q * M * M, fwd
+    else:
+        kern, fl, t = "rowpass_gemm_kernel<2> (weighted Gram, lower tiles)", 1.0 * rows * Q * M * M, gram
+    ach = fl / t / 1e9
+    out = {"kernel": kern, "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+           "frac": ach / PEAK_FP64_MFMA_TFLOPS, "avg_launch_ms": t, "source": "HIP events on the engine's stream (this run)",
+           "traffic": None}
+    if tag:
+        base = os.path.join(ROOT, "profiles", "r04_%s" % tag)
+        if os.path.exists(base + "_kernel_stats.csv"):
+            out["rocprof"] = "profiles/r04_%s_kernel_stats.csv" % tag
+        hbm = base + "_pmc_hbm.csv"
+        if os.path.exists(hbm):
+            import csv
+            want = "rowpass_gemm_kernel<1>" if fwd >= gram else "rowpass_gemm_kernel<2>"
+            rows_ = [r for r in csv.DictReader(open(hbm)) if r["kernel"].startswith(want)]
+            if rows_:
+                out["traffic"] = int(max(rows_, key=lambda r: int(r["hbm_bytes_per_launch"]))["hbm_bytes_per_launch"])
+                out["traffic_source"] = "profiles/r04_%s_pmc_hbm.csv" % tag
+    return out
+
+
+def _parity_c1_vs_reference_fixture():
+    """C1 at its exact size against what the REFERENCE ITSELF returned (tests/golden/ref_c1_exact.npz: outputs of the reference's
+    own SVMOGP.parameters_changed at N_t=1000, M=50, Q=2, captured in the authoring container): worst array-normalised error of
+    ELBO + the 7 gradient arrays.  The fixture travels with the repository; the reference's Python does not."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "ref_c1_exact.npz")
+    if not os.path.exists(path):
+        return None
+    from hetmogp_amd.engine import Engine
+    g = np.load(path)
+    specs = [(n, k) for n, k in json.loads(str(g["spec"]))]
+    T, Q, M, P = int(g["T"]), int(g["Q"]), int(g["M"]), int(g["P"])
+    e = Engine(specs, Q, M, P)
+    e.set_data([g["Xbatch_%d" % t] for t in range(T)], [g["Ybatch_%d" % t] for t in range(T)])
+    out = e.elbo_grad(Z=g["Z"], m_u=g["m_u"], L_flat=g["L_flat"], variance=g["variance"], lengthscale=g["lengthscale"],
+                      W=g["W"], kappa=g["kappa"], W0=g["W0"], batch_scale=list(g["batch_scale"]))
+    e.close()
+    worst, wk = 0.0, None
+    for k in ("elbo", "g_m_u", "g_L_u", "g_variance", "g_lengthscale", "g_W", "g_kappa", "g_Z"):
+        a, b = np.asarray(out[k], float), np.asarray(g[k], float)
+        err = float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300))
+        if err > worst:
+            worst, wk = err, k
+    if not (worst <= 1e-5):
+        raise SystemExit("bench.py: C1 disagrees with the reference-run fixture: %s rel err %.3e" % (wk, worst))
+    return {"max_rel_err": worst, "worst": wk, "against": "tests/golden/ref_c1_exact.npz (the reference's own parameters_changed, "
+            "N_t=1000, M=50, Q=2)", "tolerance": 1e-5, "reference_seconds_per_step_in_authoring_container": float(g["reference_seconds"])}
+
+
 def _time_steps(eng, prm, steps, warmup=2, **kw):
     """Wall ms per `elbo_grad` (synchronous at return) and the per-family kernel ms of the last `steps` calls."""
     for _ in range(warmup):
@@ -508,13 +582,14 @@ def other_configs(args):
     K = max(1, args.other_steps)
     res = []
 
-    def entry(name, rows, Q, M, ms, cat, out, **extra):
+    def entry(name, rows, Q, M, ms, cat, out, tag=None, **extra):
         fl = 3.0 * rows * Q * M * M + 20.0 * Q * M ** 3
         dk, dms = _dominant(cat)
         e = {"workload": name, "ms_per_step": ms, "steps_per_s": 1e3 / ms, "flops_executed": fl,
              "tflops": fl / ms / 1e9, "frac_of_peak": fl / ms / 1e9 / PEAK_FP64_MFMA_TFLOPS,
              "dominant_kernel": dk, "dominant_kernel_ms": dms,
              "kernel_ms_per_step": {k: round(v, 4) for k, v in cat.items()}, "elbo": out["elbo"], "steps": K}
+        e["roofline"] = _config_roofline(rows, Q, M, cat, tag)
         e.update(extra)
         res.append(e)
 
@@ -527,16 +602,18 @@ def other_configs(args):
             raise SystemExit("bench.py: non-finite ELBO in " + name)
         return eng, prm, X, Y, ms, cat, out
 
+
     # C1 -- the reference's own CPU-runnable case (README usage snippet's likelihood list)
     c1 = [("HetGaussian", {}), ("Bernoulli", {}), ("Categorical", {"K": 3})]
     eng, prm, X, Y, ms, cat, out = run("C1", c1, 1000, 50, 2, 1, 20260930)
     entry("C1: T=3 [HetGaussian,Bernoulli,Categorical(3)] Df=5, N_t=1000, M=50, Q=2, full-batch ELBO+gradients", 3000, 2, 50,
-          ms, cat, out, note="launch-latency bound (about 40 kernel launches); compare cpu_baseline_literal.runs[0]")
+          ms, cat, out, note="launch-latency bound (about 40 kernel launches); compare cpu_baseline_literal.runs[0]",
+          parity_vs_reference_run=_parity_c1_vs_reference_fixture())
     eng.close()
     # C2 -- the headline mix at M = 512
     eng, prm, X, Y, ms, cat, out = run("C2", SPECS, 200000, 512, 3, 1, 20260931)
     entry("C2: T=4 [Gaussian,Bernoulli,Poisson,Gamma] Df=5, N_t=200000, M=512, Q=3, full-batch ELBO+gradients", 800000, 3, 512,
-          ms, cat, out, forward_tflops=2.0 * 800000 * 3 * 512 ** 2 / cat["forward_gemm"] / 1e9,
+          ms, cat, out, tag="C2", forward_tflops=2.0 * 800000 * 3 * 512 ** 2 / cat["forward_gemm"] / 1e9,
           gram_tflops=1.0 * 800000 * 3 * 512 ** 2 / cat["gram_gemm"] / 1e9)
     eng.close()
     # C3 -- SVI streaming: N_all = 1M rows per task, contiguous minibatches of 8192 rows per task and step
@@ -559,8 +636,20 @@ def other_configs(args):
         eng.predict_f(g)
     pms = 1e3 * (time.perf_counter() - t0) / 3
     entry("C5: T=2 [Categorical(4),Gaussian] Df=4, P=2, N_t=50000, M=2048, Q=2, full-batch ELBO+gradients", 100000, 2, 2048,
-          ms, cat, out, predict_f_grid_ms=pms, predict_f_points=65536,
+          ms, cat, out, tag="C5", predict_f_grid_ms=pms, predict_f_points=65536,
           predict_f_tflops=1.0 * 65536 * 2 * 2048 ** 2 / pms / 1e9)   # triangular fold: n Q M^2 executed
+    eng.close()
+    # HD -- the headline shape with a DENSE-VALUED operand: lengthscale = 40 inducing spacings (K^ has no exact zeros: the
+    # headline's own K^ is > 90 % exact 0.0 because its lengthscales are about one spacing), GPy's jitter rung 4 forced so that
+    # K_uu factorises.  Same kernels, same launch shapes, same flops: the FP64-MFMA rate on non-zero operands on record.
+    prm, X, Y = make_case(SPECS, [200000] * 4, M=1024, Q=3, P=1, seed=20260929)
+    prm["lengthscale"] = np.full(3, 40.0 / 1023.0)
+    eng = Engine(SPECS, 3, 1024, 1, reuse_outputs=True)
+    eng.set_data(X, Y)
+    ms, cat, out = _time_steps(eng, prm, K, forced_rung=[4, 4, 4])
+    entry("HD: headline shape (N_t=200000, M=1024, Q=3) with a dense-valued K^ (lengthscale = 40 spacings, jitter rung 4 forced)",
+          800000, 3, 1024, ms, cat, out, finite=bool(np.isfinite(out["elbo"])),
+          note="timing record only: K_uu at this lengthscale is numerically singular, the ELBO is not a parity quantity")
     eng.close()
     return res
 
@@ -630,6 +719,7 @@ def svi_config(args, K):
             "ms_per_step": ms, "steps_per_s": 1e3 / ms, "flops_executed": fl, "tflops": fl / ms / 1e9,
             "frac_of_peak": fl / ms / 1e9 / PEAK_FP64_MFMA_TFLOPS, "dominant_kernel": dk, "dominant_kernel_ms": dms,
             "kernel_ms_per_step": {k: round(v, 4) for k, v in cat.items()}, "elbo": out["elbo"], "steps": K,
+            "roofline": _config_roofline(4 * B, Q, M, cat, "C3"),
             "note": "ms_per_step = one full-gradient evaluation of a minibatch (all parameter groups); svi_* = the facade's "
                     "training loop (4 E-steps with q(u) gradients only + 1 M-step, device-resident Adadelta)",
             "svi_ms_per_iteration": it_ms, "svi_iterations_per_s": 1e3 / it_ms, "svi_iterations_timed": n_it,

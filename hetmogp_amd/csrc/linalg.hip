@@ -36,8 +36,6 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {  // wave-un
   return __hiloint2double(hi, lo);
 }
 
-constexpr int LSP = 144;  // k-major leading dimension of the parked panel rows (same bank argument as gemm_f64.hip)
-
 // Value of half `HC` of the wave (lanes 32 HC .. 32 HC + 31) in BOTH halves: v_permlane32_swap_b32 of a register with itself
 // returns {lower half in both halves, upper half in both halves}.
 template <int HC>
@@ -122,9 +120,16 @@ __device__ __forceinline__ long long dinv_slot(int j, int c, int M) {
   return (c < NB - 1) ? (long long)(j + c) * M + (j + c + 1) : (long long)j * M + (j + 2);
 }
 
+// [r4] TS = edge of a trailing-matrix tile.  rocprofv3 (profiles/r04_C3_kernel_stats.csv) shows the chain is bound by the
+// DURATION of a step kernel (23.9 us at M = 1024, 41 us at M = 2048), not by the launch boundary (~1.5 us): the largest piece
+// is the tile update -- with 128 x 128 tiles one wave per SIMD issues 128 MFMAs at half rate (~6.8 us).  TS = 64 gives four
+// times as many blocks (408 at M = 1024, Q = 3) with 32 MFMAs per wave.
+template <int TS>
 __global__ __launch_bounds__(320) void potrf_step_kernel(double* __restrict__ Wall, double* __restrict__ Lall, int M, int j,
                                                          int* __restrict__ info, long long* stamps, int pre) {
   STAMP(0);
+  constexpr int WT = TS / 2, NS = WT / 16;      // wave tile (2 x 2 waves per block tile), 16 x 16 sub-tiles per wave-tile edge
+  constexpr int LSP = TS + 16;                  // k-major leading dimension of the parked panel rows (bank argument: gemm_f64.hip)
   __shared__ __attribute__((aligned(16))) double D[NB][NBP + 1];  // even leading dimension: 16-byte column pairs
   __shared__ __attribute__((aligned(16))) double Ls[2][NB][LSP];
   __shared__ double Dinv[NB];  // reciprocals of the pivots
@@ -160,10 +165,10 @@ __global__ __launch_bounds__(320) void potrf_step_kernel(double* __restrict__ Wa
   }
   __syncthreads();
   STAMP(1);
-  // Wave 4 (threads 256..319) factorises the diagonal block while the other four have their panel rows in flight.
-  const int half = (t >> 7) & 1, tl = t & 127;
-  const int prow = base + (half ? tj : ti) * 128 + tl;
-  const bool pvalid = t < 256 && rem > 0 && prow < M;  // (a ragged last panel, jb < NB, has no rows below it: rem == 0)
+  // Wave 4 (threads 256..319) factorises the diagonal block while the others have their panel rows in flight.
+  const int half = (t / TS) & 1, tl = t % TS;
+  const int prow = base + (half ? tj : ti) * TS + tl;
+  const bool pvalid = t < 2 * TS && rem > 0 && prow < M;  // (a ragged last panel, jb < NB, has no rows below it: rem == 0)
   double x[NB];
   if (t >= 256) {
     if (!pre) {
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(320) void potrf_step_kernel(double* __restrict__ Wa
       if (t == 256) fail = bad;
     }
   } else {
-    // Panel rows of the two row tiles (threads 0..127 -> tile ti, 128..255 -> tile tj): in flight while wave 4 factorises.
+    // Panel rows of the two row tiles (threads 0..TS-1 -> tile ti, TS..2TS-1 -> tile tj): in flight while wave 4 factorises.
     if (pvalid) {
       const double* w = W + (long long)prow * M + j;
       if ((M & 1) == 0) {
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(320) void potrf_step_kernel(double* __restrict__ Wa
     }
   if (rem <= 0) return;
   // x L_jj^T = w, right-looking: the updates of one column are independent FMAs (L_jj read as uniform LDS broadcasts)
-  if (t < 256) {
+  if (t < 2 * TS) {
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
       x[c] *= Dinv[c];
@@ -222,15 +227,15 @@ __global__ __launch_bounds__(320) void potrf_step_kernel(double* __restrict__ Wa
   // row = (lane >> 4) + 4 * reg); the loads are in flight across the barrier.
   const int lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1, lr = lane & 15, lk = lane >> 4;
   const bool idle = t >= 256 || ahead_blk || (ti == tj && wm == 0 && wn == 1);  // factor wave; look-ahead block; strictly-upper quadrant of a diagonal tile
-  f64x4 acc[4][4];
+  f64x4 acc[NS][NS];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NS; ++a)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = base + ti * 128 + wm * 64 + a * 16 + 4 * r + lk;
+      const int row = base + ti * TS + wm * WT + a * 16 + 4 * r + lk;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int col = base + tj * 128 + wn * 64 + b * 16 + lr;
+      for (int b = 0; b < NS; ++b) {
+        const int col = base + tj * TS + wn * WT + b * 16 + lr;
         acc[a][b][r] = (!idle && row < M && col <= row) ? W[(long long)row * M + col] : 0.0;
       }
     }
@@ -301,30 +306,30 @@ __global__ __launch_bounds__(320) void potrf_step_kernel(double* __restrict__ Wa
   if (idle) return;
 #pragma unroll
   for (int kk = 0; kk < NB / 4; ++kk) {
-    double fa[4], fb[4];
+    double fa[NS], fb[NS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fa[i] = -Ls[0][kk * 4 + lk][wm * 64 + i * 16 + lr];  // W - L21_i L21_j^T
-      fb[i] = Ls[1][kk * 4 + lk][wn * 64 + i * 16 + lr];
+    for (int i = 0; i < NS; ++i) {
+      fa[i] = -Ls[0][kk * 4 + lk][wm * WT + i * 16 + lr];  // W - L21_i L21_j^T
+      fb[i] = Ls[1][kk * 4 + lk][wn * WT + i * 16 + lr];
     }
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NS; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      for (int b = 0; b < NS; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
   }
   STAMP(4);
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NS; ++a)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = base + ti * 128 + wm * 64 + a * 16 + 4 * r + lk;
+      const int row = base + ti * TS + wm * WT + a * 16 + 4 * r + lk;
       // (the next diagonal block, rows base .. base + 31 of tile (0, 0), is NOT written back: the look-ahead block of this
       // launch reads its un-updated values from W, and nothing reads it from W again -- the next launch takes it from Lo)
       if (row >= M || row < base + NB) continue;
       double* wrow = W + (long long)row * M;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int col = base + tj * 128 + wn * 64 + b * 16 + lr;
+      for (int b = 0; b < NS; ++b) {
+        const int col = base + tj * TS + wn * WT + b * 16 + lr;
         if (col <= row) wrow[col] = acc[a][b][r];
       }
     }
@@ -439,8 +444,21 @@ void launch_potrf_batched(double* A, int Q, int M, int* d_info, double* scr, hip
   for (int pnl = panel_begin; pnl < panel_end; ++pnl) {
     const int j = pnl * NB;
     const int rem = M - j - std::min(NB, M - j);
-    const int T = (rem + 127) / 128;
-    hipLaunchKernelGGL(potrf_step_kernel, dim3(std::max(1, T * (T + 1) / 2) + (rem > 0 ? 1 : 0), Q), dim3(320), 0, stream, A, scr, M, j, d_info, j == 0 ? g_potrf_stamps : nullptr, pnl > 0 ? 1 : 0);
+    static const int forced = [] {   // HMOGP_POTRF_TILE=64|128: force one tile size (A/B runs)
+      const char* e = getenv("HMOGP_POTRF_TILE");
+      return e ? atoi(e) : 0;
+    }();
+    // 64 x 64 tiles while they give at most two blocks per CU (block 0's critical path 19 -> 10.4 us, phase stamps in
+    // profiles/r04_potrf_phases.txt; 0.608 -> 0.546 ms at M = 1024, Q = 3); with more blocks than that the redundant diagonal-
+    // block loads and panel solves of every block cost more than the shorter tile update gains (M = 2048: 1.53 -> 1.79 ms).
+    const int T64 = (rem + 63) / 64;
+    const int ts = forced == 64 || forced == 128 ? forced : ((long long)T64 * (T64 + 1) / 2 * Q <= 512 ? 64 : 128);
+    const int T = (rem + ts - 1) / ts;
+    const dim3 grid(std::max(1, T * (T + 1) / 2) + (rem > 0 ? 1 : 0), Q);
+    if (ts == 128)
+      hipLaunchKernelGGL(potrf_step_kernel<128>, grid, dim3(320), 0, stream, A, scr, M, j, d_info, pnl == npanels / 2 ? g_potrf_stamps : nullptr, pnl > 0 ? 1 : 0);
+    else
+      hipLaunchKernelGGL(potrf_step_kernel<64>, grid, dim3(320), 0, stream, A, scr, M, j, d_info, pnl == npanels / 2 ? g_potrf_stamps : nullptr, pnl > 0 ? 1 : 0);
   }
   if (panel_end == npanels) hipLaunchKernelGGL(potrf_finalize_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, stream, A, M, scr);
 }

@@ -4,8 +4,8 @@
 #include <vector>
 #include <cmath>
 extern long long* g_potrf_stamps;
-int main() {
-  const int Q = 3, M = 1024;
+int main(int argc, char** argv) {
+  const int Q = 3, M = argc > 1 ? atoi(argv[1]) : 1024;
   const long long MM = (long long)M * M;
   std::vector<double> h(Q * MM);
   for (int q = 0; q < Q; ++q)
@@ -27,7 +27,7 @@ int main() {
     HIP_TRY(hipEventSynchronize(e1));
     float ms; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     long long st[16]; HIP_TRY(hipMemcpy(st, stamps, sizeof st, hipMemcpyDeviceToHost));
-    printf("potrf Q=%d M=%d: %.3f ms;  stamps (cycles since kernel start, block 0 of first launch):", Q, M, ms);
+    printf("potrf Q=%d M=%d: %.3f ms;  stamps 1..7 (clock64 ticks since kernel start; block 0 of the MIDDLE panel launch; 6 = look-ahead block done):", Q, M, ms);
     for (int i = 1; i < 8; ++i) printf(" %lld", st[i] - st[0]);
     printf("\n");
   }

@@ -26,6 +26,8 @@ def short(name):
 
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "02"
+    if len(sys.argv) > 2:          # a workload of tools/profile_configs.sh: gpurun_out/prof_r<round>_<W> -> profiles/r<round>_<W>_*
+        rnd = "%s_%s" % (rnd, sys.argv[2])
     src = os.path.join(ROOT, "gpurun_out", "prof_r%s" % rnd)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -84,7 +86,7 @@ def main():
     # the forward contraction of the headline workload's full chunk: the dominant kernel's traffic for bench.py
     fwd = [r for r in rows if r["kernel"].startswith("rowpass_gemm_kernel<1>") or r["kernel"].startswith("gemm_f64_kernel<false, true, 1>")]
     fwd.sort(key=lambda r: -r["grid_threads"])
-    if fwd:
+    if fwd and len(sys.argv) <= 2:
         json.dump({"kernel": fwd[0]["kernel"], "grid_threads": fwd[0]["grid_threads"], "launches": fwd[0]["launches"],
                    "hbm_bytes_per_launch": fwd[0]["hbm_bytes_per_launch"], "source": "profiles/r%s_pmc_hbm.csv" % rnd,
                    "note": "forward contraction of ONE launch = all 800000 rows x all Q=3 latents of the headline workload; "
