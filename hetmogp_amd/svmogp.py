@@ -201,6 +201,11 @@ class SVMOGP(object):
         """The reference's constructor (svmogp.py:17) plus engine options (no reference equivalent):
         device            HIP device ordinal; default: LOCAL_RANK when `distributed`, else 0
         distributed       one process per GPU inside an initialised torch.distributed group: rows are sharded over ranks
+        exact_zero_windows  False (default: dense) | True | "auto": the opt-in mode that skips products with EXACT zeros of K_uf
+                          (results unchanged).  "auto" turns it on where it can pay off -- 1-D inputs that are
+                          sorted within every task (what the reference's own slicing assumes, util.py:52-72) and
+                          M <= 8192; unsorted / multi-dimensional inputs stay dense (and even when it is on, the
+                          device falls back to full ranges for rows that are not banded)
         quirks            "reference" (default: reproduce the reference's results including its known deviations from the
                           exact gradient) | "exact" (true ELBO gradients) | an int mask of _lib.QUIRK_*
         gradients_of_fixed  batch mode only: also evaluate the gradient groups whose parameters are all fixed (the
@@ -231,6 +236,12 @@ class SVMOGP(object):
         self.Ymulti_all = [np.ascontiguousarray(y, dtype=float).reshape(-1, 1) for y in Y]
         T = len(self.Ymulti_all)
         self.Xdim = Z.shape[1]
+        if isinstance(exact_zero_windows, str):
+            if exact_zero_windows != "auto":
+                raise ValueError("exact_zero_windows must be False, True or 'auto'")
+            exact_zero_windows = bool(self.Xdim == 1 and self.num_inducing <= 8192 and
+                                      all(x.shape[0] < 2 or bool(np.all(np.diff(x[:, 0]) >= 0.0)) for x in self.Xmulti_all))
+        self.exact_zero_windows = bool(exact_zero_windows)
         self._engine = Engine(likelihood.specs(), self.num_latent_funcs, self.num_inducing, self.Xdim, device=device,
                               chunk_rows=chunk_rows, exact_zero_windows=exact_zero_windows, cache_kuu=True,
                               reuse_outputs=True, quirks=quirks)   # gradients arrive in engine-owned page-locked arrays, copied into

@@ -228,8 +228,8 @@ def _nccl_worker(rank, world, port, q, mode=None):
     e.step_begin(**prm)
     red()
     out = e.step_finish()
-    if red.mode == "native":                          # and the one-call form
-        out1 = e.elbo_grad(**prm)
+    if red.mode == "native":                          # and the one-call form (hmogp_elbo_grad_sharded: collective)
+        out1 = e.elbo_grad(sharded=True, **prm)
         assert out1["elbo"] == out["elbo"] and np.array_equal(out1["g_L_u"], out["g_L_u"])
         assert e.timings()[0]["exchange"] > 0.0
     ones = torch.ones(1, dtype=torch.float64, device="cuda")
@@ -342,3 +342,43 @@ def test_facade_distributed_two_gpus_rccl_matches_reference_fixture():
         assert abs(elbo - float(np.ravel(g["elbo"])[0])) < 1e-8 * abs(float(np.ravel(g["elbo"])[0]))
         assert np.max(np.abs(gZ - g["g_Z"])) < 1e-8 * np.max(np.abs(g["g_Z"]))
         assert np.max(np.abs(gL - g["g_L_u"])) < 1e-8 * np.max(np.abs(g["g_L_u"]))
+
+
+@pytest.mark.timeout(600)
+def test_plain_c_two_ranks_file_rendezvous_no_torch(tmp_path):
+    """The row-sharded step from PLAIN C, one process per GPU, no Python / torch / MPI in the ranks: examples/c_abi_two_rank.c
+    (ncclUniqueId handed from rank 0 to rank 1 through a file; hmogp_comm_init; hmogp_elbo_grad_sharded).  Every rank must
+    print the same ELBO / gradients as the unsharded single-GPU evaluation rank 0 runs afterwards.  Skipped on 1-GPU boxes."""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+    exe = str(tmp_path / "two_rank")
+    subprocess.run(["gcc", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_two_rank.c"), "-o", exe,
+                    "-L" + os.path.join(ROOT, "hetmogp_amd"), "-lhetmogp_hip", "-Wl,-rpath," + os.path.join(ROOT, "hetmogp_amd"),
+                    "-lm"], check=True)
+    idfile = str(tmp_path / "hm_id.bin")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([exe, str(r), "2", idfile], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(2)]
+    outs = [p.communicate(timeout=500) for p in procs]
+    for p, (so_, se_) in zip(procs, outs):
+        assert p.returncode == 0, se_[-2000:]
+    lines = [l for so_, _ in outs for l in so_.splitlines() if " elbo " in l]
+    vals = {}
+    for l in lines:
+        tok = l.split()
+        key = (tok[1], tok[2])                                  # ("0" | "1", "sharded" | "single")
+        nums = []
+        for x in tok:
+            try:
+                nums.append(float(x))                          # [rank, elbo, g_var x2, g_ell x2, three sums, exchange_ms]
+            except ValueError:
+                pass
+        vals[key] = nums
+    single = vals[("0", "single")]
+    for r in ("0", "1"):
+        got = vals[(r, "sharded")]
+        for a, b in zip(got[1:9], single[1:9]):                 # elbo, g_var x2, g_ell x2, three weighted gradient sums
+            assert abs(a - b) <= 1e-9 * max(1.0, abs(b)), (r, a, b)
+    assert vals[("0", "sharded")][1:9] == vals[("1", "sharded")][1:9]          # replicated finish: identical bits on every rank

@@ -328,3 +328,41 @@ def test_q_u_read_mid_loop_sees_the_last_evaluation_and_observers_are_weak():
     gc.collect()
     assert ref() is None
     kern[0].variance[...] = 0.7                                        # must not raise on the dead observer
+
+
+def test_exact_zero_windows_auto_selects_by_input_layout_and_keeps_results():
+    """exact_zero_windows="auto" (VERDICT r3 item 8): on for sorted 1-D inputs, off for unsorted or 2-D ones; results equal the
+    dense model's either way (the mode only skips products with exact zeros)."""
+    g = np.load(os.path.join(GOLDEN, "ref_h_mix_M128.npz"))
+    import hetmogp_amd as H
+    import hetmogp_amd.svmogp as sv
+    dense = build_model(g)
+    dense.parameters_changed()
+    orig = sv.SVMOGP.__init__
+
+    def patched(self, *a, **kw):
+        kw["exact_zero_windows"] = "auto"
+        return orig(self, *a, **kw)
+    sv.SVMOGP.__init__ = patched
+    try:
+        auto = build_model(g)
+        assert auto.exact_zero_windows is True            # the fixture's inputs are sorted per task (build_case)
+        auto.parameters_changed()
+        assert rel(auto.log_likelihood(), dense.log_likelihood()) < 1e-11
+        assert rel(auto.q_u_chols.gradient, dense.q_u_chols.gradient) < 1e-10
+        assert rel(auto.Z.gradient, dense.Z.gradient) < 1e-10
+        g2 = np.load(os.path.join(GOLDEN, "ref_c5_2d_M144.npz"))
+        assert build_model(g2).exact_zero_windows is False          # 2-D inputs
+        gs = {k: g[k] for k in g.files}
+        gs["Xall_0"] = g["Xall_0"][::-1].copy()
+        gs["Yall_0"] = g["Yall_0"][::-1].copy()
+
+        class _G(dict):
+            files = list(gs.keys())
+        assert build_model(_G(gs)).exact_zero_windows is False      # unsorted rows
+    finally:
+        sv.SVMOGP.__init__ = orig
+    with pytest.raises(ValueError):
+        H.SVMOGP(X=[g["Xall_0"]], Y=[g["Yall_0"]], Z=g["Z"][:, :1].copy(), kern_list=dense.kern_list[:1],
+                 likelihood=H.HetLikelihood([H.Gaussian(sigma=0.5)]),
+                 Y_metadata=H.HetLikelihood([H.Gaussian(sigma=0.5)]).generate_metadata(), exact_zero_windows="maybe")
