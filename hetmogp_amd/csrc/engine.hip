@@ -53,6 +53,7 @@ static_assert((int)ncclSuccess == hm_nccl::Success && (int)ncclInProgress == hm_
 #include "common.h"
 #include "post.h"
 #include "rowpass.h"
+#include "small_model.h"
 
 namespace {
 
@@ -69,12 +70,18 @@ struct DevBuf {
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr, o.bytes = 0; }
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), owned(o.owned) { o.p = nullptr, o.bytes = 0; }
   ~DevBuf() { release(); }
+  bool owned = true;
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
     p = nullptr;
     bytes = 0;
+    owned = true;
+  }
+  void view(void* ptr, size_t b) {   // non-owning window into another allocation
+    release();
+    p = ptr, bytes = b, owned = false;
   }
   void ensure(size_t b, bool zero = false) {
     if (b <= bytes) return;
@@ -122,6 +129,9 @@ int lik_dimf(int lik, double param) {
 // Row ranges per weighted-Gram launch: a multiple of 8 (one range per XCD at a time), each >= 32 k-steps of 16 rows,
 // enough blocks (lower tiles x ranges) for >= 8 rounds over the 256 CUs, at most KS_MAX slabs.
 constexpr int KS_MAX = 256;  // most row ranges (slabs) of the weighted Gram
+// rows per slab of the column statistics: 256, or 32 for short passes (one thread owns two columns and walks the rows of its
+// slab one after the other: at M = 50 a 256-row slab is 25 threads x 256 dependent steps, 110 us for 3000 rows)
+inline long long col_split(long long n) { return n <= 16384 ? 32 : 256; }
 int gram_ksplit(long long n, int M) {
   static const int forced = [] {   // HMOGP_GRAM_KSPLIT=<row ranges> (experiments; profiles/r03_gram_ksplit.txt: flat)
     const char* e = getenv("HMOGP_GRAM_KSPLIT");
@@ -134,6 +144,9 @@ int gram_ksplit(long long n, int M) {
   // apart as they stream it; shorter ranges keep the shared K^ rows in that XCD's L2)
   long long want = std::max<long long>((8 * 256 + ntl - 1) / ntl, n / 8192);
   want = std::min<long long>(std::min<long long>(KS_MAX, std::max<long long>(1, ksteps / 32)), want);
+  // [r4] short passes (a few thousand rows, small M: BASELINE config 1): a handful of blocks each looping over hundreds of rows
+  // is latency-bound (77 us for 3000 rows at M = 50) -- row ranges of 8 k-steps while the grid stays below one block per CU
+  if (ntl * want < 256) want = std::max(want, std::min<long long>(std::min<long long>(KS_MAX, std::max<long long>(1, ksteps / 8)), 256 / ntl));
   return (int)(want >= 8 ? (want / 8) * 8 : std::max<long long>(1, want));
 }
 
@@ -282,7 +295,9 @@ struct hmogp_engine {
   std::vector<long long> rb, re;
   std::vector<int> rung;
   unsigned group_mask = HMOGP_GROUP_ALL;
-  DevBuf dZ, dmu, dLflat, dvar, dell, dW, dkap;
+  DevBuf dZ, dmu, dLflat, dvar, dell, dW, dkap, dsmall;
+  double* h_small = nullptr;
+  long long n_small = 0;
   // M x M (each Q*M*M)
   DevBuf Kuu, Luu, Kuui, L, S, KiS, KSK, C, Ctri, Sqi, tmpA, tmpB, HK, G, GSK, dKmm, dLdS;
   DevBuf a, Kr, gmu, gL, klout, rowout, dinfo, djit, dscr;
@@ -311,6 +326,18 @@ struct hmogp_engine {
   long long launches[NCAT] = {0};
   hipEvent_t ev_begin0 = nullptr, ev_begin1 = nullptr, ev_fin0 = nullptr, ev_fin1 = nullptr;
   bool st2_masked = false;    // the second stream leaves a few CUs of every XCD to the latency-bound chains (HMOGP_ST2_FREE)
+  // [r4] SMALL-PROBLEM MODE (M <= 128 and <= 65536 rows in the evaluation; BASELINE config 1 is M = 50, 3000 rows): such a step is
+  // bound by the HOST (45 launches, 15 copies, 37 event records: ~0.6 ms of API time, profiles/r04_c1_hip_api_stats.csv) and by
+  // cross-queue dependencies (every hipStreamWaitEvent between two hardware queues costs ~10 us of device idle time), not by
+  // any kernel.  In this mode the three streams are ONE (st2 = st3 = st: event waits on the same queue are free) and the per-
+  // family timing spans are not recorded (hmogp_last_timings then reports the total only).
+  hipStream_t st2_own = nullptr, st3_own = nullptr;
+  bool small_mode = false;
+  // ... and with M <= HMOGP_SMALL_M the replicated M x M algebra runs as TWO fused kernels, one block per latent with every matrix
+  // in LDS (small_model.hip), instead of ~30 launches.  A factorisation that needs GPy's jitter ladder is repeated on the regular
+  // path (small_veto), which owns the ladder.
+  bool small_path = false, small_veto = false, small_info_pending = false;
+  struct RetryRegular {};
   hipStream_t st2 = nullptr;  // second stream, LOW priority: bandwidth-bound work beside the main stream (K_uf prefetch, colstats)
   hipStream_t st3 = nullptr;  // third stream, HIGH priority like the main one: the q(u)-only chains (S, S^-1; dL/dL, D2H)
   hipEvent_t ev_qu = nullptr;   // behind an in-place update of the resident q(u) (hmogp_qu_natgrad)
@@ -332,7 +359,7 @@ struct hmogp_engine {
     bool on_;
     Scope(hmogp_engine* eng, int cat, int nlaunch, hipStream_t on = nullptr) : e(eng), stream(on ? on : eng->st) {
       static const bool off = getenv("HMOGP_NO_SPANS") != nullptr;   // experiment: what the timing events themselves cost
-      on_ = !off;
+      on_ = !off && !eng->small_mode;
       s.cat = cat;
       e->launches[cat] += nlaunch;
       if (!on_) return;
@@ -444,12 +471,13 @@ struct hmogp_engine {
     comm_destroy();
     for (auto e : pool) (void)hipEventDestroy(e);
     if (h_info2) (void)hipHostFree(h_info2);
+    if (h_small) (void)hipHostFree(h_small);
     for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_gsk, ev_zero, ev_info, ev_S, ev_join, ev_col, ev_kuf, ev_params, ev_ua, ev_qu})
       if (e) (void)hipEventDestroy(e);
     if (hstage) (void)hipHostFree(hstage);
     if (h_info) (void)hipHostFree(h_info);
-    if (st2) (void)hipStreamDestroy(st2);
-    if (st3) (void)hipStreamDestroy(st3);
+    if (st2_own) (void)hipStreamDestroy(st2_own);
+    if (st3_own) (void)hipStreamDestroy(st3_own);
     if (st) (void)hipStreamDestroy(st);
   }
 
@@ -512,6 +540,7 @@ struct hmogp_engine {
       }
       if (!st2) HIP_TRY(hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, lo));
       HIP_TRY(hipStreamCreateWithPriority(&st3, hipStreamNonBlocking, hi));
+      st2_own = st2, st3_own = st3;
     }
     for (hipEvent_t* e : {&ev_fork, &ev_gsk, &ev_zero, &ev_info, &ev_S, &ev_join, &ev_col, &ev_kuf, &ev_params, &ev_ua, &ev_qu})
       HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -564,8 +593,13 @@ struct hmogp_engine {
     dZ.ensure(sizeof(double) * M * Q * P);
     dmu.ensure(sizeof(double) * M * Q);
     dLflat.ensure(sizeof(double) * ((long long)M * (M + 1) / 2) * Q);
-    dvar.ensure(sizeof(double) * Q), dell.ensure(sizeof(double) * Q);
-    dW.ensure(sizeof(double) * Q * Df), dkap.ensure(sizeof(double) * Q * Df);
+    // the four small hyper-parameter arrays live in ONE device block and go up in ONE copy from a page-locked image
+    // (a host-bound small-model step pays ~4-8 us of API time per hipMemcpyAsync)
+    n_small = 2 * Q + 2 * Q * Df + Q;   // variance | lengthscale | W | kappa | jitter of the small path
+    dsmall.ensure(sizeof(double) * n_small);
+    HIP_TRY(hipHostMalloc((void**)&h_small, sizeof(double) * n_small, hipHostMallocDefault));
+    dvar.view(dsmall.d(), sizeof(double) * Q), dell.view(dsmall.d() + Q, sizeof(double) * Q);
+    dW.view(dsmall.d() + 2 * Q, sizeof(double) * Q * Df), dkap.view(dsmall.d() + 2 * Q + Q * Df, sizeof(double) * Q * Df);
     a.ensure(sizeof(double) * Q * M), Kr.ensure(sizeof(double) * Q * M), gmu.ensure(sizeof(double) * Q * M);
     gL.ensure(sizeof(double) * ((long long)M * (M + 1) / 2) * Q);
     klout.ensure(sizeof(double) * Q * KL_BLOCKS * 5);
@@ -579,6 +613,7 @@ struct hmogp_engine {
     Task& k = tasks[t];
     k.N = N;
     began = false;
+    staged_key.clear();
     if (N == 0) return;
     k.X.ensure(sizeof(double) * N * P);
     k.Y.ensure(sizeof(double) * N);
@@ -596,8 +631,9 @@ struct hmogp_engine {
     if (rows <= ws_rows) return;
     const size_t nm = sizeof(double) * rows * M * Q, nv = sizeof(double) * rows * Q;
     Kh.ensure(nm), Pt.ensure(nm), Xws.ensure(sizeof(double) * rows * P);
+    staged_key.clear();
     for (DevBuf* b : {&vp, &vc, &vpt, &vct, &valpha, &vbeta, &valpha0, &vbeta0}) b->ensure(nv, true);
-    colpart.ensure(sizeof(double) * ((rows + 255) / 256) * M * (1 + P) * Q);
+    colpart.ensure(sizeof(double) * std::max((rows + 255) / 256, (std::min<long long>(rows, 16384) + 31) / 32) * M * (1 + P) * Q);
     quadpart.ensure(sizeof(double) * (rows * 64 / 256 + 1) * HMOGP_MAXSCAL);
     fwdpart.ensure(sizeof(double) * 4 * FWD_PARTS * ((M + 127) / 128) * rows * Q);  // 4 statistics x FWD_PARTS wave columns per tile
     if (use_windows) {
@@ -647,10 +683,14 @@ struct hmogp_engine {
     // the one large parameter (12.6 MB at M = 1024, Q = 3) goes up on the second stream, whose chain is its only consumer
     // (u_algebra): the K_uu chain on the main stream starts without waiting for it
     if (!resident) HIP_TRY(hipMemcpyAsync(dLflat.p, p->L_flat, sizeof(double) * Mtri * Q, hipMemcpyHostToDevice, st3));
-    HIP_TRY(hipMemcpyAsync(dvar.p, h_var.data(), sizeof(double) * Q, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dell.p, h_ell.data(), sizeof(double) * Q, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dW.p, h_W.data(), sizeof(double) * Q * Df, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dkap.p, h_kap.data(), sizeof(double) * Q * Df, hipMemcpyHostToDevice, st));
+    // (h_small is re-written only after the previous evaluation has synchronised the stream that read it)
+    std::copy(h_var.begin(), h_var.end(), h_small);
+    std::copy(h_ell.begin(), h_ell.end(), h_small + Q);
+    std::copy(h_W.begin(), h_W.end(), h_small + 2 * Q);
+    std::copy(h_kap.begin(), h_kap.end(), h_small + 2 * Q + Q * Df);
+    for (int q = 0; q < Q; ++q)      // small path: jitter of a forced rung (GPy jitchol: mean(diag) 1e-6 10^k, diag(K_uu) = variance)
+      h_small[2 * Q + 2 * Q * Df + q] = rung[q] >= 0 ? h_var[q] * 1e-6 * std::pow(10.0, rung[q]) : 0.0;
+    HIP_TRY(hipMemcpyAsync(dsmall.p, h_small, sizeof(double) * n_small, hipMemcpyHostToDevice, st));
     if (resident) HIP_TRY(hipStreamWaitEvent(st3, ev_qu, 0));   // an in-place natural-gradient update of the resident q(u)
     HIP_TRY(hipEventRecord(ev_params, st));   // what the second stream has to wait for before it reads Z / the hypers
   }
@@ -673,7 +713,34 @@ struct hmogp_engine {
   }
 
   // ------------------------------------------------------------------------------------------ u algebra
+  void u_algebra_small() {
+    Scope sc(this, CAT_MM, 1);
+    kuu_key_valid = false;
+    if (!h_info) HIP_TRY(hipHostMalloc((void**)&h_info, sizeof(int) * HMOGP_MAXQ, hipHostMallocDefault));
+    // (the jitter of a forced rung went up with the hyper-parameter block: upload_params)
+    for (int q = 0; q < Q; ++q)
+      if (rung[q] == -2) rung[q] = -1;
+    HIP_TRY(hipMemsetAsync(dinfo.p, 0, sizeof(int) * Q, st));
+    if (!pools.empty()) {
+      HIP_TRY(hipMemsetAsync(stats.p, 0, sizeof(double) * nstats, st));
+      stage_pool_inputs(pools[0], st);
+      kuf_pool(pools[0], st);
+      kuf_prefetched = true;
+      HIP_TRY(hipEventRecord(ev_kuf, st));
+    }
+    SmallU u;
+    u.M = M, u.Q = Q, u.P = P, u.ldz = Q * P;
+    u.Z = dZ.d(), u.var = dvar.d(), u.ell = dell.d(), u.jit = dsmall.d() + 2 * Q + 2 * Q * Df, u.mu = dmu.d(), u.Lflat = dLflat.d();
+    u.Kuu = Kuu.d(), u.Luu = Luu.d(), u.Kuui = Kuui.d(), u.L = L.d(), u.S = S.d(), u.KiS = KiS.d(), u.KSK = KSK.d(), u.C = C.d();
+    u.Ctri = Ctri.d(), u.Sqi = Sqi.d(), u.a = a.d(), u.klout = klout.d(), u.info = dinfo.as<int>();
+    launch_u_small(u, st);
+    HIP_TRY(hipMemcpyAsync(h_info, dinfo.p, sizeof(int) * Q, hipMemcpyDeviceToHost, st));
+    small_info_pending = true;
+    HIP_TRY(hipEventRecord(ev_join, st));    // (what hmogp_step_finish orders itself behind on the regular path)
+  }
+
   void u_algebra() {
+    if (small_path) return u_algebra_small();
     Scope sc(this, CAT_MM, 0);
     const long long MM = (long long)M * M;
     const int ldz = Q * P;
@@ -816,6 +883,15 @@ struct hmogp_engine {
     int* cw = use_windows ? wincol.as<int>() : nullptr;    // [Q][ncb][2]
     seg_end = std::min(seg_end, pl.size());
     if (seg_begin >= seg_end) return;
+    if (small_mode && pl.size() > 1 && seg_begin == 0 && seg_end == pl.size() && !use_windows) {
+      // small-problem mode: the pool's rows are contiguous in Xws (stage_pool_inputs): ONE launch for all tasks and latents
+      Scope sc(this, CAT_RBF, 1, stream);
+      RbfBatch rbt;
+      rbt.nq = Q, rbt.var = dvar.d(), rbt.ell = dell.d(), rbt.sZ = P, rbt.sK = sK, rbt.sWin = 2 * wtiles;
+      const long long n = pl.back().off + pl.back().n;
+      launch_rbf(Xws.d(), P, n, P, dZ.d(), ldz, M, 0.0, 1.0, Kh.d(), false, stream, nullptr, false, &rbt);
+      return;
+    }
     Scope sc(this, CAT_RBF, (int)(seg_end - seg_begin) + (use_windows ? 3 * Q : 0), stream);
     for (size_t si = seg_begin; si < seg_end; ++si) {
       const Seg& sg = pl[si];
@@ -841,8 +917,15 @@ struct hmogp_engine {
   }
 
   // inputs of a multi-segment pool, contiguous in pool order (fs_x of the forward epilogue, the column statistics)
+  // (the staged copy is reused while the SAME segments of the SAME data are asked for again -- every full-batch evaluation after
+  //  the first: one D2D copy per task less per step, which matters for host-bound small models)
+  std::vector<long long> staged_key;
   void stage_pool_inputs(const std::vector<Seg>& pl, hipStream_t stream) {
     if (pl.size() <= 1) return;
+    std::vector<long long> key;
+    for (auto& sg : pl) key.push_back(sg.t), key.push_back(sg.r0), key.push_back(sg.n), key.push_back(sg.off);
+    if (pools.size() == 1 && key == staged_key) return;
+    staged_key = pools.size() == 1 ? key : std::vector<long long>();
     for (auto& sg : pl)
       HIP_TRY(hipMemcpyAsync(Xws.d() + sg.off * P, tasks[sg.t].X.d() + sg.r0 * P, sizeof(double) * sg.n * P,
                              hipMemcpyDeviceToDevice, stream));
@@ -877,7 +960,8 @@ struct hmogp_engine {
       const long long sPart = 4LL * FWD_PARTS * tiles * ldn;
       const long long clen = (long long)M * (1 + P);          // one column-statistics slab: [ r (M) | dZ (M*P) ]
       // slabs of the column statistics: 256-row splits
-      const long long nsp = (n + 255) / 256;                  // 256-row slabs of the column statistics
+      const long long csplit = col_split(n);
+      const long long nsp = (n + csplit - 1) / csplit;        // slabs of the column statistics
 
       auto quad_segment = [&](const Seg& sg) {
         Task& k = tasks[sg.t];
@@ -927,7 +1011,7 @@ struct hmogp_engine {
         // (P > 1: more arithmetic per byte -- a block streams 4.8 instead of 6.3 GB/s at P = 2 -- so proportionally more of them)
         const int cap = cap_env >= 0 ? cap_env : (use_windows ? 0 : std::max(48, (int)(196608.0 * (1.0 + 0.35 * (P - 1)) / std::max(1, M))));
         launch_colstats(Kh.d() + off * M, Pt.d() + off * M, a.d(), valpha.d() + off, valpha0.d() + off, vbeta0.d() + off,
-                        X + off * P, P, dZ.d(), ldz, rows, M, 256, want_z, colpart.d() + slab_first * clen, st2, cw, &cb, cap);
+                        X + off * P, P, dZ.d(), ldz, rows, M, (int)csplit, want_z, colpart.d() + slab_first * clen, st2, cw, &cb, cap);
       };
 
       {
@@ -1017,12 +1101,38 @@ struct hmogp_engine {
     HIP_TRY(hipStreamSynchronize(st));
   }
 
-  void begin(const hmogp_params* p, bool sync = true) {
+  void begin(const hmogp_params* p, bool sync = true, bool will_exchange = false) {
     HIP_TRY(hipSetDevice(device));
     began = false, exchanged = false;
     spans.clear();  // a failed evaluation may have left unmatched timing spans behind
     pool_used = 0;
     for (int c = 0; c < NCAT; ++c) ms[c] = 0.0, launches[c] = 0;
+    {
+      static const int small_env = [] {   // HMOGP_SMALL_MODE=0|1: force the small-problem mode off / on (A/B runs)
+        const char* e = getenv("HMOGP_SMALL_MODE");
+        return e ? atoi(e) : -1;
+      }();
+      long long rows_eval = 0;
+      for (int t = 0; t < T && p; ++t) {
+        const long long b = p->row_begin ? p->row_begin[t] : 0, e = p->row_end ? p->row_end[t] : tasks[t].N;
+        rows_eval += std::max<long long>(0, e - b);
+      }
+      const bool want_small = small_env >= 0 ? small_env != 0 : (M <= 128 && rows_eval <= 65536 && !use_windows && !st2_masked);
+      if (want_small != small_mode) {     // (rare: drain the queues the previous evaluations used before re-wiring them)
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipStreamSynchronize(st2_own));
+        HIP_TRY(hipStreamSynchronize(st3_own));
+        small_mode = want_small;
+        st2 = small_mode ? st : st2_own;
+        st3 = small_mode ? st : st3_own;
+      }
+      static const int path_env = [] {   // HMOGP_SMALL_PATH=0: keep the regular kernels in small-problem mode (A/B runs)
+        const char* e = getenv("HMOGP_SMALL_PATH");
+        return e ? atoi(e) : 1;
+      }();
+      small_path = small_mode && M <= HMOGP_SMALL_M && path_env != 0 && !small_veto;
+      small_info_pending = false;
+    }
     upload_params(p);
     HIP_TRY(hipEventRecord(ev_begin0, st));
     plan_pools();
@@ -1032,7 +1142,33 @@ struct hmogp_engine {
     // hmogp_step_begin returns with the bundle complete (the caller all-reduces it); the fused hmogp_elbo_grad goes straight
     // on to enqueue the post-processing behind the row pass -- no host round trip, no launch latency in the tail
     if (sync) HIP_TRY(hipStreamSynchronize(st));
+    if (small_path && (sync || will_exchange)) {   // callers that exchange the bundle must know NOW whether the factorisation held
+      if (!sync) HIP_TRY(hipStreamSynchronize(st));
+      if (small_failed()) {
+        small_veto = true;
+        try {
+          begin(p, sync, will_exchange);
+        } catch (...) {
+          small_veto = false;
+          throw;
+        }
+        small_veto = false;
+        return;
+      }
+    }
     began = true;
+  }
+  // after a synchronisation behind u_small_kernel: did a latent's plain factorisation fail?  (forced rung: an error)
+  bool small_failed() {
+    if (!small_info_pending) return false;
+    small_info_pending = false;
+    bool failed = false;
+    for (int q = 0; q < Q; ++q)
+      if (h_info[q] != 0) {
+        if (rung_request[q] != -2) throw EngineError{HMOGP_E_NOT_PD, "Cholesky failed at the forced jitter rung"};
+        failed = true;
+      }
+    return failed;
   }
 
   // ------------------------------------------------------------------------------------------ finish
@@ -1045,6 +1181,24 @@ struct hmogp_engine {
     const bool want_hz = (group_mask & (HMOGP_GROUP_HYPER | HMOGP_GROUP_Z)) != 0;
     HIP_TRY(hipEventRecord(ev_fin0, st));
     HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));   // the S^-1 chain of hmogp_step_begin (third stream) used HK / G as scratch
+    if (small_path) {
+      // M <= 64: the whole post-processing of the bundle in ONE kernel (one block per latent, matrices in LDS), then the K_uu-side
+      // row sums; q(u) gradients leave on the same (only) stream
+      Scope sc(this, CAT_MM, 2);
+      SmallF f;
+      f.M = M, f.Q = Q, f.want_qu = want_qu ? 1 : 0, f.want_hz = want_hz ? 1 : 0, f.per_q = per_q, f.oR = oR;
+      f.H = Hq(0), f.Hfull = Hq(0), f.Kuui = Kuui.d(), f.KiS = KiS.d(), f.KSK = KSK.d(), f.Sqi = Sqi.d(), f.L = L.d(), f.a = a.d();
+      f.G = G.d(), f.GSK = GSK.d(), f.dLdS = dLdS.d(), f.dKmm = dKmm.d(), f.Kr = Kr.d(), f.gL = gL.d(), f.gmu = gmu.d();
+      launch_finish_small(f, st);
+      if (want_qu) {
+        if (out->g_L_u && (group_mask & HMOGP_GROUP_QU))
+          HIP_TRY(hipMemcpyAsync(out->g_L_u, gL.p, sizeof(double) * Mtri * Q, hipMemcpyDeviceToHost, st));
+        if (out->g_m_u && (group_mask & HMOGP_GROUP_QU))
+          HIP_TRY(hipMemcpyAsync(out->g_m_u, gmu.p, sizeof(double) * M * Q, hipMemcpyDeviceToHost, st));
+      }
+      if (want_hz) launch_kzz_rows(dKmm.d(), dZ.d(), Q * P, P, dvar.d(), dell.d(), Q, M, rowout.d(), st);
+      HIP_TRY(hipEventRecord(ev_join, st));
+    } else
     {
       Scope sc(this, CAT_MM, 0);
       launch_mirror_lower(Hq(0), Q, M, per_q, st);                   // the row pass / the exchange fill the lower triangle
@@ -1113,6 +1267,11 @@ struct hmogp_engine {
     HIP_TRY(hipEventRecord(ev_fin1, st));
     if (exchanged && comm) wait_exchanged();          // a collective is in flight: watchdog instead of a blind wait
     HIP_TRY(hipStreamSynchronize(st));
+    if (small_path && small_failed()) {               // a latent needs GPy's jitter ladder: the regular path owns it
+      spans.clear(), pool_used = 0;
+      began = false;
+      throw RetryRegular{};
+    }
     collect_spans();
     float f0 = 0.f, f1 = 0.f;
     (void)hipEventElapsedTime(&f0, ev_begin0, ev_begin1);
@@ -1587,8 +1746,20 @@ int hmogp_step_finish(hmogp_handle h, hmogp_outputs* out) {
 int hmogp_elbo_grad(hmogp_handle h, const hmogp_params* p, hmogp_outputs* out) {
   if (!h) return HMOGP_E_INVALID;
   return guarded(h, [&] {       // single device, NEVER a collective -- also with a communicator attached (debug / parity calls)
-    h->begin(p, false);
-    h->finish(out);
+    try {
+      h->begin(p, false);
+      h->finish(out);
+    } catch (const hmogp_engine::RetryRegular&) {   // small-model path: a latent needs the jitter ladder
+      h->small_veto = true;
+      try {
+        h->begin(p, false);
+        h->finish(out);
+      } catch (...) {
+        h->small_veto = false;
+        throw;
+      }
+      h->small_veto = false;
+    }
   });
 }
 
@@ -1597,7 +1768,7 @@ int hmogp_elbo_grad_sharded(hmogp_handle h, const hmogp_params* p, hmogp_outputs
   return guarded(h, [&] {
     if (!h->comm) throw EngineError{HMOGP_E_STATE, "hmogp_elbo_grad_sharded without a communicator (hmogp_comm_init)"};
     try {
-      h->begin(p, false);
+      h->begin(p, false, true);
       h->exchange();            // the one collective of the path, enqueued between the two halves on the engine's stream
     } catch (...) {
       h->comm_abort();          // this rank cannot contribute: the peers must fail, not hang

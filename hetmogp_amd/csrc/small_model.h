@@ -1,0 +1,35 @@
+// small_model.h -- the fused small-model kernels (small_model.hip): M <= HMOGP_SMALL_M, one block per latent GP.
+#pragma once
+#include "common.h"
+
+#define HMOGP_SMALL_M 64
+
+struct SmallU {   // inputs / outputs of u_small_kernel (all device pointers; per-latent stride M*M unless noted)
+  int M = 0, Q = 0, P = 1, ldz = 0;
+  const double* Z = nullptr;       // [M][Q*P]
+  const double* var = nullptr;     // [Q]
+  const double* ell = nullptr;     // [Q]
+  const double* jit = nullptr;     // [Q] jitter added to the factorised copy of K_uu (0, or a forced rung's value)
+  const double* mu = nullptr;      // [M][Q]
+  const double* Lflat = nullptr;   // [M(M+1)/2][Q]
+  double *Kuu = nullptr, *Luu = nullptr, *Kuui = nullptr, *L = nullptr, *S = nullptr, *KiS = nullptr, *KSK = nullptr, *C = nullptr,
+         *Ctri = nullptr, *Sqi = nullptr;
+  double* a = nullptr;             // [Q][M]
+  double* klout = nullptr;         // [Q][KL_BLOCKS][5]
+  int* info = nullptr;             // [Q] LAPACK info of the factorisation (zeroed by the caller)
+};
+
+struct SmallF {   // finish_small_kernel
+  int M = 0, Q = 0, want_qu = 1, want_hz = 1;
+  long long per_q = 0, oR = 0;     // bundle: H_q at H + q * per_q (lower triangle), r_q at + oR
+  const double* H = nullptr;
+  double* Hfull = nullptr;         // the same buffer: receives the mirrored upper triangle
+  const double *Kuui = nullptr, *KiS = nullptr, *KSK = nullptr, *Sqi = nullptr, *L = nullptr, *a = nullptr;
+  double *G = nullptr, *GSK = nullptr, *dLdS = nullptr, *dKmm = nullptr, *Kr = nullptr;
+  double* gL = nullptr;            // [M(M+1)/2][Q]
+  double* gmu = nullptr;           // [M][Q]
+};
+
+size_t small_lds_bytes();
+void launch_u_small(const SmallU& u, hipStream_t s);
+void launch_finish_small(const SmallF& f, hipStream_t s);

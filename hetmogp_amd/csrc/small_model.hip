@@ -1,0 +1,348 @@
+// small_model.hip -- the replicated M x M algebra of the svmogp_inf path for SMALL models (M <= 64), one block per latent GP
+// with every matrix in LDS: TWO launches instead of ~30.
+//
+// BASELINE.json's config 1 (the reference's own runnable size: N_t = 1000, M = 50, Q = 2; notebooks/demo.ipynb uses M = 8) is
+// bound by launch count, not by arithmetic: profiles/r04_C1_kernel_stats.csv shows 45 kernels per evaluation, twelve of them
+// 50 x 50 x 50 products at ~16 us each.  Everything of util.py:181-200 (K_uu, jitchol, K_uu^-1) and svmogp_inf.py:192-195,
+// 227-250 (S, K_uu^-1 S K_uu^-1 - K_uu^-1, S^-1, the KL terms) fits one CU's 160 KB of LDS at this size:
+//
+//   u_small_kernel       K_uu (GPy rounding order) -> + jitter -> Cholesky -> L_uu^-1 -> K_uu^-1 ; a = K_uu^-1 m ;
+//                        L = tril(flat) ; S = L L^T ; K^-1 S ; K^-1 S K^-1 ; C ; tril-fold(C) ; S^-1 ; KL partials
+//   finish_small_kernel  H mirrored ; G = K^-1 H K^-1 ; K^-1 r ; dL/dS ; dL/dL (packed) ; dL/dm ; G S K^-1 ; dL/dKmm
+//
+// Both write the SAME global buffers as the regular path (engine.hip: Kuu, Luu, Kuui, L, S, KiS, KSK, C, Ctri, Sqi, a, klout /
+// G, GSK, dLdS, gL, gmu, Kr, dKmm), so posterior_u / predict_f / natgrad / the debug export work unchanged behind them.
+// A failed factorisation (GPy's jitter ladder is needed) only sets info[q]: the engine then repeats the evaluation on the
+// regular path, which owns the ladder.  Arithmetic: plain FP64 FMAs on 4 x 4 register micro-tiles (a 64^3 product is
+// ~4 us on one CU; MFMA tiles would not be faster at one block per latent) -- results agree with the blocked kernels to rounding.
+#include "common.h"
+#include "post.h"
+#include "rbf_device.h"
+#include "small_model.h"
+
+namespace {
+
+constexpr int SM = HMOGP_SMALL_M, SLD = SM + 2, NT = 256;   // even leading dimension: 16-byte aligned row pairs
+
+// C = op(A) op(B) (all M x M, LDS, C aliases neither operand): thread (t >> 4, t & 15) owns a 4 x 4 micro-tile.
+// Rows / columns beyond M hold garbage that is never stored.  KLO / KHI trim the k-range for triangular operands:
+//   tri == 0: k in [0, M);  tri == 1: k <= min(i, j) style handled by the caller through `kmax_of_tile`.
+template <bool TA, bool TB>
+__device__ __forceinline__ void sm_gemm(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int M,
+                                        int kbeg_mode = 0) {
+  const int t = threadIdx.x, r0 = 4 * (t >> 4), c0 = 4 * (t & 15);
+  if (r0 >= M || c0 >= M) return;
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+  // kbeg_mode 1: op(A)[i][k] == 0 for k < i and op(B)[k][j] == 0 for k < j (upper x lower: L^-T L^-1): start at max(r0, c0)
+  // kbeg_mode 2: op(A)[i][k] == 0 for k > i and op(B)[k][j] == 0 for k > j (lower x upper: L L^T): stop at min(r0, c0) + 3
+  const int k0 = kbeg_mode == 1 ? max(r0, c0) : 0;
+  const int k1 = kbeg_mode == 2 ? min(M, min(r0, c0) + 4) : M;
+  for (int k = k0; k < k1; ++k) {
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = TA ? A[k * SLD + r0 + i] : A[(r0 + i) * SLD + k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = TB ? B[(c0 + j) * SLD + k] : B[k * SLD + c0 + j];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (r0 + i < M && c0 + j < M) C[(r0 + i) * SLD + c0 + j] = acc[i][j];
+}
+
+__device__ __forceinline__ void sm_load(double* __restrict__ X, const double* __restrict__ g, int M, long long ldg) {
+  for (int e = threadIdx.x; e < M * M; e += NT) {
+    const int i = e / M, j = e - i * M;
+    X[i * SLD + j] = g[(long long)i * ldg + j];
+  }
+}
+__device__ __forceinline__ void sm_store(const double* __restrict__ X, double* __restrict__ g, int M) {
+  for (int e = threadIdx.x; e < M * M; e += NT) {
+    const int i = e / M, j = e - i * M;
+    g[(long long)i * M + j] = X[i * SLD + j];
+  }
+}
+
+// Lower Cholesky of X (in place, lower triangle; the strict upper triangle is left as it was), by ONE wave, left-looking, one
+// row per lane.  A wave's LDS operations are processed in order, so the lanes exchange columns through LDS without block
+// barriers.  The diagonal stays un-normalised in X until the end (no column product reads it); `diag` receives the pivots.
+// Returns LAPACK's info (0, or 1 + the first column whose pivot is <= 0 or NaN); uniform across the wave.
+__device__ __forceinline__ int sm_potrf_wave(double* X, double* diag, int M, int lane) {
+  int info = 0;
+  for (int j = 0; j < M; ++j) {
+    if (lane >= j && lane < M) {   // four interleaved partial sums: the loop is bound by the LDS round trip, not by the FMAs
+      const double* xi = X + lane * SLD;
+      const double* xj = X + j * SLD;
+      double s0 = xi[j], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int k = 0;
+      for (; k + 4 <= j; k += 4) {
+        s0 = fma(-xi[k], xj[k], s0);
+        s1 = fma(-xi[k + 1], xj[k + 1], s1);
+        s2 = fma(-xi[k + 2], xj[k + 2], s2);
+        s3 = fma(-xi[k + 3], xj[k + 3], s3);
+      }
+      for (; k < j; ++k) s0 = fma(-xi[k], xj[k], s0);
+      X[lane * SLD + j] = (s0 + s1) + (s2 + s3);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double d = X[j * SLD + j];
+    if (!(d > 0.0)) {
+      info = j + 1;
+      break;
+    }
+    const double sq = sqrt(d);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == j) diag[j] = sq;
+    else if (lane > j && lane < M) X[lane * SLD + j] = X[lane * SLD + j] / sq;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  if (!info && lane < M) X[lane * SLD + lane] = diag[lane];
+  return info;
+}
+
+// Xi = L^-1 (L lower triangular in LDS), zeros above the diagonal: lane c owns column c (forward substitution of L x = e_c;
+// it only ever reads its own column of Xi back).  One wave; the other waves of the block may do independent work meanwhile.
+__device__ __forceinline__ void sm_trtri_wave(const double* __restrict__ L, double* __restrict__ Xi, int M, int lane) {
+  // row by row: x[r][c] = (delta_rc - sum_{k<r} L[r][k] x[k][c]) / L[r][r]; rows above the diagonal are zeros, so every lane runs
+  // the same k-range (uniform loop, L[r][k] is an LDS broadcast, x[k][c] a conflict-free row access)
+  for (int r = 0; r < M; ++r) {
+    const double* lr = L + r * SLD;
+    double s0 = (lane == r) ? 1.0 : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+    for (; k + 4 <= r; k += 4) {
+      s0 = fma(-lr[k], Xi[k * SLD + lane], s0);
+      s1 = fma(-lr[k + 1], Xi[(k + 1) * SLD + lane], s1);
+      s2 = fma(-lr[k + 2], Xi[(k + 2) * SLD + lane], s2);
+      s3 = fma(-lr[k + 3], Xi[(k + 3) * SLD + lane], s3);
+    }
+    for (; k < r; ++k) s0 = fma(-lr[k], Xi[k * SLD + lane], s0);
+    const double v = (lane <= r) ? ((s0 + s1) + (s2 + s3)) / lr[r] : 0.0;
+    if (lane < SM) Xi[r * SLD + lane] = v;
+  }
+}
+
+template <int P>
+__global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* X0 = lds;
+  double* X1 = X0 + SM * SLD;
+  double* X2 = X1 + SM * SLD;
+  double* X3 = X2 + SM * SLD;
+  double* vec = X3 + SM * SLD;          // [4][SM]: diag pivots | m | a | scratch
+  __shared__ double red[16];
+  __shared__ int s_info;
+  const int q = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int M = u.M, Q = u.Q;
+  const long long MM = (long long)M * M, off = (long long)q * MM;
+  const double var = u.var[q], ell = u.ell[q], jit = u.jit[q];
+
+  // ---- K_uu = k_q(Z_q, Z_q), both arguments passed (util.py:197): GPy's rounding order, no forced diagonal --------------------
+  for (int e = t; e < M * M; e += NT) {
+    const int i = e / M, j = e - i * M;
+    double zi[P], zj[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) zi[p] = u.Z[(long long)i * u.ldz + q * P + p], zj[p] = u.Z[(long long)j * u.ldz + q * P + p];
+    const double r2 = rbf_r2<P>(zi, sumsq<P>(zi), zj, sumsq<P>(zj), ell);
+    const double k = var * exp(-0.5 * r2);
+    u.Kuu[off + e] = k;
+    X0[i * SLD + j] = k + ((i == j) ? jit : 0.0);     // the factorised copy carries the jitter (GPy jitchol)
+  }
+  // meanwhile L = flat_to_triang(L_flat) (svmogp_inf.py:193) into X2, m into vec[1]
+  for (int e = t; e < M * M; e += NT) {
+    const int r = e / M, c = e - r * M;
+    const double v = (c <= r) ? u.Lflat[((long long)r * (r + 1) / 2 + c) * Q + q] : 0.0;
+    X2[r * SLD + c] = v;
+    u.L[off + e] = v;
+  }
+  if (t < M) vec[SM + t] = u.mu[(long long)t * Q + q];
+  if (t == 0) s_info = 0;
+  __syncthreads();
+  // ---- wave 0: L_uu = chol(K_uu + jitter I), then L_uu^-1 (X1) ; wave 1 meanwhile: L^-1 (X3) -- the two sequential chains ----
+  if (w == 0) {
+    const int info = sm_potrf_wave(X0, vec, M, lane);
+    if (lane == 0) s_info = info;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!info) sm_trtri_wave(X0, X1, M, lane);
+  } else if (w == 1) {
+    sm_trtri_wave(X2, X3, M, lane);                      // S^-1 = dpotri(L) needs L^-1 (svmogp_inf.py:124)
+  }
+  __syncthreads();
+  if (s_info) {                                          // (the engine falls back to the regular path and its ladder)
+    if (t == 0) u.info[q] = s_info;
+    return;
+  }
+  for (int e = t; e < M * M; e += NT) {                  // L_uu with an explicit zero upper triangle (potrf_finalize)
+    const int i = e / M, j = e - i * M;
+    u.Luu[off + e] = (j <= i) ? X0[i * SLD + j] : 0.0;
+  }
+  double l1 = 0.0, l2 = 0.0;
+  if (t < M) l1 = log(fabs(X0[t * SLD + t])), l2 = log(fabs(X2[t * SLD + t]));
+  __syncthreads();
+  sm_gemm<true, false>(X1, X1, X0, M, 1);                // K_uu^-1 = L_uu^-T L_uu^-1            (util.py:199)            -> X0
+  __syncthreads();
+  sm_store(X0, u.Kuui + off, M);
+  sm_gemm<true, false>(X3, X3, X1, M, 1);                // S^-1 = L^-T L^-1                                               -> X1
+  double ma = 0.0, tr = 0.0, ninf = 0.0;
+  if (t < M) {                                           // a = K_uu^-1 m
+    double sacc = 0.0;
+    for (int k = 0; k < M; ++k) sacc = fma(X0[t * SLD + k], vec[SM + k], sacc);
+    u.a[(long long)q * M + t] = sacc;
+    ma = vec[SM + t] * sacc;
+  }
+  __syncthreads();
+  sm_store(X1, u.Sqi + off, M);
+  for (int e = t; e < M * M; e += NT) {
+    const int i = e / M, j = e - i * M;
+    ninf += isinf(X1[i * SLD + j]) ? 1.0 : 0.0;
+  }
+  sm_gemm<false, true>(X2, X2, X3, M, 2);                // S = L L^T                           (svmogp_inf.py:194-195)   -> X3
+  __syncthreads();
+  sm_store(X3, u.S + off, M);
+  for (int e = t; e < M * M; e += NT) {
+    const int i = e / M, j = e - i * M;
+    tr += X0[i * SLD + j] * X3[i * SLD + j];
+  }
+  sm_gemm<false, false>(X0, X3, X1, M);                  // K^-1 S                                                         -> X1
+  __syncthreads();
+  sm_store(X1, u.KiS + off, M);
+  sm_gemm<false, false>(X1, X0, X2, M);                  // K^-1 S K^-1                                                    -> X2
+  __syncthreads();
+  sm_store(X2, u.KSK + off, M);
+  for (int e = t; e < M * M; e += NT) {                  // C = K^-1 S K^-1 - K^-1 ; T = tril(C) + tril(C^T, -1)
+    const int i = e / M, j = e - i * M;
+    const double cij = X2[i * SLD + j] - X0[i * SLD + j];
+    u.C[off + e] = cij;
+    double tv = 0.0;
+    if (j == i) tv = cij;
+    else if (j < i) tv = cij + (X2[j * SLD + i] - X0[j * SLD + i]);
+    u.Ctri[off + e] = tv;
+  }
+  // ---- KL partials (svmogp_inf.py:245-249): the layout of kl_terms_kernel, everything in block 0 of the latent -------------------
+  tr = block_sum(tr, red);
+  ma = block_sum(ma, red);
+  l1 = block_sum(l1, red);
+  l2 = block_sum(l2, red);
+  ninf = block_sum(ninf, red);
+  double* o = u.klout + (long long)q * KL_BLOCKS * 5;
+  for (int e = t; e < KL_BLOCKS * 5; e += NT) o[e] = 0.0;
+  __syncthreads();
+  if (t == 0) o[0] = tr, o[1] = ma, o[2] = l1, o[3] = l2, o[4] = ninf;
+}
+
+__global__ __launch_bounds__(NT) void finish_small_kernel(SmallF f) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* X0 = lds;
+  double* X1 = X0 + SM * SLD;
+  double* X2 = X1 + SM * SLD;
+  double* X3 = X2 + SM * SLD;
+  double* vec = X3 + SM * SLD;          // [4][SM]: r | K^-1 r | a
+  const int q = blockIdx.x, t = threadIdx.x;
+  const int M = f.M, Q = f.Q;
+  const long long MM = (long long)M * M, off = (long long)q * MM;
+  const double* Hq = f.H + (long long)q * f.per_q;
+  // H_q arrives as its lower triangle (row pass / exchange step): mirrored here
+  for (int e = t; e < M * M; e += NT) {
+    const int i = e / M, j = e - i * M;
+    X0[i * SLD + j] = (j <= i) ? Hq[(long long)i * M + j] : Hq[(long long)j * M + i];
+  }
+  sm_load(X1, f.Kuui + off, M, M);
+  if (t < M) vec[t] = Hq[f.oR + t], vec[2 * SM + t] = f.a[(long long)q * M + t];
+  __syncthreads();
+  if (f.want_hz || f.want_qu) {
+    for (int e = t; e < M * M; e += NT) {               // (the bundle itself keeps the full symmetric H_q, like launch_mirror_lower)
+      const int i = e / M, j = e - i * M;
+      if (j > i) f.Hfull[(long long)q * f.per_q + (long long)i * M + j] = X0[i * SLD + j];
+    }
+  }
+  sm_gemm<false, false>(X0, X1, X2, M);                  // H K^-1                                                X2
+  if (t < M) {                                           // K^-1 r  (dVE_dmu, svmogp_inf.py:144)
+    double s = 0.0;
+    for (int k = 0; k < M; ++k) s = fma(X1[t * SLD + k], vec[k], s);
+    vec[SM + t] = s;
+    f.Kr[(long long)q * M + t] = s;
+    if (f.want_qu) f.gmu[(long long)t * Q + q] = s - vec[2 * SM + t];   // dL/dm = K^-1 r - a   (:130,144,168)
+  }
+  __syncthreads();
+  sm_gemm<false, false>(X1, X2, X3, M);                  // G = K^-1 (H K^-1)  (dVE_dS, svmogp_inf.py:148)          X3
+  __syncthreads();
+  // The regular path forms the lower tiles of G = K^-1 H K^-1 and mirrors them: exactly symmetric.  Same here.
+  for (int e = t; e < M * M; e += NT) {
+    const int i = e / M, j = e - i * M;
+    if (j > i) X3[i * SLD + j] = X3[j * SLD + i];
+  }
+  __syncthreads();
+  sm_store(X3, f.G + off, M);
+  if (f.want_qu) {
+    sm_load(X0, f.Sqi + off, M, M);                      // (H is no longer needed)
+    __syncthreads();
+    for (int e = t; e < M * M; e += NT) {                // dL/dS = G - (K^-1 - S^-1) / 2   (svmogp_inf.py:131,169)
+      const int i = e / M, j = e - i * M;
+      const double v = X3[i * SLD + j] - 0.5 * (X1[i * SLD + j] - X0[i * SLD + j]);
+      X2[i * SLD + j] = v;
+      f.dLdS[off + e] = v;
+    }
+    __syncthreads();
+    sm_load(X0, f.L + off, M, M);
+    __syncthreads();
+    sm_gemm<false, false>(X2, X0, X1, M);                // dL/dS L (:175-177)  [X1: K^-1 is re-read from HBM below]
+    __syncthreads();
+    for (int e = t; e < M * M; e += NT) {                // GPy triang_to_flat of 2 dL/dS L
+      const int r = e / M, c = e - r * M;
+      if (c <= r) f.gL[((long long)r * (r + 1) / 2 + c) * Q + q] = 2.0 * X1[r * SLD + c];
+    }
+    __syncthreads();
+  }
+  if (f.want_hz) {
+    sm_load(X0, f.KiS + off, M, M);
+    __syncthreads();
+    sm_gemm<false, true>(X3, X0, X2, M);                 // G S K^-1 = G (K^-1 S)^T   (tmp_dv, svmogp_inf.py:151)    X2
+    __syncthreads();
+    sm_store(X2, f.GSK + off, M);
+    // dL_dKmm (svmogp_inf.py:130-133,151-154,166,170): dkmm_kernel's formula
+    for (int e = t; e < M * M; e += NT) {
+      const int i = e / M, j = e - i * M;
+      const double kri = vec[SM + i], krj = vec[SM + j], ai = vec[2 * SM + i], aj = vec[2 * SM + j];
+      const double xij = X3[i * SLD + j] - X2[i * SLD + j] - X2[j * SLD + i] - kri * aj;
+      const double xji = X3[j * SLD + i] - X2[j * SLD + i] - X2[i * SLD + j] - krj * ai;
+      const double dve = 0.5 * (xij + xji);
+      const double dkl = 0.5 * f.Kuui[off + e] - 0.5 * f.KSK[off + e] - 0.5 * (ai * aj);
+      f.dKmm[off + e] = dve - dkl;
+    }
+  }
+}
+
+}  // namespace
+
+size_t small_lds_bytes() { return sizeof(double) * (4 * SM * SLD + 4 * SM); }
+
+void launch_u_small(const SmallU& u, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {   // > 64 KB of dynamic LDS needs the opt-in
+    HIP_TRY(hipFuncSetAttribute((const void*)u_small_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes()));
+    HIP_TRY(hipFuncSetAttribute((const void*)u_small_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes()));
+    HIP_TRY(hipFuncSetAttribute((const void*)u_small_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes()));
+    HIP_TRY(hipFuncSetAttribute((const void*)u_small_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes()));
+    HIP_TRY(hipFuncSetAttribute((const void*)finish_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes()));
+    attr_set = true;
+  }
+  DISPATCH_P(u.P, hipLaunchKernelGGL((u_small_kernel<PP>), dim3(u.Q), dim3(NT), small_lds_bytes(), s, u));
+}
+
+void launch_finish_small(const SmallF& f, hipStream_t s) {
+  hipLaunchKernelGGL(finish_small_kernel, dim3(f.Q), dim3(NT), small_lds_bytes(), s, f);
+}

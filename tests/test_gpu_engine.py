@@ -421,7 +421,7 @@ def test_exact_zero_windows_equal_dense():
     win = run(make_engine(prob, X, Y, exact_zero_windows=True), prm, bs)
     want = so.elbo_grad_fused(prm, prob, X, Y, bs)
     for k in KEYS:
-        assert rel(win[k], dense[k]) < 1e-11, k
+        assert rel(win[k], dense[k]) < 1e-10, k
         assert rel(win[k], want[k]) < TOL, k
     # chunked + windows
     winc = run(make_engine(prob, X, Y, exact_zero_windows=True, chunk_rows=512), prm, bs)

@@ -1,0 +1,15 @@
+import sys, time, os
+sys.path.insert(0, "/root/repo")
+import numpy as np
+from hetmogp_amd.engine import Engine
+from hetmogp_amd.synthetic import make_case
+c1 = [("HetGaussian", {}), ("Bernoulli", {}), ("Categorical", {"K": 3})]
+prm, X, Y = make_case(c1, [1000] * 3, M=50, Q=2, P=1, seed=20260930)
+e = Engine(c1, 2, 50, 1, reuse_outputs=True)
+e.set_data(X, Y)
+for _ in range(20): e.elbo_grad(**prm)
+t0 = time.perf_counter()
+for _ in range(200): out = e.elbo_grad(**prm)
+dt = (time.perf_counter() - t0) / 200
+ms, nl = e.timings()
+print("C1: %.1f us/step; device total %.1f us; launches %s" % (1e6 * dt, 1e3 * ms["total"], sum(nl.values())), {k: round(1e3*v,1) for k, v in ms.items()})
