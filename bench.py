@@ -706,7 +706,7 @@ def svi_config(args, K):
     model2.stochastic = True
     ng = model2.device_natgrad(gamma=0.1, step_rate=0.005, momentum=0.9)
     it2 = iter(ng)
-    for _ in range(6):
+    for _ in range(35):                 # past the log-linear step-size warm-up (20 E-steps = 25 iterations)
         next(it2)
     t0 = time.perf_counter()
     for _ in range(n_it):
@@ -727,7 +727,9 @@ def svi_config(args, K):
             "svi_natgrad_ms_per_iteration": ng_ms, "svi_natgrad_elbo_last": ng_elbo, "svi_natgrad_gamma": ng.gamma_used,
             "svi_natgrad_rejected_steps": ng.rejected,
             "svi_natgrad_note": "same loop, E-steps = natural-gradient step of the device-resident q(u) (hmogp_qu_natgrad: "
-                                "two M^3/3 factorisations + one triangular inverse per step, no host copy of q(u))"}
+                                "two M^3/3 factorisations + one triangular inverse per step, no host copy of q(u)); rows "
+                                "shuffled once, q(u) started at the prior, step size log-linear 1e-5 -> gamma over 20 E-steps "
+                                "(DeviceNatGrad); elbo_last after 35 + timed iterations vs the Adadelta loop's after 6 + timed"}
 
 
 if __name__ == "__main__":

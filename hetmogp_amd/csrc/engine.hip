@@ -327,7 +327,7 @@ struct hmogp_engine {
   hipEvent_t ev_begin0 = nullptr, ev_begin1 = nullptr, ev_fin0 = nullptr, ev_fin1 = nullptr;
   bool st2_masked = false;    // the second stream leaves a few CUs of every XCD to the latency-bound chains (HMOGP_ST2_FREE)
   // [r4] SMALL-PROBLEM MODE (M <= 128 and <= 65536 rows in the evaluation; BASELINE config 1 is M = 50, 3000 rows): such a step is
-  // bound by the HOST (45 launches, 15 copies, 37 event records: ~0.6 ms of API time, profiles/r04_c1_hip_api_stats.csv) and by
+  // bound by the HOST (45 launches, 15 copies, 37 event records: ~0.6 ms of API time, profiles/r04_C1_hip_api_stats_before.csv) and by
   // cross-queue dependencies (every hipStreamWaitEvent between two hardware queues costs ~10 us of device idle time), not by
   // any kernel.  In this mode the three streams are ONE (st2 = st3 = st: event waits on the same queue are free) and the per-
   // family timing spans are not recorded (hmogp_last_timings then reports the total only).

@@ -83,6 +83,38 @@ __global__ void dkmm_kernel(const double* __restrict__ G, const double* __restri
   out[ij] = dve - dkl;
 }
 
+// The same through 32 x 32 tiles staged in LDS: the transposed entries G[j][i], GSK[j][i] come from the mirrored tile, read row-wise
+// (the element-wise kernel above reads them column-wise -- uncoalesced 8-byte loads: 245 us at M = 1024, Q = 3, on the
+// critical path of the gradient tail).  Same operations in the same order per element: bit-identical results.
+__global__ __launch_bounds__(256) void dkmm_tiled_kernel(const double* __restrict__ G, const double* __restrict__ GSK,
+                                                         const double* __restrict__ Kuui, const double* __restrict__ KSK,
+                                                         const double* __restrict__ Kr, const double* __restrict__ a,
+                                                         double* __restrict__ out, int M) {
+  __shared__ double tG[32][33], tS[32][33];
+  const int q = blockIdx.z, bi = blockIdx.y * 32, bj = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long long b = (long long)q * M * M;
+  for (int r = ty; r < 32; r += 8) {          // mirrored tile (rows bj.., columns bi..): [r][c] = X[bj + r][bi + c]
+    const int row = bj + r, col = bi + tx;
+    const bool ok = row < M && col < M;
+    tG[r][tx] = ok ? G[b + (long long)row * M + col] : 0.0;
+    tS[r][tx] = ok ? GSK[b + (long long)row * M + col] : 0.0;
+  }
+  __syncthreads();
+  const double* kr = Kr + (long long)q * M;
+  const double* av = a + (long long)q * M;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bi + r, j = bj + tx;
+    if (i >= M || j >= M) continue;
+    const long long ij = b + (long long)i * M + j;
+    const double gij = G[ij], sij = GSK[ij], gji = tG[tx][r], sji = tS[tx][r];
+    const double xij = gij - sij - sji - kr[i] * av[j];
+    const double xji = gji - sji - sij - kr[j] * av[i];
+    const double dve = 0.5 * (xij + xji);
+    const double dkl = 0.5 * Kuui[ij] - 0.5 * KSK[ij] - 0.5 * (av[i] * av[j]);
+    out[ij] = dve - dkl;
+  }
+}
+
 // dL_dS = G - (Kuui - Sqi)/2        (svmogp_inf.py:131,169)
 __global__ void dlds_kernel(const double* __restrict__ G, const double* __restrict__ Kuui, const double* __restrict__ Sqi,
                             double* __restrict__ out, long long n) {
@@ -225,7 +257,10 @@ void launch_kl_terms(const double* Kuui, const double* S, const double* m_u, con
 }
 void launch_dkmm(const double* G, const double* GSK, const double* Kuui, const double* KSK, const double* Kr, const double* a,
                  double* out, int Q, int M, hipStream_t s) {
-  hipLaunchKernelGGL(dkmm_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, G, GSK, Kuui, KSK, Kr, a, out, M);
+  if (M >= 64)
+    hipLaunchKernelGGL(dkmm_tiled_kernel, dim3((M + 31) / 32, (M + 31) / 32, Q), dim3(256), 0, s, G, GSK, Kuui, KSK, Kr, a, out, M);
+  else
+    hipLaunchKernelGGL(dkmm_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, G, GSK, Kuui, KSK, Kr, a, out, M);
 }
 void launch_dlds(const double* G, const double* Kuui, const double* Sqi, double* out, long long n, hipStream_t s) {
   if (n <= 0) return;

@@ -2,7 +2,7 @@
 // with every matrix in LDS: TWO launches instead of ~30.
 //
 // BASELINE.json's config 1 (the reference's own runnable size: N_t = 1000, M = 50, Q = 2; notebooks/demo.ipynb uses M = 8) is
-// bound by launch count, not by arithmetic: profiles/r04_C1_kernel_stats.csv shows 45 kernels per evaluation, twelve of them
+// bound by launch count, not by arithmetic: profiles/r04_C1_kernel_stats_before.csv shows 45 kernels per evaluation, twelve of them
 // 50 x 50 x 50 products at ~16 us each.  Everything of util.py:181-200 (K_uu, jitchol, K_uu^-1) and svmogp_inf.py:192-195,
 // 227-250 (S, K_uu^-1 S K_uu^-1 - K_uu^-1, S^-1, the KL terms) fits one CU's 160 KB of LDS at this size:
 //

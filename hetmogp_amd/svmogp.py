@@ -134,11 +134,17 @@ class DeviceNatGrad(DeviceAdadelta):
     logic).  A step that would leave the positive-definite cone is retried with gamma halved (q(u) untouched by a failed
     step); `gamma_used` records the last accepted value."""
 
-    def __init__(self, model, gamma=0.1, step_rate=1.0, decay=0.9, momentum=0.0, offset=1e-4):
+    def __init__(self, model, gamma=0.1, step_rate=1.0, decay=0.9, momentum=0.0, offset=1e-4, gamma_start=1e-5, warmup=20):
         DeviceAdadelta.__init__(self, model, step_rate=step_rate, decay=decay, momentum=momentum, offset=offset)
         self.gamma = float(gamma)
         self.gamma_used = float(gamma)
         self.rejected = 0
+        # Step-size schedule: log-linear from gamma_start to gamma over the first `warmup` E-steps.  With N >> M the data term
+        # dominates the prior in the new precision, and then m_new = S_new theta_new is nearly the FULL Newton step of the mean
+        # whatever gamma is (it cancels) -- from a poor start that overshoots for exp-link likelihoods (Poisson: measured ELBO
+        # -1.2e7 -> -4.5e10 in one step of gamma = 0.1 at N_all = 1e6).  Only a gamma small enough for gamma * (data precision) to
+        # be comparable with K_uu^-1 damps it; the schedule is the usual remedy for non-conjugate natural-gradient VI.
+        self.gamma_start, self.warmup, self.e_steps = float(min(gamma_start, gamma)), int(warmup), 0
 
     def __iter__(self):
         m, eng = self.model, self.model._engine
@@ -174,7 +180,9 @@ class DeviceNatGrad(DeviceAdadelta):
                 self.sms *= d
                 self.sms += t2
                 if e_step:                                          # the evaluation carried the q(u) group
-                    gam = self.gamma
+                    frac = min(1.0, self.e_steps / float(self.warmup)) if self.warmup > 0 else 1.0
+                    gam = float(np.exp(np.log(self.gamma_start) + frac * (np.log(self.gamma) - np.log(self.gamma_start))))
+                    self.e_steps += 1
                     for _ in range(8):
                         try:
                             eng.qu_natgrad(gam)
@@ -411,6 +419,45 @@ class SVMOGP(object):
         self.Xmulti, self.Ymulti = X, Y
 
 
+    def init_q_u_to_prior(self, jitter=1e-6):
+        """q(u_q) := p(u_q) = N(0, K_uu,q) (L_q = chol(K_uu,q + jitter * variance * I), m_q = 0).  Not in the reference, whose
+        constructor starts from S_q = I (svmogp.py:66-69): with many close inducing points K_uu^-1 S K_uu^-1 is then
+        enormous, q(f) has variances of 1e3 and more, and the expectations of exp-link likelihoods (Poisson, Gamma) are
+        astronomically large -- a natural-gradient (Newton-like) step computed from them diverges.  Adadelta's small
+        Euclidean steps survive that start; the natural-gradient loop starts from the prior instead."""
+        r, c = np.tril_indices(self.num_inducing)
+        for q, k in enumerate(self.kern_list):
+            Zq = self.Z.values[:, q * self.Xdim:(q + 1) * self.Xdim]
+            K = k.K(Zq, Zq)
+            K = 0.5 * (K + K.T) + jitter * float(k.variance[0]) * np.eye(self.num_inducing)
+            self.q_u_chols[:, q] = np.linalg.cholesky(K)[r, c]
+        self.q_u_means[...] = 0.0
+        self._dirty = True
+        return self
+
+    def shuffle_rows(self, seed=0):
+        """Permute the rows of every task ONCE (data resident in HBM are re-uploaded in the new order), so that the contiguous
+        minibatch slices of `new_batch` (the reference's protocol, util.py:52-72: slices are visited in order and never shuffled)
+        become uniform random subsets.  Not in the reference.  Needed by natural-gradient SVI: a contiguous slice of sorted
+        inputs informs a small part of the input space only, its batch_scale pretends the whole data set looks like it, and a
+        natural-gradient step towards that local, over-confident posterior diverges where Adadelta's tiny Euclidean steps do
+        not (measured at N_all = 1e6, batch 8192: ELBO -3e7 -> -1e17 within two steps at gamma = 0.1)."""
+        rng = np.random.RandomState(seed)
+        for t in range(len(self.Ymulti_all)):
+            perm = rng.permutation(self.Xmulti_all[t].shape[0])
+            self.Xmulti_all[t] = np.ascontiguousarray(self.Xmulti_all[t][perm])
+            self.Ymulti_all[t] = np.ascontiguousarray(self.Ymulti_all[t][perm])
+        self._engine.set_data(self.Xmulti_all, self.Ymulti_all)
+        self._engine_has_full = True
+        self._last_batch = None
+        if self.stochastic:
+            self.set_data(*self.new_batch())
+        else:
+            self.Xmulti, self.Ymulti = self.Xmulti_all, self.Ymulti_all
+            self._rows = [(0, x.shape[0]) for x in self.Xmulti_all]
+        self._dirty = True
+        return self
+
     def new_batch(self):
         """svmogp.py:175-186: the next contiguous slice of every task."""
         Xb, Yb, rows = [], [], []
@@ -445,9 +492,20 @@ class SVMOGP(object):
             return None
         return DeviceAdadelta(self, step_rate=step_rate, decay=decay, momentum=momentum, offset=offset)
 
-    def device_natgrad(self, gamma=0.1, step_rate=1.0, decay=0.9, momentum=0.0, offset=1e-4):
+    def device_natgrad(self, gamma=0.1, step_rate=1.0, decay=0.9, momentum=0.0, offset=1e-4, shuffle=True, seed=0,
+                       init="prior"):
         """The SVI loop with natural-gradient E-steps on the device-resident q(u) (DeviceNatGrad); None when it does not
-        apply (same conditions as `device_adadelta`)."""
+        apply (same conditions as `device_adadelta`).  `shuffle` (default on): `shuffle_rows(seed)` first -- natural-gradient
+        steps need minibatches that represent the whole data set.  `init="prior"` (default) starts q(u) at p(u)
+        (`init_q_u_to_prior`); None keeps the model's current q(u)."""
+        if not self.stochastic or self._dist is not None or self.q_u_means.is_fixed or self.q_u_chols.is_fixed:
+            return None
+        if shuffle:
+            self.shuffle_rows(seed)
+        if init == "prior":      # see init_q_u_to_prior: the reference's S = I start is no place to take Newton-like steps from
+            self.init_q_u_to_prior()
+        elif init is not None:
+            raise ValueError("init must be 'prior' or None")
         if not self.stochastic or self._dist is not None or self.q_u_means.is_fixed or self.q_u_chols.is_fixed:
             return None
         return DeviceNatGrad(self, gamma=gamma, step_rate=step_rate, decay=decay, momentum=momentum, offset=offset)

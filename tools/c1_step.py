@@ -13,3 +13,10 @@ for _ in range(200): out = e.elbo_grad(**prm)
 dt = (time.perf_counter() - t0) / 200
 ms, nl = e.timings()
 print("C1: %.1f us/step; device total %.1f us; launches %s" % (1e6 * dt, 1e3 * ms["total"], sum(nl.values())), {k: round(1e3*v,1) for k, v in ms.items()})
+if len(sys.argv) > 1 and sys.argv[1] == "profile":
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(300): e.elbo_grad(**prm)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(12)
