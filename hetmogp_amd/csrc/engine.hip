@@ -359,7 +359,7 @@ struct hmogp_engine {
     bool on_;
     Scope(hmogp_engine* eng, int cat, int nlaunch, hipStream_t on = nullptr) : e(eng), stream(on ? on : eng->st) {
       static const bool off = getenv("HMOGP_NO_SPANS") != nullptr;   // experiment: what the timing events themselves cost
-      on_ = !off && !eng->small_mode;
+      on_ = !off && (!eng->small_mode || cat == CAT_EXCHANGE);   // (the exchange step is always timed)
       s.cat = cat;
       e->launches[cat] += nlaunch;
       if (!on_) return;
