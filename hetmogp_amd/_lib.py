@@ -21,6 +21,7 @@ FLAG_V_NEGATIVE = 1
 GROUP_QU, GROUP_HYPER, GROUP_Z, GROUP_ALL = 1, 2, 4, 7
 CFG_EXACT_ZERO_WINDOWS = 1
 CFG_CACHE_KUU = 2
+CFG_NO_SMALL_PATH = 4
 QUIRK_GAMMA_BETA_PI, QUIRK_CATEGORICAL_DM, QUIRK_STALE_W, QUIRK_W_DIAG, QUIRK_KAPPA_DIAG = 1, 2, 4, 8, 16
 QUIRKS_REFERENCE, QUIRKS_EXACT = 31, 0
 

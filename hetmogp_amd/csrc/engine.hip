@@ -278,7 +278,7 @@ RcclApi& rccl() {
 struct hmogp_engine {
   int T = 0, Q = 0, M = 0, P = 0, Df = 0, device = 0;
   long long chunk = 1048576;  // rows per pool (hmogp_config.chunk_rows); workspaces are sized by the rows actually streamed
-  bool use_windows = false, cache_kuu = false, kuu_key_valid = false;
+  bool use_windows = false, cache_kuu = false, kuu_key_valid = false, no_small = false;
   unsigned quirks = HMOGP_QUIRKS_REFERENCE;
   std::vector<double> h_Z, kuu_key;
   std::vector<int> rung_request, kuu_rung;
@@ -497,6 +497,7 @@ struct hmogp_engine {
     }
     use_windows = (c->flags & HMOGP_CFG_EXACT_ZERO_WINDOWS) != 0;
     cache_kuu = (c->flags & HMOGP_CFG_CACHE_KUU) != 0;
+    no_small = (c->flags & HMOGP_CFG_NO_SMALL_PATH) != 0;
     quirks = c->quirks;
     if (quirks & ~HMOGP_QUIRKS_REFERENCE) throw EngineError{HMOGP_E_INVALID, "unknown bits in hmogp_config.quirks"};
     if (use_windows && M > 8192) throw EngineError{HMOGP_E_INVALID, "exact-zero windows support M <= 8192"};
@@ -1117,7 +1118,7 @@ struct hmogp_engine {
         const long long b = p->row_begin ? p->row_begin[t] : 0, e = p->row_end ? p->row_end[t] : tasks[t].N;
         rows_eval += std::max<long long>(0, e - b);
       }
-      const bool want_small = small_env >= 0 ? small_env != 0 : (M <= 128 && rows_eval <= 65536 && !use_windows && !st2_masked);
+      const bool want_small = !no_small && (small_env >= 0 ? small_env != 0 : (M <= 128 && rows_eval <= 65536 && !use_windows && !st2_masked));
       if (want_small != small_mode) {     // (rare: drain the queues the previous evaluations used before re-wiring them)
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipStreamSynchronize(st2_own));

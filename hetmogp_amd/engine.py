@@ -73,7 +73,7 @@ def pinned_empty(shape, dtype=np.float64):
 class Engine(object):
     """specs: list of (likelihood class name, kwargs) per task, e.g. [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {})]."""
 
-    def __init__(self, specs, Q, M, P, device=0, chunk_rows=0, exact_zero_windows=False, cache_kuu=False,
+    def __init__(self, specs, Q, M, P, device=0, chunk_rows=0, exact_zero_windows=False, cache_kuu=False, small_path=True,
                  reuse_outputs=False, quirks="reference"):
         self.specs = [(n, dict(k)) for n, k in specs]
         self.T, self.Q, self.M, self.P = len(specs), int(Q), int(M), int(P)
@@ -92,7 +92,8 @@ class Engine(object):
                           lik_id.ctypes.data_as(_lib.c_int32_p), _p(lik_par),
                           self.f_index.ctypes.data_as(_lib.c_int32_p), self.d_index.ctypes.data_as(_lib.c_int32_p),
                           int(device), int(chunk_rows),
-                          (_lib.CFG_EXACT_ZERO_WINDOWS if exact_zero_windows else 0) | (_lib.CFG_CACHE_KUU if cache_kuu else 0),
+                          (_lib.CFG_EXACT_ZERO_WINDOWS if exact_zero_windows else 0) | (_lib.CFG_CACHE_KUU if cache_kuu else 0) |
+                          (0 if small_path else _lib.CFG_NO_SMALL_PATH),
                           _lib.quirk_mask(quirks))
         self.quirks = _lib.quirk_mask(quirks)
         self._h = C.c_void_p()

@@ -109,6 +109,9 @@ typedef struct {
  * exact-zero windows: M <= 8192.  T, M, Df and the row counts are bounded by device memory only.                 */
 
 /* hmogp_config.flags */
+#define HMOGP_CFG_NO_SMALL_PATH 4u /* ABI v5: keep the regular kernels and three streams also for small models (M <= 64 would
+                                    * otherwise take the fused small-model kernels, M <= 128 with <= 65536 rows one stream): A/B
+                                    * comparisons of the two paths inside one process (tests)                                */
 #define HMOGP_CFG_CACHE_KUU 2u /* opt-in: reuse K_uu, its Cholesky factor and inverse while (Z, variance, lengthscale,
    forced rungs) are bit-identical to the previous evaluation's (VEM / SVI E-steps only move q(u)).  Off by default and
    never used by bench.py, whose steps re-evaluate identical parameters.                                          */
