@@ -295,9 +295,9 @@ struct hmogp_engine {
   std::vector<long long> rb, re;
   std::vector<int> rung;
   unsigned group_mask = HMOGP_GROUP_ALL;
-  DevBuf dZ, dmu, dLflat, dvar, dell, dW, dkap, dsmall;
+  DevBuf dZ, dmu, dLflat, dvar, dell, dW, dkap, dsmall, dparams;
   double* h_small = nullptr;
-  long long n_small = 0;
+  long long n_small = 0, oZ = 0, oMu = 0, oLf = 0, n_params = 0;
   // M x M (each Q*M*M)
   DevBuf Kuu, Luu, Kuui, L, S, KiS, KSK, C, Ctri, Sqi, tmpA, tmpB, HK, G, GSK, dKmm, dLdS;
   DevBuf a, Kr, gmu, gL, klout, rowout, dinfo, djit, dscr;
@@ -591,14 +591,18 @@ struct hmogp_engine {
     // parameter + M x M buffers
     const size_t mmq = sizeof(double) * MM * Q;
     for (DevBuf* b : {&Kuu, &Luu, &Kuui, &L, &S, &KiS, &KSK, &C, &Ctri, &Sqi, &tmpA, &tmpB, &HK, &G, &GSK, &dKmm, &dLdS}) b->ensure(mmq, true);
-    dZ.ensure(sizeof(double) * M * Q * P);
-    dmu.ensure(sizeof(double) * M * Q);
-    dLflat.ensure(sizeof(double) * ((long long)M * (M + 1) / 2) * Q);
-    // the four small hyper-parameter arrays live in ONE device block and go up in ONE copy from a page-locked image
-    // (a host-bound small-model step pays ~4-8 us of API time per hipMemcpyAsync)
+    // ALL parameters live in ONE device block [ hypers + jitter | Z | m_u | L_flat ] (segments 16-byte aligned): large models fill
+    // the segments by separate copies straight from the caller's arrays, small-problem mode by ONE copy from a page-locked image
+    // (a host-bound small-model step pays ~4-8 us of API time and ~4 us of device time per hipMemcpyAsync)
     n_small = 2 * Q + 2 * Q * Df + Q;   // variance | lengthscale | W | kappa | jitter of the small path
-    dsmall.ensure(sizeof(double) * n_small);
-    HIP_TRY(hipHostMalloc((void**)&h_small, sizeof(double) * n_small, hipHostMallocDefault));
+    auto even = [](long long n) { return (n + 1) & ~1LL; };
+    const long long nZ = (long long)M * Q * P, nmu = (long long)M * Q, nL = ((long long)M * (M + 1) / 2) * Q;
+    oZ = even(n_small), oMu = oZ + even(nZ), oLf = oMu + even(nmu), n_params = oLf + even(nL);
+    dparams.ensure(sizeof(double) * n_params);
+    dsmall.view(dparams.d(), sizeof(double) * n_small);
+    dZ.view(dparams.d() + oZ, sizeof(double) * nZ), dmu.view(dparams.d() + oMu, sizeof(double) * nmu);
+    dLflat.view(dparams.d() + oLf, sizeof(double) * nL);
+    HIP_TRY(hipHostMalloc((void**)&h_small, sizeof(double) * (M <= 128 ? n_params : n_small), hipHostMallocDefault));
     dvar.view(dsmall.d(), sizeof(double) * Q), dell.view(dsmall.d() + Q, sizeof(double) * Q);
     dW.view(dsmall.d() + 2 * Q, sizeof(double) * Q * Df), dkap.view(dsmall.d() + 2 * Q + Q * Df, sizeof(double) * Q * Df);
     a.ensure(sizeof(double) * Q * M), Kr.ensure(sizeof(double) * Q * M), gmu.ensure(sizeof(double) * Q * M);
@@ -679,11 +683,6 @@ struct hmogp_engine {
       if (!(h_ell[q] > 0.0)) throw EngineError{HMOGP_E_INVALID, "lengthscale must be positive"};
     }
     group_mask = p->group_mask;
-    HIP_TRY(hipMemcpyAsync(dZ.p, p->Z, sizeof(double) * M * Q * P, hipMemcpyHostToDevice, st));
-    if (!resident) HIP_TRY(hipMemcpyAsync(dmu.p, p->m_u, sizeof(double) * M * Q, hipMemcpyHostToDevice, st));
-    // the one large parameter (12.6 MB at M = 1024, Q = 3) goes up on the second stream, whose chain is its only consumer
-    // (u_algebra): the K_uu chain on the main stream starts without waiting for it
-    if (!resident) HIP_TRY(hipMemcpyAsync(dLflat.p, p->L_flat, sizeof(double) * Mtri * Q, hipMemcpyHostToDevice, st3));
     // (h_small is re-written only after the previous evaluation has synchronised the stream that read it)
     std::copy(h_var.begin(), h_var.end(), h_small);
     std::copy(h_ell.begin(), h_ell.end(), h_small + Q);
@@ -691,7 +690,23 @@ struct hmogp_engine {
     std::copy(h_kap.begin(), h_kap.end(), h_small + 2 * Q + Q * Df);
     for (int q = 0; q < Q; ++q)      // small path: jitter of a forced rung (GPy jitchol: mean(diag) 1e-6 10^k, diag(K_uu) = variance)
       h_small[2 * Q + 2 * Q * Df + q] = rung[q] >= 0 ? h_var[q] * 1e-6 * std::pow(10.0, rung[q]) : 0.0;
-    HIP_TRY(hipMemcpyAsync(dsmall.p, h_small, sizeof(double) * n_small, hipMemcpyHostToDevice, st));
+    if (small_mode && M <= 128) {     // one image, one copy: [ hypers | Z | (m_u | L_flat unless q(u) is resident) ]
+      std::memcpy(h_small + oZ, p->Z, sizeof(double) * M * Q * P);
+      long long n_up = oMu;
+      if (!resident) {
+        std::memcpy(h_small + oMu, p->m_u, sizeof(double) * M * Q);
+        std::memcpy(h_small + oLf, p->L_flat, sizeof(double) * Mtri * Q);
+        n_up = n_params;
+      }
+      HIP_TRY(hipMemcpyAsync(dparams.p, h_small, sizeof(double) * n_up, hipMemcpyHostToDevice, st));
+    } else {
+      HIP_TRY(hipMemcpyAsync(dZ.p, p->Z, sizeof(double) * M * Q * P, hipMemcpyHostToDevice, st));
+      if (!resident) HIP_TRY(hipMemcpyAsync(dmu.p, p->m_u, sizeof(double) * M * Q, hipMemcpyHostToDevice, st));
+      // the one large parameter (12.6 MB at M = 1024, Q = 3) goes up on the second stream, whose chain is its only consumer
+      // (u_algebra): the K_uu chain on the main stream starts without waiting for it
+      if (!resident) HIP_TRY(hipMemcpyAsync(dLflat.p, p->L_flat, sizeof(double) * Mtri * Q, hipMemcpyHostToDevice, st3));
+      HIP_TRY(hipMemcpyAsync(dsmall.p, h_small, sizeof(double) * n_small, hipMemcpyHostToDevice, st));
+    }
     if (resident) HIP_TRY(hipStreamWaitEvent(st3, ev_qu, 0));   // an in-place natural-gradient update of the resident q(u)
     HIP_TRY(hipEventRecord(ev_params, st));   // what the second stream has to wait for before it reads Z / the hypers
   }
@@ -1182,6 +1197,19 @@ struct hmogp_engine {
     const bool want_hz = (group_mask & (HMOGP_GROUP_HYPER | HMOGP_GROUP_Z)) != 0;
     HIP_TRY(hipEventRecord(ev_fin0, st));
     HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));   // the S^-1 chain of hmogp_step_begin (third stream) used HK / G as scratch
+    // the small results (head of the bundle, KL partials, per-latent tails, K_uu-side rows) are gathered device-side and
+    // leave in ONE copy into a page-locked buffer; on the small-model path the q(u) gradients ride in the same block
+    const size_t n_hg = NG, n_kl = (size_t)Q * KL_BLOCKS * 5, n_tail = (size_t)Q * (per_q - oDZ),
+                 n_row = want_hz ? (size_t)Q * M * (2 + P) : 0, n_all = n_hg + n_kl + n_tail + n_row;
+    const bool qu_out = small_path && want_qu && (group_mask & HMOGP_GROUP_QU) != 0;
+    const size_t n_gmu = qu_out ? (size_t)M * Q : 0, n_gl = qu_out ? (size_t)Mtri * Q : 0, n_stage = n_all + n_gmu + n_gl;
+    dstage.ensure(sizeof(double) * n_stage);
+    if (hstage_cap < n_stage) {
+      if (hstage) (void)hipHostFree(hstage);
+      hstage = nullptr, hstage_cap = 0;
+      HIP_TRY(hipHostMalloc((void**)&hstage, sizeof(double) * n_stage, hipHostMallocDefault));
+      hstage_cap = n_stage;
+    }
     if (small_path) {
       // M <= 64: the whole post-processing of the bundle in ONE kernel (one block per latent, matrices in LDS), then the K_uu-side
       // row sums; q(u) gradients leave on the same (only) stream
@@ -1190,13 +1218,8 @@ struct hmogp_engine {
       f.M = M, f.Q = Q, f.want_qu = want_qu ? 1 : 0, f.want_hz = want_hz ? 1 : 0, f.per_q = per_q, f.oR = oR;
       f.H = Hq(0), f.Hfull = Hq(0), f.Kuui = Kuui.d(), f.KiS = KiS.d(), f.KSK = KSK.d(), f.Sqi = Sqi.d(), f.L = L.d(), f.a = a.d();
       f.G = G.d(), f.GSK = GSK.d(), f.dLdS = dLdS.d(), f.dKmm = dKmm.d(), f.Kr = Kr.d(), f.gL = gL.d(), f.gmu = gmu.d();
+      if (qu_out) f.gmu2 = dstage.d() + n_all, f.gL2 = dstage.d() + n_all + n_gmu;
       launch_finish_small(f, st);
-      if (want_qu) {
-        if (out->g_L_u && (group_mask & HMOGP_GROUP_QU))
-          HIP_TRY(hipMemcpyAsync(out->g_L_u, gL.p, sizeof(double) * Mtri * Q, hipMemcpyDeviceToHost, st));
-        if (out->g_m_u && (group_mask & HMOGP_GROUP_QU))
-          HIP_TRY(hipMemcpyAsync(out->g_m_u, gmu.p, sizeof(double) * M * Q, hipMemcpyDeviceToHost, st));
-      }
       if (want_hz) launch_kzz_rows(dKmm.d(), dZ.d(), Q * P, P, dvar.d(), dell.d(), Q, M, rowout.d(), st);
       HIP_TRY(hipEventRecord(ev_join, st));
     } else
@@ -1245,20 +1268,11 @@ struct hmogp_engine {
     // ---- device -> host ------------------------------------------------------------------------------
     // the small results (head of the bundle, KL partials, per-latent tails, K_uu-side rows) are gathered device-side and
     // leave in ONE copy into a page-locked buffer: ten separate pageable copies cost 0.3 ms of gaps
-    const size_t n_hg = NG, n_kl = (size_t)Q * KL_BLOCKS * 5, n_tail = (size_t)Q * (per_q - oDZ),
-                 n_row = want_hz ? (size_t)Q * M * (2 + P) : 0, n_all = n_hg + n_kl + n_tail + n_row;
-    dstage.ensure(sizeof(double) * n_all);
-    if (hstage_cap < n_all) {
-      if (hstage) (void)hipHostFree(hstage);
-      hstage = nullptr, hstage_cap = 0;
-      HIP_TRY(hipHostMalloc((void**)&hstage, sizeof(double) * n_all, hipHostMallocDefault));
-      hstage_cap = n_all;
-    }
     {
       double* d = dstage.d();
       launch_gather_small(stats.d(), (long long)n_hg, klout.d(), (long long)n_kl, per_q, oDZ, per_q - oDZ, Q, rowout.d(),
                           (long long)n_row, d, st);
-      HIP_TRY(hipMemcpyAsync(hstage, d, sizeof(double) * n_all, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(hstage, d, sizeof(double) * n_stage, hipMemcpyDeviceToHost, st));
     }
     const double *hg = hstage, *hkl = hstage + n_hg, *htail = hstage + n_hg + n_kl, *hrow = hstage + n_hg + n_kl + n_tail;
     const bool qu = (group_mask & HMOGP_GROUP_QU) != 0;
@@ -1274,6 +1288,10 @@ struct hmogp_engine {
       throw RetryRegular{};
     }
     collect_spans();
+    if (qu_out) {      // small-model path: the q(u) gradients arrived in the staging block
+      if (out->g_m_u) std::memcpy(out->g_m_u, hstage + n_all, sizeof(double) * n_gmu);
+      if (out->g_L_u) std::memcpy(out->g_L_u, hstage + n_all + n_gmu, sizeof(double) * n_gl);
+    }
     float f0 = 0.f, f1 = 0.f;
     (void)hipEventElapsedTime(&f0, ev_begin0, ev_begin1);
     (void)hipEventElapsedTime(&f1, ev_fin0, ev_fin1);

@@ -28,6 +28,7 @@ struct SmallF {   // finish_small_kernel
   double *G = nullptr, *GSK = nullptr, *dLdS = nullptr, *dKmm = nullptr, *Kr = nullptr;
   double* gL = nullptr;            // [M(M+1)/2][Q]
   double* gmu = nullptr;           // [M][Q]
+  double *gL2 = nullptr, *gmu2 = nullptr;   // optional second copies (the engine's D2H staging block: one copy for all results)
 };
 
 size_t small_lds_bytes();

@@ -275,7 +275,10 @@ __global__ __launch_bounds__(NT) void finish_small_kernel(SmallF f) {
     for (int k = 0; k < M; ++k) s = fma(X1[t * SLD + k], vec[k], s);
     vec[SM + t] = s;
     f.Kr[(long long)q * M + t] = s;
-    if (f.want_qu) f.gmu[(long long)t * Q + q] = s - vec[2 * SM + t];   // dL/dm = K^-1 r - a   (:130,144,168)
+    if (f.want_qu) {                                                     // dL/dm = K^-1 r - a   (:130,144,168)
+      f.gmu[(long long)t * Q + q] = s - vec[2 * SM + t];
+      if (f.gmu2) f.gmu2[(long long)t * Q + q] = s - vec[2 * SM + t];
+    }
   }
   __syncthreads();
   sm_gemm<false, false>(X1, X2, X3, M);                  // G = K^-1 (H K^-1)  (dVE_dS, svmogp_inf.py:148)          X3
@@ -303,7 +306,11 @@ __global__ __launch_bounds__(NT) void finish_small_kernel(SmallF f) {
     __syncthreads();
     for (int e = t; e < M * M; e += NT) {                // GPy triang_to_flat of 2 dL/dS L
       const int r = e / M, c = e - r * M;
-      if (c <= r) f.gL[((long long)r * (r + 1) / 2 + c) * Q + q] = 2.0 * X1[r * SLD + c];
+      if (c <= r) {
+        const long long o = ((long long)r * (r + 1) / 2 + c) * Q + q;
+        f.gL[o] = 2.0 * X1[r * SLD + c];
+        if (f.gL2) f.gL2[o] = 2.0 * X1[r * SLD + c];
+      }
     }
     __syncthreads();
   }
