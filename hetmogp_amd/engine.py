@@ -207,6 +207,7 @@ class Engine(object):
         return self._wrap(o)
 
     def step_begin(self, **params):
+        self._skip_qu = params.get("m_u") is None      # device-resident q(u): step_finish leaves its gradient in HBM too
         p, keep = self._params(**params)
         check(lib.hmogp_step_begin(self._h, C.byref(p)), self._h)
 
@@ -271,7 +272,7 @@ class Engine(object):
         check(lib.hmogp_step_exchange(self._h), self._h)
 
     def step_finish(self, want_dL_dS=False):
-        c, o = self._outputs(want_dL_dS)
+        c, o = self._outputs(want_dL_dS, skip_qu=getattr(self, "_skip_qu", False))
         check(lib.hmogp_step_finish(self._h, C.byref(c)), self._h)
         return self._wrap(o)
 

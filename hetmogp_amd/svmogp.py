@@ -486,9 +486,11 @@ class SVMOGP(object):
 
     def device_adadelta(self, step_rate=1.0, decay=0.9, momentum=0.0, offset=1e-4):
         """An Adadelta optimiser over `stochastic_grad` with q(u) and its accumulators resident in HBM (DeviceAdadelta),
-        or None when that does not apply (batch mode, q(u) fixed, row-sharded evaluation) -- callers then fall back to
-        `util.Adadelta(model.optimizer_array, model.stochastic_grad, ...)`, which produces the same iterates."""
-        if not self.stochastic or self._dist is not None or self.q_u_means.is_fixed or self.q_u_chols.is_fixed:
+        or None when that does not apply (batch mode, q(u) fixed) -- callers then fall back to
+        `util.Adadelta(model.optimizer_array, model.stochastic_grad, ...)`, which produces the same iterates.
+        [r4] Also in a row-sharded (distributed=True) model: every rank holds the same resident q(u), the all-reduced bundle gives
+        every rank the same gradients, and the device recurrence is deterministic -- the replicas stay bit-identical."""
+        if not self.stochastic or self.q_u_means.is_fixed or self.q_u_chols.is_fixed:
             return None
         return DeviceAdadelta(self, step_rate=step_rate, decay=decay, momentum=momentum, offset=offset)
 
@@ -498,16 +500,14 @@ class SVMOGP(object):
         apply (same conditions as `device_adadelta`).  `shuffle` (default on): `shuffle_rows(seed)` first -- natural-gradient
         steps need minibatches that represent the whole data set.  `init="prior"` (default) starts q(u) at p(u)
         (`init_q_u_to_prior`); None keeps the model's current q(u)."""
-        if not self.stochastic or self._dist is not None or self.q_u_means.is_fixed or self.q_u_chols.is_fixed:
+        if not self.stochastic or self.q_u_means.is_fixed or self.q_u_chols.is_fixed:
             return None
-        if shuffle:
+        if shuffle:                 # (distributed: every rank holds all rows and the same seed gives the same permutation)
             self.shuffle_rows(seed)
         if init == "prior":      # see init_q_u_to_prior: the reference's S = I start is no place to take Newton-like steps from
             self.init_q_u_to_prior()
         elif init is not None:
             raise ValueError("init must be 'prior' or None")
-        if not self.stochastic or self._dist is not None or self.q_u_means.is_fixed or self.q_u_chols.is_fixed:
-            return None
         return DeviceNatGrad(self, gamma=gamma, step_rate=step_rate, decay=decay, momentum=momentum, offset=offset)
 
     def callback(self, i, max_iter, verbose=True, verbose_plot=False):

@@ -186,7 +186,7 @@ def vem_algorithm(model, stochastic=False, vem_iters=None, step_rate=None, verbo
         make = getattr(model, "device_natgrad", None)
         optimizer = make(gamma=natgrad_gamma, step_rate=rate, momentum=0.9) if make is not None else None
         if optimizer is None:
-            raise ValueError("qu_optimizer='natgrad' needs a stochastic, single-process model with a free q(u)")
+            raise ValueError("qu_optimizer='natgrad' needs a stochastic model with a free q(u)")
     elif device_optimizer and getattr(model, "device_adadelta", None) is not None:
         optimizer = model.device_adadelta(step_rate=rate, momentum=0.9)      # None when it does not apply
     if optimizer is None:

@@ -382,3 +382,61 @@ def test_plain_c_two_ranks_file_rendezvous_no_torch(tmp_path):
         for a, b in zip(got[1:9], single[1:9]):                 # elbo, g_var x2, g_ell x2, three weighted gradient sums
             assert abs(a - b) <= 1e-9 * max(1.0, abs(b)), (r, a, b)
     assert vals[("0", "sharded")][1:9] == vals[("1", "sharded")][1:9]          # replicated finish: identical bits on every rank
+
+
+def _svi_worker(rank, world, port, q, optimizer):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import torch.distributed as dist
+    import hetmogp_amd as H
+    from test_facade_gpu import build_model
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import hetmogp_amd.svmogp as sv
+        orig = sv.SVMOGP.__init__
+
+        def patched(self, *a, **kw):
+            kw["distributed"] = True
+            return orig(self, *a, **kw)
+        sv.SVMOGP.__init__ = patched
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_h_mix_M128.npz"))
+    model = build_model(g, batch_size=96)
+    np.random.seed(0)
+    H.vem_algorithm(model, stochastic=True, vem_iters=14, step_rate=0.01, qu_optimizer=optimizer, natgrad_gamma=0.05)
+    res = (rank, model.elbo[:14, 0].copy(), np.asarray(model.q_u_means.values).copy(), np.asarray(model.q_u_chols.values).copy())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    q.put(res)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("optimizer", ["adadelta", "natgrad"])
+def test_device_resident_svi_loop_in_a_row_sharded_model(optimizer):
+    """[r4] The SVI loops with q(u) resident in HBM (DeviceAdadelta / DeviceNatGrad) inside SVMOGP(distributed=True): two ranks
+    (gloo, both on the one GPU) shard every minibatch's rows, all-reduce the bundle and apply the SAME device-side update to
+    their replicas of q(u).  The ELBO trace and the final q(u) equal the single-process loop's (to the summation order of the
+    sharded statistics) and are bit-identical on the two ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q1 = ctx.Queue()
+    p1 = ctx.Process(target=_svi_worker, args=(0, 1, _free_port(), q1, optimizer))
+    p1.start()
+    _, e1, m1, L1 = q1.get(timeout=400)
+    p1.join(60)
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_svi_worker, args=(r, 2, port, q, optimizer)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, ea, ma, La), (_, eb, mb, Lb) = res
+    assert np.array_equal(ea, eb) and np.array_equal(ma, mb) and np.array_equal(La, Lb)       # replicas never diverge
+    assert np.all(np.isfinite(ea))
+    assert np.max(np.abs(ea - e1)) < 1e-7 * np.max(np.abs(e1))
+    assert np.max(np.abs(ma - m1)) < 1e-6 * np.max(np.abs(m1)) and np.max(np.abs(La - L1)) < 1e-6 * np.max(np.abs(L1))
