@@ -86,6 +86,7 @@ EXPORTS = {
     "hmogp_posterior_u": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "hmogp_natgrad_step": (C.c_int, [C.c_void_p, C.c_double, c_double_p, c_double_p]),
     "hmogp_qu_natgrad": (C.c_int, [C.c_void_p, C.c_double]),
+    "hmogp_graph_stats": (C.c_int, [C.c_void_p, c_int64_p, c_int64_p]),
     "hmogp_predict_f": (C.c_int, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p]),
     "hmogp_last_timings": (C.c_int, [C.c_void_p, c_double_p, c_int64_p]),
     "hmogp_rbf_cross_cov": (C.c_int, [C.c_int32, c_double_p, C.c_int64, c_double_p, C.c_int32, C.c_int32, C.c_double,

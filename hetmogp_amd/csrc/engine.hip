@@ -297,7 +297,7 @@ struct hmogp_engine {
   unsigned group_mask = HMOGP_GROUP_ALL;
   DevBuf dZ, dmu, dLflat, dvar, dell, dW, dkap, dsmall, dparams;
   double* h_small = nullptr;
-  long long n_small = 0, oZ = 0, oMu = 0, oLf = 0, n_params = 0;
+  long long n_small = 0, oZ = 0, oMu = 0, oLf = 0, n_params = 0, oJit = 0, oW0 = 0, oBs = 0;
   // M x M (each Q*M*M)
   DevBuf Kuu, Luu, Kuui, L, S, KiS, KSK, C, Ctri, Sqi, tmpA, tmpB, HK, G, GSK, dKmm, dLdS;
   DevBuf a, Kr, gmu, gL, klout, rowout, dinfo, djit, dscr;
@@ -338,6 +338,124 @@ struct hmogp_engine {
   // path (small_veto), which owns the ladder.
   bool small_path = false, small_veto = false, small_info_pending = false;
   struct RetryRegular {};
+  // [r4] hipGraph of one small-model evaluation.  The small path is a FIXED sequence on one stream (one upload from the page-locked
+  // parameter image, ~20 kernels, one download into the page-locked staging block) whose kernel arguments do not depend on the
+  // parameter VALUES (quad_kernel reads the mixing weights from the parameter block): the second evaluation with the same key
+  // (gradient gates, row ranges, forced rungs, resident q(u) or not) is captured, every later one is a replay -- one
+  // hipGraphLaunch instead of ~35 API calls.  Graphs are dropped when the data or the workspaces change.
+  struct SmallGraph {
+    std::vector<long long> key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+  };
+  std::vector<SmallGraph> graphs;
+  std::vector<std::vector<long long>> warm_keys;
+  long long graph_replays = 0, graph_captures = 0;
+  void drop_graphs(bool keep_warm = false) {
+    for (auto& g : graphs) {
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
+      if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    graphs.clear();
+    if (!keep_warm) warm_keys.clear();
+  }
+  std::vector<long long> graph_key(const hmogp_params* p) const {
+    std::vector<long long> k{(long long)p->group_mask, (!p->m_u && !p->L_flat) ? 1 : 0};
+    for (int t = 0; t < T; ++t) k.push_back(p->row_begin ? p->row_begin[t] : 0), k.push_back(p->row_end ? p->row_end[t] : tasks[t].N);
+    for (int q = 0; q < Q; ++q) k.push_back(p->forced_rung ? p->forced_rung[q] : -2);
+    return k;
+  }
+  // hmogp_elbo_grad on the small path: normal evaluation the first time a key is seen, capture + launch the second time, replay
+  // afterwards.  Returns false when the call does not qualify (the caller then runs the normal begin / finish).
+  bool graph_step(const hmogp_params* p, hmogp_outputs* out) {
+    static const bool enabled = [] {   // HMOGP_SMALL_GRAPH=0: no graphs (A/B runs)
+      const char* e = getenv("HMOGP_SMALL_GRAPH");
+      return !(e && e[0] == '0');
+    }();
+    if (!enabled || !p || !out || out->dL_dS || small_veto || comm) return false;
+    HIP_TRY(hipSetDevice(device));
+    decide_mode(p);
+    if (!small_path) return false;
+    const std::vector<long long> key = graph_key(p);
+    SmallGraph* hit = nullptr;
+    for (auto& g : graphs)
+      if (g.key == key) hit = &g;
+    if (!hit) {
+      if (std::find(warm_keys.begin(), warm_keys.end(), key) == warm_keys.end()) {
+        pending_warm = key;          // first sight: a normal evaluation sizes every workspace; warm once it has SUCCEEDED
+        return false;
+      }
+      if (graphs.size() >= 32) drop_graphs();
+      // ---- capture: the normal code path, recorded instead of executed ------------------------------------------------------
+      SmallGraph g;
+      g.key = key;
+      HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      bool ok = true;
+      std::string why;
+      try {
+        begin(p, false);
+        if (!out) throw EngineError{HMOGP_E_INVALID, "null outputs"};
+        finish_enqueue(out);
+      } catch (const EngineError& e) {
+        ok = false, why = e.msg;
+      } catch (const HipError& e) {
+        ok = false, why = hipGetErrorString(e.code);
+      }
+      const hipError_t ec = hipStreamEndCapture(st, &g.graph);
+      if (!ok || ec != hipSuccess || !g.graph) {
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+        (void)hipGetLastError();
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
+          throw EngineError{HMOGP_E_NO_DEVICE, "a failed hipGraph capture left the engine's stream in capture mode: " + why};
+        (void)hipGetLastError();
+        began = false;
+        warm_keys.clear();            // (do not try again for this engine's current keys; the normal path reports real errors)
+        graphs_broken = true;
+        return false;
+      }
+      if (hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGraphDestroy(g.graph);
+        (void)hipGetLastError();
+        began = false;
+        graphs_broken = true;
+        return false;
+      }
+      graphs.push_back(g);
+      hit = &graphs.back();
+      ++graph_captures;
+    } else {
+      // ---- replay: only the HOST side of begin() (validation, parameter image, pool plan, output layout) ----------------------
+      began = false, exchanged = false;
+      spans.clear(), pool_used = 0;
+      for (int c = 0; c < NCAT; ++c) ms[c] = 0.0, launches[c] = 0;
+      upload_params(p, false);
+      plan_pools();
+      kuu_key_valid = false;
+      for (int q = 0; q < Q; ++q)
+        if (rung[q] == -2) rung[q] = -1;
+      small_info_pending = true;
+      began = true;
+      fin_layout(out);
+      ++graph_replays;
+    }
+    HIP_TRY(hipGraphLaunch(hit->exec, st));
+    via_graph = true;
+    try {
+      finish_tail(out);
+    } catch (...) {
+      via_graph = false;
+      throw;
+    }
+    via_graph = false;
+    return true;
+  }
+  bool graphs_broken = false, via_graph = false;
+  std::vector<long long> pending_warm;
+  void mark_warm() {
+    if (!pending_warm.empty() && small_path && warm_keys.size() < 64) warm_keys.push_back(pending_warm);
+    pending_warm.clear();
+  }
   hipStream_t st2 = nullptr;  // second stream, LOW priority: bandwidth-bound work beside the main stream (K_uf prefetch, colstats)
   hipStream_t st3 = nullptr;  // third stream, HIGH priority like the main one: the q(u)-only chains (S, S^-1; dL/dL, D2H)
   hipEvent_t ev_qu = nullptr;   // behind an in-place update of the resident q(u) (hmogp_qu_natgrad)
@@ -468,6 +586,7 @@ struct hmogp_engine {
   }
 
   ~hmogp_engine() {
+    drop_graphs();
     comm_destroy();
     for (auto e : pool) (void)hipEventDestroy(e);
     if (h_info2) (void)hipHostFree(h_info2);
@@ -594,7 +713,9 @@ struct hmogp_engine {
     // ALL parameters live in ONE device block [ hypers + jitter | Z | m_u | L_flat ] (segments 16-byte aligned): large models fill
     // the segments by separate copies straight from the caller's arrays, small-problem mode by ONE copy from a page-locked image
     // (a host-bound small-model step pays ~4-8 us of API time and ~4 us of device time per hipMemcpyAsync)
-    n_small = 2 * Q + 2 * Q * Df + Q;   // variance | lengthscale | W | kappa | jitter of the small path
+    // variance | lengthscale | W | kappa | jitter of the small path | chain-factor W0 (quirk Q3) | batch scales
+    oJit = 2 * Q + 2 * Q * Df, oW0 = oJit + Q, oBs = oW0 + Q * Df;
+    n_small = oBs + T;
     auto even = [](long long n) { return (n + 1) & ~1LL; };
     const long long nZ = (long long)M * Q * P, nmu = (long long)M * Q, nL = ((long long)M * (M + 1) / 2) * Q;
     oZ = even(n_small), oMu = oZ + even(nZ), oLf = oMu + even(nmu), n_params = oLf + even(nL);
@@ -619,6 +740,7 @@ struct hmogp_engine {
     k.N = N;
     began = false;
     staged_key.clear();
+    drop_graphs();
     if (N == 0) return;
     k.X.ensure(sizeof(double) * N * P);
     k.Y.ensure(sizeof(double) * N);
@@ -637,6 +759,7 @@ struct hmogp_engine {
     const size_t nm = sizeof(double) * rows * M * Q, nv = sizeof(double) * rows * Q;
     Kh.ensure(nm), Pt.ensure(nm), Xws.ensure(sizeof(double) * rows * P);
     staged_key.clear();
+    drop_graphs(true);   // (the evaluation that grows the workspaces runs normally to its end: its key stays warm)
     for (DevBuf* b : {&vp, &vc, &vpt, &vct, &valpha, &vbeta, &valpha0, &vbeta0}) b->ensure(nv, true);
     colpart.ensure(sizeof(double) * std::max((rows + 255) / 256, (std::min<long long>(rows, 16384) + 31) / 32) * M * (1 + P) * Q);
     quadpart.ensure(sizeof(double) * (rows * 64 / 256 + 1) * HMOGP_MAXSCAL);
@@ -649,7 +772,7 @@ struct hmogp_engine {
   }
 
   // ------------------------------------------------------------------------------------------ parameters
-  void upload_params(const hmogp_params* p) {
+  void upload_params(const hmogp_params* p, bool enqueue = true) {
     if (!p || !p->Z || !p->variance || !p->lengthscale || !p->W || !p->kappa)
       throw EngineError{HMOGP_E_INVALID, "missing parameter array"};
     const bool resident = !p->m_u && !p->L_flat;     // q(u) stays where hmogp_qu_load / hmogp_qu_adadelta left it
@@ -689,7 +812,17 @@ struct hmogp_engine {
     std::copy(h_W.begin(), h_W.end(), h_small + 2 * Q);
     std::copy(h_kap.begin(), h_kap.end(), h_small + 2 * Q + Q * Df);
     for (int q = 0; q < Q; ++q)      // small path: jitter of a forced rung (GPy jitchol: mean(diag) 1e-6 10^k, diag(K_uu) = variance)
-      h_small[2 * Q + 2 * Q * Df + q] = rung[q] >= 0 ? h_var[q] * 1e-6 * std::pow(10.0, rung[q]) : 0.0;
+      h_small[oJit + q] = rung[q] >= 0 ? h_var[q] * 1e-6 * std::pow(10.0, rung[q]) : 0.0;
+    std::copy(h_W0.begin(), h_W0.end(), h_small + oW0);
+    std::copy(h_bs.begin(), h_bs.end(), h_small + oBs);
+    if (!enqueue) {                   // replay of a captured graph: the page-locked image is all the graph's upload node reads
+      std::memcpy(h_small + oZ, p->Z, sizeof(double) * M * Q * P);
+      if (!resident) {
+        std::memcpy(h_small + oMu, p->m_u, sizeof(double) * M * Q);
+        std::memcpy(h_small + oLf, p->L_flat, sizeof(double) * Mtri * Q);
+      }
+      return;
+    }
     if (small_mode && M <= 128) {     // one image, one copy: [ hypers | Z | (m_u | L_flat unless q(u) is resident) ]
       std::memcpy(h_small + oZ, p->Z, sizeof(double) * M * Q * P);
       long long n_up = oMu;
@@ -707,7 +840,8 @@ struct hmogp_engine {
       if (!resident) HIP_TRY(hipMemcpyAsync(dLflat.p, p->L_flat, sizeof(double) * Mtri * Q, hipMemcpyHostToDevice, st3));
       HIP_TRY(hipMemcpyAsync(dsmall.p, h_small, sizeof(double) * n_small, hipMemcpyHostToDevice, st));
     }
-    if (resident) HIP_TRY(hipStreamWaitEvent(st3, ev_qu, 0));   // an in-place natural-gradient update of the resident q(u)
+    // (an in-place natural-gradient update of the resident q(u); one stream in small-problem mode: already ordered)
+    if (resident && !small_mode) HIP_TRY(hipStreamWaitEvent(st3, ev_qu, 0));
     HIP_TRY(hipEventRecord(ev_params, st));   // what the second stream has to wait for before it reads Z / the hypers
   }
 
@@ -746,7 +880,7 @@ struct hmogp_engine {
     }
     SmallU u;
     u.M = M, u.Q = Q, u.P = P, u.ldz = Q * P;
-    u.Z = dZ.d(), u.var = dvar.d(), u.ell = dell.d(), u.jit = dsmall.d() + 2 * Q + 2 * Q * Df, u.mu = dmu.d(), u.Lflat = dLflat.d();
+    u.Z = dZ.d(), u.var = dvar.d(), u.ell = dell.d(), u.jit = dsmall.d() + oJit, u.mu = dmu.d(), u.Lflat = dLflat.d();
     u.Kuu = Kuu.d(), u.Luu = Luu.d(), u.Kuui = Kuui.d(), u.L = L.d(), u.S = S.d(), u.KiS = KiS.d(), u.KSK = KSK.d(), u.C = C.d();
     u.Ctri = Ctri.d(), u.Sqi = Sqi.d(), u.a = a.d(), u.klout = klout.d(), u.info = dinfo.as<int>();
     launch_u_small(u, st);
@@ -999,6 +1133,10 @@ struct hmogp_engine {
           }
         }
         qa.scale = h_bs[sg.t];
+        if (small_path) {     // (replayable from a captured graph: the mixing weights are read from the parameter block)
+          qa.Wd = dW.d(), qa.W0d = dsmall.d() + oW0, qa.kapd = dkap.d(), qa.vard = dvar.d(), qa.scaled = dsmall.d() + oBs + sg.t;
+          qa.Df = Df, qa.d0 = k.d0;
+        }
         qa.quirks = quirks;
         qa.alpha = valpha.d() + sg.off, qa.beta = vbeta.d() + sg.off;
         qa.alpha0 = valpha0.d() + sg.off, qa.beta0 = vbeta0.d() + sg.off;
@@ -1117,13 +1255,7 @@ struct hmogp_engine {
     HIP_TRY(hipStreamSynchronize(st));
   }
 
-  void begin(const hmogp_params* p, bool sync = true, bool will_exchange = false) {
-    HIP_TRY(hipSetDevice(device));
-    began = false, exchanged = false;
-    spans.clear();  // a failed evaluation may have left unmatched timing spans behind
-    pool_used = 0;
-    for (int c = 0; c < NCAT; ++c) ms[c] = 0.0, launches[c] = 0;
-    {
+  void decide_mode(const hmogp_params* p) {
       static const int small_env = [] {   // HMOGP_SMALL_MODE=0|1: force the small-problem mode off / on (A/B runs)
         const char* e = getenv("HMOGP_SMALL_MODE");
         return e ? atoi(e) : -1;
@@ -1149,6 +1281,14 @@ struct hmogp_engine {
       small_path = small_mode && M <= HMOGP_SMALL_M && path_env != 0 && !small_veto;
       small_info_pending = false;
     }
+
+  void begin(const hmogp_params* p, bool sync = true, bool will_exchange = false) {
+    HIP_TRY(hipSetDevice(device));
+    began = false, exchanged = false;
+    spans.clear();  // a failed evaluation may have left unmatched timing spans behind
+    pool_used = 0;
+    for (int c = 0; c < NCAT; ++c) ms[c] = 0.0, launches[c] = 0;
+    decide_mode(p);
     upload_params(p);
     HIP_TRY(hipEventRecord(ev_begin0, st));
     plan_pools();
@@ -1188,28 +1328,43 @@ struct hmogp_engine {
   }
 
   // ------------------------------------------------------------------------------------------ finish
+  // what one evaluation returns through the single D2H staging block: the small results (head of the bundle, KL partials,
+  // per-latent tails, K_uu-side rows) gathered device-side; on the small-model path the q(u) gradients ride in the same block
+  struct FinLayout {
+    bool want_qu = false, want_hz = false, qu_out = false;
+    size_t n_hg = 0, n_kl = 0, n_tail = 0, n_row = 0, n_all = 0, n_gmu = 0, n_gl = 0, n_stage = 0;
+  } fl;
+  void fin_layout(const hmogp_outputs* out) {
+    const long long Mtri = (long long)M * (M + 1) / 2;
+    fl.want_qu = (group_mask & HMOGP_GROUP_QU) != 0 || out->dL_dS != nullptr;
+    fl.want_hz = (group_mask & (HMOGP_GROUP_HYPER | HMOGP_GROUP_Z)) != 0;
+    fl.n_hg = NG, fl.n_kl = (size_t)Q * KL_BLOCKS * 5, fl.n_tail = (size_t)Q * (per_q - oDZ);
+    fl.n_row = fl.want_hz ? (size_t)Q * M * (2 + P) : 0, fl.n_all = fl.n_hg + fl.n_kl + fl.n_tail + fl.n_row;
+    fl.qu_out = small_path && fl.want_qu && (group_mask & HMOGP_GROUP_QU) != 0;
+    fl.n_gmu = fl.qu_out ? (size_t)M * Q : 0, fl.n_gl = fl.qu_out ? (size_t)Mtri * Q : 0;
+    fl.n_stage = fl.n_all + fl.n_gmu + fl.n_gl;
+    dstage.ensure(sizeof(double) * fl.n_stage);
+    if (hstage_cap < fl.n_stage) {
+      if (hstage) (void)hipHostFree(hstage);
+      hstage = nullptr, hstage_cap = 0;
+      HIP_TRY(hipHostMalloc((void**)&hstage, sizeof(double) * fl.n_stage, hipHostMallocDefault));
+      hstage_cap = fl.n_stage;
+    }
+  }
   void finish(hmogp_outputs* out) {
+    finish_enqueue(out);
+    finish_tail(out);
+  }
+  void finish_enqueue(hmogp_outputs* out) {
     if (!began) throw EngineError{HMOGP_E_STATE, "hmogp_step_finish without hmogp_step_begin"};
     if (!out) throw EngineError{HMOGP_E_INVALID, "null outputs"};
     HIP_TRY(hipSetDevice(device));
     const long long MM = (long long)M * M, Mtri = (long long)M * (M + 1) / 2;
-    const bool want_qu = (group_mask & HMOGP_GROUP_QU) != 0 || out->dL_dS != nullptr;
-    const bool want_hz = (group_mask & (HMOGP_GROUP_HYPER | HMOGP_GROUP_Z)) != 0;
+    fin_layout(out);
+    const bool want_qu = fl.want_qu, want_hz = fl.want_hz, qu_out = fl.qu_out;
+    const size_t n_hg = fl.n_hg, n_kl = fl.n_kl, n_row = fl.n_row, n_all = fl.n_all, n_gmu = fl.n_gmu, n_stage = fl.n_stage;
     HIP_TRY(hipEventRecord(ev_fin0, st));
     HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));   // the S^-1 chain of hmogp_step_begin (third stream) used HK / G as scratch
-    // the small results (head of the bundle, KL partials, per-latent tails, K_uu-side rows) are gathered device-side and
-    // leave in ONE copy into a page-locked buffer; on the small-model path the q(u) gradients ride in the same block
-    const size_t n_hg = NG, n_kl = (size_t)Q * KL_BLOCKS * 5, n_tail = (size_t)Q * (per_q - oDZ),
-                 n_row = want_hz ? (size_t)Q * M * (2 + P) : 0, n_all = n_hg + n_kl + n_tail + n_row;
-    const bool qu_out = small_path && want_qu && (group_mask & HMOGP_GROUP_QU) != 0;
-    const size_t n_gmu = qu_out ? (size_t)M * Q : 0, n_gl = qu_out ? (size_t)Mtri * Q : 0, n_stage = n_all + n_gmu + n_gl;
-    dstage.ensure(sizeof(double) * n_stage);
-    if (hstage_cap < n_stage) {
-      if (hstage) (void)hipHostFree(hstage);
-      hstage = nullptr, hstage_cap = 0;
-      HIP_TRY(hipHostMalloc((void**)&hstage, sizeof(double) * n_stage, hipHostMallocDefault));
-      hstage_cap = n_stage;
-    }
     if (small_path) {
       // M <= 64: the whole post-processing of the bundle in ONE kernel (one block per latent, matrices in LDS), then the K_uu-side
       // row sums; q(u) gradients leave on the same (only) stream
@@ -1274,12 +1429,19 @@ struct hmogp_engine {
                           (long long)n_row, d, st);
       HIP_TRY(hipMemcpyAsync(hstage, d, sizeof(double) * n_stage, hipMemcpyDeviceToHost, st));
     }
+    if (out->dL_dS) HIP_TRY(hipMemcpyAsync(out->dL_dS, dLdS.p, sizeof(double) * MM * Q, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(ev_fin1, st));
+    (void)n_gmu, (void)n_all;
+  }
+  // everything behind the last enqueued operation of an evaluation: the one host synchronisation, then the host assembly
+  void finish_tail(hmogp_outputs* out) {
+    const long long Mtri = (long long)M * (M + 1) / 2;
+    const bool want_qu = fl.want_qu, want_hz = fl.want_hz, qu_out = fl.qu_out;
+    const size_t n_hg = fl.n_hg, n_kl = fl.n_kl, n_tail = fl.n_tail, n_all = fl.n_all, n_gmu = fl.n_gmu, n_gl = fl.n_gl;
     const double *hg = hstage, *hkl = hstage + n_hg, *htail = hstage + n_hg + n_kl, *hrow = hstage + n_hg + n_kl + n_tail;
     const bool qu = (group_mask & HMOGP_GROUP_QU) != 0;
     if (out->g_m_u && !qu) std::memset(out->g_m_u, 0, sizeof(double) * M * Q);      // (copied on the second stream otherwise)
     if (out->g_L_u && !qu) std::memset(out->g_L_u, 0, sizeof(double) * Mtri * Q);
-    if (out->dL_dS) HIP_TRY(hipMemcpyAsync(out->dL_dS, dLdS.p, sizeof(double) * MM * Q, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipEventRecord(ev_fin1, st));
     if (exchanged && comm) wait_exchanged();          // a collective is in flight: watchdog instead of a blind wait
     HIP_TRY(hipStreamSynchronize(st));
     if (small_path && small_failed()) {               // a latent needs GPy's jitter ladder: the regular path owns it
@@ -1293,8 +1455,10 @@ struct hmogp_engine {
       if (out->g_L_u) std::memcpy(out->g_L_u, hstage + n_all + n_gmu, sizeof(double) * n_gl);
     }
     float f0 = 0.f, f1 = 0.f;
-    (void)hipEventElapsedTime(&f0, ev_begin0, ev_begin1);
-    (void)hipEventElapsedTime(&f1, ev_fin0, ev_fin1);
+    if (!via_graph) {     // (events recorded by graph nodes are not read back: a replayed evaluation reports no device time)
+      (void)hipEventElapsedTime(&f0, ev_begin0, ev_begin1);
+      (void)hipEventElapsedTime(&f1, ev_fin0, ev_fin1);
+    }
     ms[CAT_TOTAL] = f0 + f1 + ms[CAT_EXCHANGE];
 
     // ---- host assembly (svmogp.py:101-166) -----------------------------------------------------------
@@ -1766,8 +1930,12 @@ int hmogp_elbo_grad(hmogp_handle h, const hmogp_params* p, hmogp_outputs* out) {
   if (!h) return HMOGP_E_INVALID;
   return guarded(h, [&] {       // single device, NEVER a collective -- also with a communicator attached (debug / parity calls)
     try {
-      h->begin(p, false);
-      h->finish(out);
+      h->pending_warm.clear();
+      if (h->graphs_broken || !h->graph_step(p, out)) {
+        h->begin(p, false);
+        h->finish(out);
+        h->mark_warm();
+      }
     } catch (const hmogp_engine::RetryRegular&) {   // small-model path: a latent needs the jitter ladder
       h->small_veto = true;
       try {
@@ -1826,6 +1994,13 @@ int hmogp_debug_raw_grads(hmogp_handle h, double* dL_dKmm, double* dL_dKmn, doub
 int hmogp_natgrad_step(hmogp_handle h, double gamma, double* m_u_new, double* L_flat_new) {
   if (!h) return HMOGP_E_INVALID;
   return guarded(h, [&] { h->natgrad_step(gamma, m_u_new, L_flat_new); });
+}
+
+int hmogp_graph_stats(hmogp_handle h, int64_t* captures, int64_t* replays) {
+  if (!h) return HMOGP_E_INVALID;
+  if (captures) *captures = h->graph_captures;
+  if (replays) *replays = h->graph_replays;
+  return HMOGP_OK;
 }
 
 int hmogp_qu_natgrad(hmogp_handle h, double gamma) {

@@ -24,6 +24,11 @@ struct QuadArgs {
   double kap[HMOGP_MAXQ][HMOGP_MAXJ];  // live kappa
   double var[HMOGP_MAXQ];              // RBF variances
   double scale = 1.0;                  // batch_scale[t]
+  // [r4] the same five inputs read from DEVICE memory instead (all non-null together; the by-value copies above are then ignored):
+  // what lets a captured hipGraph of the evaluation be replayed with new hyper-parameters.  Wd / W0d / kapd: [Q][Df] (row q,
+  // column d0 + j), vard: [Q], scaled: one value
+  const double *Wd = nullptr, *W0d = nullptr, *kapd = nullptr, *vard = nullptr, *scaled = nullptr;
+  int Df = 0, d0 = 0;
   unsigned quirks = 0x1fu;             // HMOGP_QUIRK_* (default: reproduce the reference)
   double* alpha = nullptr;             // [Q][ldn] outputs: row weights of the backward pass
   double* beta = nullptr;

@@ -223,7 +223,25 @@ __global__ __launch_bounds__(256) void quad_kernel(QuadArgs a) {
   constexpr int G = lik_lanes(LIK);
   __shared__ double etab[4][HMOGP_ETAB];
   __shared__ double red[4][HMOGP_MAXSCAL];
+  // mixing weights of this task's functions: from the kernel arguments, or (captured-graph replays) from device memory
+  __shared__ double s_w[HMOGP_MAXQ][HMOGP_MAXJ], s_w0[HMOGP_MAXQ][HMOGP_MAXJ], s_kap[HMOGP_MAXQ][HMOGP_MAXJ], s_var[HMOGP_MAXQ];
+  __shared__ double s_scale;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t < HMOGP_MAXQ * HMOGP_MAXJ) {
+    const int q = t / HMOGP_MAXJ, j = t % HMOGP_MAXJ;
+    const bool in = q < a.Q && j < a.dimf;
+    if (a.Wd) {
+      const long long o = (long long)q * a.Df + a.d0 + j;
+      s_w[q][j] = in ? a.Wd[o] : 0.0, s_w0[q][j] = in ? a.W0d[o] : 0.0, s_kap[q][j] = in ? a.kapd[o] : 0.0;
+      if (j == 0) s_var[q] = q < a.Q ? a.vard[q] : 0.0;
+      if (t == 0) s_scale = a.scaled[0];
+    } else {
+      s_w[q][j] = a.w[q][j], s_w0[q][j] = a.w0[q][j], s_kap[q][j] = a.kap[q][j];
+      if (j == 0) s_var[q] = a.var[q];
+      if (t == 0) s_scale = a.scale;
+    }
+  }
+  __syncthreads();
   const long long n = ((long long)blockIdx.x * 256 + t) / G;
   const bool valid = n < a.N;                       // uniform per wave when G == 64
   const bool lead = valid && (G == 1 || lane == 0);  // the lane that owns the row's outputs
@@ -249,9 +267,9 @@ __global__ __launch_bounds__(256) void quad_kernel(QuadArgs a) {
 #pragma unroll
       for (int q = 0; q < HMOGP_MAXQ; ++q)
         if (q < Q) {
-          const double wq = a.w[q][j];
+          const double wq = s_w[q][j];
           m += wq * pq[q];
-          v += (wq * wq + a.kap[q][j]) * a.var[q] + wq * wq * cq[q];
+          v += (wq * wq + s_kap[q][j]) * s_var[q] + wq * wq * cq[q];
         }
       neg |= (v < 0.0);
     }
@@ -277,7 +295,7 @@ __global__ __launch_bounds__(256) void quad_kernel(QuadArgs a) {
       a.out_v[n * J + j] = vv[j];
     }
   }
-  const double s = lead ? a.scale : 0.0;  // non-owning lanes contribute zeros
+  const double s = lead ? s_scale : 0.0;  // non-owning lanes contribute zeros
   o.ve *= s;
 #pragma unroll
   for (int j = 0; j < HMOGP_MAXJ; ++j) {
@@ -299,7 +317,7 @@ __global__ __launch_bounds__(256) void quad_kernel(QuadArgs a) {
 #pragma unroll
       for (int j = 0; j < HMOGP_MAXJ; ++j)
         if (j < J) {
-          const double wq = a.w[q][j], w0 = a.w0[q][j];
+          const double wq = s_w[q][j], w0 = s_w0[q][j];
           al += wq * o.gm[j];
           be += wq * wq * o.gv[j];
           al0 += w0 * o.gm[j];

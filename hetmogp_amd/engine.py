@@ -339,6 +339,12 @@ class Engine(object):
             out["dL_dKdiag"].append(b)
         return out
 
+    def graph_stats(self):
+        """(graphs captured, evaluations replayed) of the small-model hipGraph mechanism (hmogp_graph_stats)."""
+        cap, rep = np.zeros(1, dtype=np.int64), np.zeros(1, dtype=np.int64)
+        check(lib.hmogp_graph_stats(self._h, cap.ctypes.data_as(_lib.c_int64_p), rep.ctypes.data_as(_lib.c_int64_p)), self._h)
+        return int(cap[0]), int(rep[0])
+
     def timings(self):
         ms = np.zeros(_lib.NTIMINGS)
         n = np.zeros(_lib.NTIMINGS, dtype=np.int64)

@@ -170,6 +170,12 @@ int hmogp_set_task_data(hmogp_handle h, int32_t t, const double* X, const double
 /* ---- the hot path ----------------------------------------------------------------------------------- */
 /* One full evaluation = parameters_changed(): ELBO + all parameter gradients (single device).           */
 int hmogp_elbo_grad(hmogp_handle h, const hmogp_params* p, hmogp_outputs* out);
+/* Small models (M <= 64, see HMOGP_CFG_NO_SMALL_PATH): the evaluation is a fixed launch sequence on one stream; the second
+ * hmogp_elbo_grad with the same gradient gates / row ranges / forced rungs is captured into a hipGraph and every later one is a
+ * replay (one hipGraphLaunch instead of ~35 API calls; the parameter VALUES travel through a page-locked image the graph's
+ * upload node reads).  hmogp_graph_stats reports how many graphs were captured and how many evaluations were replays
+ * (diagnostics / tests; environment HMOGP_SMALL_GRAPH=0 disables the mechanism).  ABI v5.                                  */
+int hmogp_graph_stats(hmogp_handle h, int64_t* captures, int64_t* replays);
 
 /* The same, split at the one exchange point of the path for row-sharded multi-GPU runs:
  *   begin  : upload parameters, replicated M x M pre-algebra, row pass over [row_begin,row_end) of every

@@ -147,3 +147,62 @@ def test_small_mode_switches_with_the_evaluated_rows():
         for k in KEYS:
             assert rel(a[k], b[k]) < 1e-10, (rb, k, rel(a[k], b[k]))
     es.close(), er.close()
+
+
+def test_graph_replay_tracks_parameter_values_and_keys():
+    """[r4] hipGraph of the small-model evaluation: first call normal, second call captured, later calls replayed.  A replay must see
+    NEW parameter values (they travel through the page-locked image the graph's upload node reads, and quad_kernel reads the mixing
+    weights from device memory), a different gate / row range / forced rung is a different key, new data drops the graphs."""
+    from oracle import svmogp_oracle as so
+    from hetmogp_amd import _lib
+    g = np.load(os.path.join(GOLDEN, "ref_c1_exact.npz"))
+    prm, prob, X, Y, bs = so.load_case(g)
+    es, er = _pair(prob, X, Y)
+    rng = np.random.RandomState(0)
+    outs = []
+    for it in range(6):
+        p2 = dict(prm)
+        if it >= 2:                                   # every parameter group moves between replays
+            p2["m_u"] = prm["m_u"] + 0.1 * it * rng.randn(*prm["m_u"].shape)
+            p2["L_flat"] = prm["L_flat"] * (1.0 + 0.01 * it)
+            p2["W"] = prm["W"] * (1.0 + 0.05 * it)
+            p2["variance"] = prm["variance"] * (1.0 + 0.02 * it)
+            p2["lengthscale"] = prm["lengthscale"] * (1.0 + 0.03 * it)
+            p2["Z"] = prm["Z"] + 1e-3 * it
+            p2["kappa"] = prm["kappa"] + 0.01 * it
+        bs2 = [b * (1.0 + 0.5 * max(it - 1, 0)) for b in bs]
+        a, b = es.elbo_grad(**_args(p2, bs2)), er.elbo_grad(**_args(p2, bs2))
+        for k in KEYS:
+            assert rel(a[k], b[k]) < 1e-9, (it, k, rel(a[k], b[k]))
+        outs.append(a)
+    cap, rep = es.graph_stats()
+    assert cap == 1 and rep == 4, (cap, rep)          # call 0 normal, call 1 capture (+ launch), calls 2..5 replays
+    assert er.graph_stats() == (0, 0)
+    for k in KEYS:                                    # calls 0 (normal) and 1 (captured graph) had identical inputs
+        assert np.array_equal(np.asarray(outs[0][k]), np.asarray(outs[1][k])), k
+    # other keys: E-step gate, a row range, resident q(u)
+    for kw in (dict(group_mask=_lib.GROUP_QU), dict(row_begin=[10, 20, 30], row_end=[900, 800, 1000])):
+        for _ in range(3):
+            a, b = es.elbo_grad(**_args(prm, bs, **kw)), er.elbo_grad(**_args(prm, bs, **kw))
+            for k in KEYS:
+                assert rel(a[k], b[k]) < 1e-9, (kw, k)
+    assert es.graph_stats()[0] == 3
+    es.qu_load(prm["m_u"], prm["L_flat"])
+    small = {k: v for k, v in _args(prm, bs).items() if k not in ("m_u", "L_flat")}
+    ref = er.elbo_grad(**_args(prm, bs))
+    for i in range(4):
+        a = es.elbo_grad(m_u=None, L_flat=None, **small)
+        assert rel(a["elbo"], ref["elbo"]) < 1e-12 and rel(a["g_Z"], ref["g_Z"]) < 1e-9
+        if i == 2:
+            es.qu_adadelta(0, 0.01, 0.9, 0.9, 1e-4)   # an optimiser touching the resident q(u) between replays
+            es.qu_adadelta(1, 0.01, 0.9, 0.9, 1e-4)
+            m2, L2 = es.qu_read()
+            ref = er.elbo_grad(**dict(_args(prm, bs), m_u=m2, L_flat=L2))
+    assert es.graph_stats()[0] == 4
+    # new data: graphs dropped, results follow the data
+    es.set_data([x[:500] for x in X], [y[:500] for y in Y]), er.set_data([x[:500] for x in X], [y[:500] for y in Y])
+    for _ in range(3):
+        a, b = es.elbo_grad(**_args(prm, bs)), er.elbo_grad(**_args(prm, bs))
+        assert rel(a["elbo"], b["elbo"]) < 1e-11 and rel(a["g_L_u"], b["g_L_u"]) < 1e-9
+    assert es.graph_stats()[0] == 5 and es.graph_stats()[1] >= 8
+    es.close(), er.close()
