@@ -337,6 +337,8 @@ struct hmogp_engine {
   // in LDS (small_model.hip), instead of ~30 launches.  A factorisation that needs GPy's jitter ladder is repeated on the regular
   // path (small_veto), which owns the ladder.
   bool small_path = false, small_veto = false, small_info_pending = false;
+  bool small_rows = false;     // ... and its row pass as the two fused kernels of small_model.hip (small_fwd / small_bwd)
+  DevBuf smallslab;
   struct RetryRegular {};
   // [r4] hipGraph of one small-model evaluation.  The small path is a FIXED sequence on one stream (one upload from the page-locked
   // parameter image, ~20 kernels, one download into the page-locked staging block) whose kernel arguments do not depend on the
@@ -730,7 +732,7 @@ struct hmogp_engine {
     gL.ensure(sizeof(double) * ((long long)M * (M + 1) / 2) * Q);
     klout.ensure(sizeof(double) * Q * KL_BLOCKS * 5);
     rowout.ensure(sizeof(double) * Q * M * (2 + P));
-    dinfo.ensure(sizeof(int) * Q), djit.ensure(sizeof(double) * Q), dscr.ensure(sizeof(double) * Q * M * M);
+    dinfo.ensure(sizeof(int) * 2 * HMOGP_MAXQ), djit.ensure(sizeof(double) * Q), dscr.ensure(sizeof(double) * Q * M * M);
     rung.assign(Q, -1);
   }
 
@@ -870,11 +872,11 @@ struct hmogp_engine {
     // (the jitter of a forced rung went up with the hyper-parameter block: upload_params)
     for (int q = 0; q < Q; ++q)
       if (rung[q] == -2) rung[q] = -1;
-    HIP_TRY(hipMemsetAsync(dinfo.p, 0, sizeof(int) * Q, st));
+    HIP_TRY(hipMemsetAsync(dinfo.p, 0, sizeof(int) * 2 * HMOGP_MAXQ, st));     // info words + the hand-over flags of u_small_kernel
     if (!pools.empty()) {
       HIP_TRY(hipMemsetAsync(stats.p, 0, sizeof(double) * nstats, st));
       stage_pool_inputs(pools[0], st);
-      kuf_pool(pools[0], st);
+      if (!small_rows) kuf_pool(pools[0], st);      // (the fused forward kernel builds K^ itself)
       kuf_prefetched = true;
       HIP_TRY(hipEventRecord(ev_kuf, st));
     }
@@ -882,7 +884,7 @@ struct hmogp_engine {
     u.M = M, u.Q = Q, u.P = P, u.ldz = Q * P;
     u.Z = dZ.d(), u.var = dvar.d(), u.ell = dell.d(), u.jit = dsmall.d() + oJit, u.mu = dmu.d(), u.Lflat = dLflat.d();
     u.Kuu = Kuu.d(), u.Luu = Luu.d(), u.Kuui = Kuui.d(), u.L = L.d(), u.S = S.d(), u.KiS = KiS.d(), u.KSK = KSK.d(), u.C = C.d();
-    u.Ctri = Ctri.d(), u.Sqi = Sqi.d(), u.a = a.d(), u.klout = klout.d(), u.info = dinfo.as<int>();
+    u.Ctri = Ctri.d(), u.Sqi = Sqi.d(), u.a = a.d(), u.klout = klout.d(), u.info = dinfo.as<int>(), u.flag = dinfo.as<int>() + HMOGP_MAXQ;
     launch_u_small(u, st);
     HIP_TRY(hipMemcpyAsync(h_info, dinfo.p, sizeof(int) * Q, hipMemcpyDeviceToHost, st));
     small_info_pending = true;
@@ -1104,7 +1106,7 @@ struct hmogp_engine {
         if (!prefetched) stage_pool_inputs(pl, st);
         X = Xws.d();
       }
-      if (!prefetched) kuf_pool(pl, st);
+      if (!prefetched && !small_rows) kuf_pool(pl, st);
       // Forward contraction for all latents (batched), row statistics fused into its epilogue; P~ itself is only stored
       // when the Z gradient (its one remaining consumer, colstats) is requested.  One launch per pool.
       const long long sPart = 4LL * FWD_PARTS * tiles * ldn;
@@ -1168,6 +1170,18 @@ struct hmogp_engine {
                         X + off * P, P, dZ.d(), ldz, rows, M, (int)csplit, want_z, colpart.d() + slab_first * clen, st2, cw, &cb, cap);
       };
 
+      SmallRows sr;
+      if (small_rows) {
+        const long long nblk = (n + 63) / 64, slab_q = (long long)M * M + M + (long long)M * P;
+        sr.M = M, sr.Q = Q, sr.P = P, sr.ldz = ldz, sr.hyper = want_hyper ? 1 : 0, sr.want_z = want_z ? 1 : 0, sr.n = n, sr.ldn = ldn;
+        sr.X = X, sr.Z = dZ.d(), sr.var = dvar.d(), sr.ell = dell.d(), sr.C = C.d(), sr.a = a.d();
+        sr.Kh = Kh.d(), sr.Pt = Pt.d(), sr.vp = vp.d(), sr.vc = vc.d(), sr.vpt = vpt.d(), sr.vct = vct.d();
+        sr.alpha = valpha.d(), sr.beta = vbeta.d(), sr.alpha0 = valpha0.d(), sr.beta0 = vbeta0.d();
+        smallslab.ensure(sizeof(double) * nblk * Q * slab_q);
+        sr.slab = smallslab.d(), sr.stats = stats.d(), sr.NG = NG, sr.per_q = per_q, sr.oR = oR, sr.oDZ = oDZ;
+        Scope sc(this, CAT_FWD, 1);
+        launch_small_fwd(sr, st);      // K^ + P~ = K^ C_q + row statistics, one launch for all tasks and latents of the pool
+      } else
       {
         const long long off = 0, rows = n;
         if (prefetched) HIP_TRY(hipStreamWaitEvent(st, ev_kuf, 0));
@@ -1207,6 +1221,11 @@ struct hmogp_engine {
       // column statistics of segment i beside the forward contraction of segment i + 1 -- the Gram gains 4.0 ms, the
       // forward contractions lose 5.7 ms: an HBM-saturating kernel costs an FP64-MFMA GEMM beside it about its own
       // stand-alone time either way.)
+      if (small_rows) {
+        Scope sc(this, CAT_GRAM, 2);
+        launch_small_bwd(sr, st);      // H_q, r_q, dZ_q: block partials + their ordered sum into the bundle
+        continue;
+      }
       colstats_rows(0, n, 0);
       {
         // H_q += K^T diag(beta) K^ for all latents (svmogp_inf.py:145-147 summed over d)
@@ -1280,6 +1299,11 @@ struct hmogp_engine {
       }();
       small_path = small_mode && M <= HMOGP_SMALL_M && path_env != 0 && !small_veto;
       small_info_pending = false;
+      static const int rows_env = [] {   // HMOGP_SMALL_ROWS=0: the regular row-pass kernels behind the fused M x M kernels (A/B runs)
+        const char* e = getenv("HMOGP_SMALL_ROWS");
+        return e ? atoi(e) : 1;
+      }();
+      small_rows = small_path && rows_env != 0;
     }
 
   void begin(const hmogp_params* p, bool sync = true, bool will_exchange = false) {

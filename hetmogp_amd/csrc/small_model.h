@@ -17,6 +17,7 @@ struct SmallU {   // inputs / outputs of u_small_kernel (all device pointers; pe
   double* a = nullptr;             // [Q][M]
   double* klout = nullptr;         // [Q][KL_BLOCKS][5]
   int* info = nullptr;             // [Q] LAPACK info of the factorisation (zeroed by the caller)
+  int* flag = nullptr;             // [Q] hand-over flag of S between the two blocks of a latent (zeroed by the caller)
 };
 
 struct SmallF {   // finish_small_kernel
@@ -30,6 +31,25 @@ struct SmallF {   // finish_small_kernel
   double* gmu = nullptr;           // [M][Q]
   double *gL2 = nullptr, *gmu2 = nullptr;   // optional second copies (the engine's D2H staging block: one copy for all results)
 };
+
+struct SmallRows {   // small_fwd_kernel / small_bwd_kernel / small_red_kernel: the row pass of one pool of n rows, 64 rows per block
+  int M = 0, Q = 0, P = 1, ldz = 0, hyper = 1, want_z = 1;
+  long long n = 0, ldn = 0;        // rows of the pool, row stride of the per-latent row vectors / K^ / P~ workspaces
+  const double* X = nullptr;       // [n][P] inputs of the pool's rows
+  const double* Z = nullptr;       // [M][Q*P]
+  const double *var = nullptr, *ell = nullptr;   // [Q]
+  const double* C = nullptr;       // [Q][M][M]
+  const double* a = nullptr;       // [Q][M]
+  double *Kh = nullptr, *Pt = nullptr;           // [Q][ldn][M]
+  double *vp = nullptr, *vc = nullptr, *vpt = nullptr, *vct = nullptr;   // [Q][ldn] (vpt / vct unused without hyper)
+  const double *alpha = nullptr, *beta = nullptr, *alpha0 = nullptr, *beta0 = nullptr;   // [Q][ldn] row weights (backward)
+  double* slab = nullptr;          // [nblk][Q][M*M + M + M*P] block partials of H_q | r_q | dZ_q
+  double* stats = nullptr;         // bundle (H_q at stats + NG + q * per_q, r at + oR, dZ at + oDZ): receives the sums
+  long long NG = 0, per_q = 0, oR = 0, oDZ = 0;
+};
+size_t small_rows_lds_bytes();
+void launch_small_fwd(const SmallRows& r, hipStream_t s);
+void launch_small_bwd(const SmallRows& r, hipStream_t s);    // block partials + their deterministic sum into the bundle
 
 size_t small_lds_bytes();
 void launch_u_small(const SmallU& u, hipStream_t s);

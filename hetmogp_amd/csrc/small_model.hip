@@ -134,6 +134,10 @@ __device__ __forceinline__ void sm_trtri_wave(const double* __restrict__ L, doub
   }
 }
 
+// grid (Q, 2): block (q, 0) runs the K_uu chain and then the joint part, block (q, 1) the q(u) chain -- the two sequential
+// wave-level chains (Cholesky + triangular inverse of K_uu; triangular inverse of L) run on two CUs at once.  Block (q, 0) needs
+// S from block (q, 1): handed over through HBM behind an agent-scope release / acquire on flag[q] (2 Q <= 16 blocks: always
+// co-resident; S is published first thing, so the wait is never taken in practice).
 template <int P>
 __global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -144,12 +148,43 @@ __global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
   double* vec = X3 + SM * SLD;          // [4][SM]: diag pivots | m | a | scratch
   __shared__ double red[16];
   __shared__ int s_info;
-  const int q = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int q = blockIdx.x, role = blockIdx.y, t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int M = u.M, Q = u.Q;
   const long long MM = (long long)M * M, off = (long long)q * MM;
-  const double var = u.var[q], ell = u.ell[q], jit = u.jit[q];
+  double* o = u.klout + (long long)q * KL_BLOCKS * 5;
 
-  // ---- K_uu = k_q(Z_q, Z_q), both arguments passed (util.py:197): GPy's rounding order, no forced diagonal --------------------
+  if (role == 1) {
+    // ---- q(u) chain: L = flat_to_triang(L_flat) (svmogp_inf.py:193), S = L L^T (:194-195), S^-1 = dpotri(L) (:124) ------------
+    for (int e = t; e < M * M; e += NT) {
+      const int r = e / M, c = e - r * M;
+      const double v = (c <= r) ? u.Lflat[((long long)r * (r + 1) / 2 + c) * Q + q] : 0.0;
+      X2[r * SLD + c] = v;
+      u.L[off + e] = v;
+    }
+    __syncthreads();
+    sm_gemm<false, true>(X2, X2, X0, M, 2);                // S = L L^T  -> X0
+    __syncthreads();
+    sm_store(X0, u.S + off, M);
+    __threadfence();                                       // S is in HBM (agent scope) ...
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&u.flag[q], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... before block (q, 0) may read it
+    double l2 = 0.0, ninf = 0.0;
+    if (t < M) l2 = log(fabs(X2[t * SLD + t]));
+    if (w == 0) sm_trtri_wave(X2, X3, M, lane);            // L^-1 -> X3 (one wave)
+    __syncthreads();
+    sm_gemm<true, false>(X3, X3, X1, M, 1);                // S^-1 = L^-T L^-1  -> X1
+    __syncthreads();
+    sm_store(X1, u.Sqi + off, M);
+    for (int e = t; e < M * M; e += NT) ninf += isinf(X1[(e / M) * SLD + (e % M)]) ? 1.0 : 0.0;
+    l2 = block_sum(l2, red);
+    ninf = block_sum(ninf, red);
+    if (t == 0) o[5 + 0] = 0.0, o[5 + 1] = 0.0, o[5 + 2] = 0.0, o[5 + 3] = l2, o[5 + 4] = ninf;   // KL partial "block 1"
+    return;
+  }
+
+  // ---- K_uu chain ------------------------------------------------------------------------------------------------------------
+  const double var = u.var[q], ell = u.ell[q], jit = u.jit[q];
+  // K_uu = k_q(Z_q, Z_q), both arguments passed (util.py:197): GPy's rounding order, no forced diagonal
   for (int e = t; e < M * M; e += NT) {
     const int i = e / M, j = e - i * M;
     double zi[P], zj[P];
@@ -160,26 +195,18 @@ __global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
     u.Kuu[off + e] = k;
     X0[i * SLD + j] = k + ((i == j) ? jit : 0.0);     // the factorised copy carries the jitter (GPy jitchol)
   }
-  // meanwhile L = flat_to_triang(L_flat) (svmogp_inf.py:193) into X2, m into vec[1]
-  for (int e = t; e < M * M; e += NT) {
-    const int r = e / M, c = e - r * M;
-    const double v = (c <= r) ? u.Lflat[((long long)r * (r + 1) / 2 + c) * Q + q] : 0.0;
-    X2[r * SLD + c] = v;
-    u.L[off + e] = v;
-  }
   if (t < M) vec[SM + t] = u.mu[(long long)t * Q + q];
   if (t == 0) s_info = 0;
+  for (int e = t; e < KL_BLOCKS * 5; e += NT)          // KL partials: blocks 0 and 1 are written below / by block (q, 1)
+    if (e >= 10) o[e] = 0.0;
   __syncthreads();
-  // ---- wave 0: L_uu = chol(K_uu + jitter I), then L_uu^-1 (X1) ; wave 1 meanwhile: L^-1 (X3) -- the two sequential chains ----
-  if (w == 0) {
+  if (w == 0) {                                        // L_uu = chol(K_uu + jitter I), then L_uu^-1 -> X1, by one wave
     const int info = sm_potrf_wave(X0, vec, M, lane);
     if (lane == 0) s_info = info;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!info) sm_trtri_wave(X0, X1, M, lane);
-  } else if (w == 1) {
-    sm_trtri_wave(X2, X3, M, lane);                      // S^-1 = dpotri(L) needs L^-1 (svmogp_inf.py:124)
   }
   __syncthreads();
   if (s_info) {                                          // (the engine falls back to the regular path and its ladder)
@@ -190,29 +217,26 @@ __global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
     const int i = e / M, j = e - i * M;
     u.Luu[off + e] = (j <= i) ? X0[i * SLD + j] : 0.0;
   }
-  double l1 = 0.0, l2 = 0.0;
-  if (t < M) l1 = log(fabs(X0[t * SLD + t])), l2 = log(fabs(X2[t * SLD + t]));
+  double l1 = 0.0;
+  if (t < M) l1 = log(fabs(X0[t * SLD + t]));
   __syncthreads();
   sm_gemm<true, false>(X1, X1, X0, M, 1);                // K_uu^-1 = L_uu^-T L_uu^-1            (util.py:199)            -> X0
   __syncthreads();
   sm_store(X0, u.Kuui + off, M);
-  sm_gemm<true, false>(X3, X3, X1, M, 1);                // S^-1 = L^-T L^-1                                               -> X1
-  double ma = 0.0, tr = 0.0, ninf = 0.0;
+  double ma = 0.0, tr = 0.0;
   if (t < M) {                                           // a = K_uu^-1 m
     double sacc = 0.0;
     for (int k = 0; k < M; ++k) sacc = fma(X0[t * SLD + k], vec[SM + k], sacc);
     u.a[(long long)q * M + t] = sacc;
     ma = vec[SM + t] * sacc;
   }
+  // ---- joint part: needs S of block (q, 1) ---------------------------------------------------------------------------------
+  if (t == 0)
+    while (__hip_atomic_load(&u.flag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
   __syncthreads();
-  sm_store(X1, u.Sqi + off, M);
-  for (int e = t; e < M * M; e += NT) {
-    const int i = e / M, j = e - i * M;
-    ninf += isinf(X1[i * SLD + j]) ? 1.0 : 0.0;
-  }
-  sm_gemm<false, true>(X2, X2, X3, M, 2);                // S = L L^T                           (svmogp_inf.py:194-195)   -> X3
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  sm_load(X3, u.S + off, M, M);
   __syncthreads();
-  sm_store(X3, u.S + off, M);
   for (int e = t; e < M * M; e += NT) {
     const int i = e / M, j = e - i * M;
     tr += X0[i * SLD + j] * X3[i * SLD + j];
@@ -232,16 +256,11 @@ __global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
     else if (j < i) tv = cij + (X2[j * SLD + i] - X0[j * SLD + i]);
     u.Ctri[off + e] = tv;
   }
-  // ---- KL partials (svmogp_inf.py:245-249): the layout of kl_terms_kernel, everything in block 0 of the latent -------------------
+  // KL partials (svmogp_inf.py:245-249), kl_terms_kernel's layout: "block 0" of the latent
   tr = block_sum(tr, red);
   ma = block_sum(ma, red);
   l1 = block_sum(l1, red);
-  l2 = block_sum(l2, red);
-  ninf = block_sum(ninf, red);
-  double* o = u.klout + (long long)q * KL_BLOCKS * 5;
-  for (int e = t; e < KL_BLOCKS * 5; e += NT) o[e] = 0.0;
-  __syncthreads();
-  if (t == 0) o[0] = tr, o[1] = ma, o[2] = l1, o[3] = l2, o[4] = ninf;
+  if (t == 0) o[0] = tr, o[1] = ma, o[2] = l1, o[3] = 0.0, o[4] = 0.0;
 }
 
 __global__ __launch_bounds__(NT) void finish_small_kernel(SmallF f) {
@@ -333,6 +352,236 @@ __global__ __launch_bounds__(NT) void finish_small_kernel(SmallF f) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// [r4] The ROW PASS of a small model as two kernels (64 rows per block, latents one after the other, K^ / C_q tiles in LDS):
+//   small_fwd_kernel  K^ = k_q(X, Z_q) (the hot path's rounding variant, rbf_kernel<P, false>) -> HBM; P~ = K^ C_q on 4 x 4 FMA
+//                     micro-tiles; row statistics p, c (and the r2-weighted p~, c~) reduced over the 16 lanes that share a row
+//                     -- replaces rbf + forward GEMM + combine_parts (svmogp_inf.py:212-218; util.py:145-164)
+//   small_bwd_kernel  block partials of H_q = K^T diag(beta) K^ (lower micro-tiles), r_q = K^T alpha, dZ_q (svmogp_inf.py:145-147,
+//                     157-161 reduced against K^) -- replaces colstats + weighted Gram + two slab reductions
+//   small_red_kernel  deterministic sum of the block partials into the statistic bundle
+constexpr int RB = 64;
+
+template <int P>
+__global__ __launch_bounds__(NT) void small_fwd_kernel(SmallRows a) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* Cs = lds;                     // [M][SLD]
+  double* Kt = Cs + SM * SLD;           // [RB][SLD]
+  double* av = Kt + RB * SLD;           // [SM]
+  double* zs = av + SM;                 // [SM][P] inducing inputs / lengthscale
+  double* xs = zs + SM * P;             // [RB][P] inputs / lengthscale
+  const int t = threadIdx.x, M = a.M;
+  const long long n0 = (long long)blockIdx.x * RB;
+  const int nr = (int)min((long long)RB, a.n - n0);
+  const int r0 = 4 * (t >> 4), c0 = 4 * (t & 15);
+  {                                      // one latent per block: grid (row blocks, Q)
+    const int q = blockIdx.y;
+    const double var = a.var[q], ell = a.ell[q], il2 = 1.0 / (ell * ell), inv_l = 1.0 / ell;
+    const double* Cq = a.C + (long long)q * M * M;
+    for (int e = t; e < M * M; e += NT) Cs[(e / M) * SLD + (e % M)] = Cq[e];
+    if (t < M) av[t] = a.a[(long long)q * M + t];
+    for (int e = t; e < M * P; e += NT) zs[e] = a.Z[(long long)(e / P) * a.ldz + q * P + (e % P)];
+    for (int e = t; e < RB * P; e += NT) xs[e] = (e / P < nr) ? a.X[(n0 + e / P) * P + (e % P)] : 0.0;
+    __syncthreads();
+    double* Khq = a.Kh + (long long)q * a.ldn * M;
+    for (int e = t; e < RB * M; e += NT) {      // K^ tile: rbf_kernel<P, false>'s arithmetic (clip(r2) / l^2, no sqrt / divide)
+      const int r = e / M, m = e - r * M;
+      double k = 0.0;
+      if (r < nr) {
+        double xv[P], zv[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) xv[p] = xs[r * P + p], zv[p] = zs[m * P + p];
+        const double r2 = rbf_r2_fast<P>(xv, sumsq<P>(xv), zv, sumsq<P>(zv), il2);
+        k = var * exp(-0.5 * r2);
+        Khq[(n0 + r) * M + m] = k;
+      }
+      Kt[r * SLD + m] = k;
+    }
+    __syncthreads();
+    // P~ micro-tile: rows r0..r0+3 of the block, columns c0..c0+3
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    if (c0 < M)
+      for (int k = 0; k < M; ++k) {
+        double ka[4], cb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ka[i] = Kt[(r0 + i) * SLD + k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cb[j] = Cs[k * SLD + c0 + j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = fma(ka[i], cb[j], acc[i][j]);
+      }
+    double sp[4], sc[4], spt[4], sct[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sp[i] = sc[i] = spt[i] = sct[i] = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = c0 + j;
+        if (m < M) {
+          const double kv = Kt[(r0 + i) * SLD + m], pv = acc[i][j];
+          sp[i] += kv * av[m];
+          sc[i] += pv * kv;
+          if (a.hyper) {          // r2 as the regular epilogue forms it: sum_p (x/l - z/l)^2
+            double r2 = 0.0;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+              const double d = xs[(r0 + i) * P + p] * inv_l - zs[m * P + p] * inv_l;
+              r2 += d * d;
+            }
+            const double wv = kv * r2;
+            spt[i] += wv * av[m];
+            sct[i] += pv * wv;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 1; o <= 8; o <<= 1)             // the 16 lanes (t & 15) that share rows r0..r0+3
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        sp[i] += __shfl_xor(sp[i], o, 64);
+        sc[i] += __shfl_xor(sc[i], o, 64);
+        if (a.hyper) spt[i] += __shfl_xor(spt[i], o, 64), sct[i] += __shfl_xor(sct[i], o, 64);
+      }
+    if ((t & 15) == 0)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (r0 + i < nr) {
+          const long long o = (long long)q * a.ldn + n0 + r0 + i;
+          a.vp[o] = sp[i], a.vc[o] = sc[i];
+          if (a.hyper) a.vpt[o] = spt[i], a.vct[o] = sct[i];
+        }
+    if (a.want_z && c0 < M) {
+      double* Ptq = a.Pt + (long long)q * a.ldn * M;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (r0 + i < nr)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (c0 + j < M) Ptq[(n0 + r0 + i) * M + c0 + j] = acc[i][j];
+    }
+    __syncthreads();
+  }
+}
+
+template <int P>
+__global__ __launch_bounds__(NT) void small_bwd_kernel(SmallRows a) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* Kt = lds;                     // [RB][SLD]  K^ rows of the block
+  double* Pl = Kt + RB * SLD;           // [RB][SLD]  P~ rows (Z gradient only)
+  double* av = Pl + RB * SLD;           // [SM]
+  double* zs = av + SM;                 // [SM][P]
+  double* xs = zs + SM * P;             // [RB][P]
+  double* wt = xs + RB * P;             // [4][RB] alpha | beta | alpha0 | beta0
+  const int t = threadIdx.x, M = a.M;
+  const long long n0 = (long long)blockIdx.x * RB;
+  const int nr = (int)min((long long)RB, a.n - n0);
+  const long long slab_q = (long long)M * M + M + (long long)M * P;
+  const int m0 = 4 * (t >> 4), c0 = 4 * (t & 15);
+  {                                      // one latent per block: grid (row blocks, Q)
+    const int q = blockIdx.y;
+    const double* Khq = a.Kh + (long long)q * a.ldn * M;
+    const double* Ptq = a.Pt + (long long)q * a.ldn * M;
+    for (int e = t; e < RB * M; e += NT) {
+      const int r = e / M, m = e - r * M;
+      Kt[r * SLD + m] = (r < nr) ? Khq[(n0 + r) * M + m] : 0.0;
+      if (a.want_z) Pl[r * SLD + m] = (r < nr) ? Ptq[(n0 + r) * M + m] : 0.0;
+    }
+    if (t < M) av[t] = a.a[(long long)q * M + t];
+    for (int e = t; e < M * P; e += NT) zs[e] = a.Z[(long long)(e / P) * a.ldz + q * P + (e % P)];
+    for (int e = t; e < RB * P; e += NT) xs[e] = (e / P < nr) ? a.X[(n0 + e / P) * P + (e % P)] : 0.0;
+    if (t < RB) {
+      const long long o = (long long)q * a.ldn + n0 + t;
+      const bool in = t < nr;
+      wt[t] = in ? a.alpha[o] : 0.0, wt[RB + t] = in ? a.beta[o] : 0.0;
+      wt[2 * RB + t] = in ? a.alpha0[o] : 0.0, wt[3 * RB + t] = in ? a.beta0[o] : 0.0;
+    }
+    __syncthreads();
+    double* out = a.slab + ((long long)blockIdx.x * a.Q + q) * slab_q;
+    // H_q partial: lower micro-tiles only (the bundle carries the lower triangle between begin and finish)
+    if (m0 < M && c0 < M && c0 <= m0 + 3) {
+      double acc[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+      for (int r = 0; r < nr; ++r) {
+        const double b = wt[RB + r];
+        double ka[4], kb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ka[i] = Kt[r * SLD + m0 + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kb[j] = Kt[r * SLD + c0 + j] * b;     // k-scaled B operand, like the MFMA Gram
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = fma(ka[i], kb[j], acc[i][j]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (m0 + i < M && c0 + j <= m0 + i) out[(long long)(m0 + i) * M + c0 + j] = acc[i][j];
+    }
+    // r_q = K^T alpha ; dZ_q[m] = sum_n E_nm (x_n - z_m), E = (alpha0 a^T + 2 diag(beta0) P~) .* K^
+    if (t < M) {
+      const int m = t;
+      double rs = 0.0, dz[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) dz[p] = 0.0;
+      const double am = av[m];
+      for (int r = 0; r < nr; ++r) {
+        const double k = Kt[r * SLD + m];
+        rs += k * wt[r];
+        if (a.want_z) {
+          const double e = (wt[2 * RB + r] * am + 2.0 * wt[3 * RB + r] * Pl[r * SLD + m]) * k;
+#pragma unroll
+          for (int p = 0; p < P; ++p) dz[p] += e * (xs[r * P + p] - zs[m * P + p]);
+        }
+      }
+      out[(long long)M * M + m] = rs;
+#pragma unroll
+      for (int p = 0; p < P; ++p) out[(long long)M * M + M + (long long)m * P + p] = dz[p];
+    }
+    __syncthreads();
+  }
+}
+
+// bundle += sum over the blocks' partials, block by block in order (deterministic); one thread per output element
+__global__ __launch_bounds__(NT) void small_red_kernel(SmallRows a, int nblk) {
+  const int q = blockIdx.y, M = a.M, P = a.P;
+  const long long slab_q = (long long)M * M + M + (long long)M * P;
+  const long long e = (long long)blockIdx.x * NT + threadIdx.x;
+  if (e >= slab_q) return;
+  long long dst;
+  if (e < (long long)M * M) {
+    const int i = (int)(e / M), j = (int)(e - (long long)i * M);
+    if (j > i) return;                                   // (upper triangle: never written by the blocks)
+    dst = a.NG + q * a.per_q + e;
+  } else if (e < (long long)M * M + M) {
+    dst = a.NG + q * a.per_q + a.oR + (e - (long long)M * M);
+  } else {
+    if (!a.want_z) return;
+    dst = a.NG + q * a.per_q + a.oDZ + (e - (long long)M * M - M);
+  }
+  // four interleaved partial sums in a FIXED order (blocks b = i mod 4): independent loads in flight, same bits every run
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const double* src = a.slab + (long long)q * slab_q + e;
+  const long long st = (long long)a.Q * slab_q;
+  int b = 0;
+  for (; b + 4 <= nblk; b += 4) {
+    s0 += src[(long long)b * st], s1 += src[(long long)(b + 1) * st], s2 += src[(long long)(b + 2) * st], s3 += src[(long long)(b + 3) * st];
+  }
+  for (; b < nblk; ++b) s0 += src[(long long)b * st];
+  a.stats[dst] += (s0 + s1) + (s2 + s3);
+}
 }  // namespace
 
 size_t small_lds_bytes() { return sizeof(double) * (4 * SM * SLD + 4 * SM); }
@@ -347,9 +596,42 @@ void launch_u_small(const SmallU& u, hipStream_t s) {
     HIP_TRY(hipFuncSetAttribute((const void*)finish_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes()));
     attr_set = true;
   }
-  DISPATCH_P(u.P, hipLaunchKernelGGL((u_small_kernel<PP>), dim3(u.Q), dim3(NT), small_lds_bytes(), s, u));
+  DISPATCH_P(u.P, hipLaunchKernelGGL((u_small_kernel<PP>), dim3(u.Q, 2), dim3(NT), small_lds_bytes(), s, u));
 }
 
 void launch_finish_small(const SmallF& f, hipStream_t s) {
   hipLaunchKernelGGL(finish_small_kernel, dim3(f.Q), dim3(NT), small_lds_bytes(), s, f);
+}
+
+size_t small_rows_lds_bytes() { return sizeof(double) * (2 * SM * SLD + SM + SM * 4 + RB * 4 + 4 * RB); }
+
+static void small_rows_attr() {
+  static bool done = false;
+  if (done) return;
+  const int b = (int)small_rows_lds_bytes();
+  HIP_TRY(hipFuncSetAttribute((const void*)small_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
+  HIP_TRY(hipFuncSetAttribute((const void*)small_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
+  HIP_TRY(hipFuncSetAttribute((const void*)small_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
+  HIP_TRY(hipFuncSetAttribute((const void*)small_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
+  HIP_TRY(hipFuncSetAttribute((const void*)small_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
+  HIP_TRY(hipFuncSetAttribute((const void*)small_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
+  HIP_TRY(hipFuncSetAttribute((const void*)small_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
+  HIP_TRY(hipFuncSetAttribute((const void*)small_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, b));
+  done = true;
+}
+
+void launch_small_fwd(const SmallRows& r, hipStream_t s) {
+  if (r.n <= 0) return;
+  small_rows_attr();
+  const unsigned nblk = (unsigned)((r.n + 63) / 64);
+  DISPATCH_P(r.P, hipLaunchKernelGGL((small_fwd_kernel<PP>), dim3(nblk, r.Q), dim3(NT), small_rows_lds_bytes(), s, r));
+}
+
+void launch_small_bwd(const SmallRows& r, hipStream_t s) {
+  if (r.n <= 0) return;
+  small_rows_attr();
+  const unsigned nblk = (unsigned)((r.n + 63) / 64);
+  DISPATCH_P(r.P, hipLaunchKernelGGL((small_bwd_kernel<PP>), dim3(nblk, r.Q), dim3(NT), small_rows_lds_bytes(), s, r));
+  const long long slab_q = (long long)r.M * r.M + r.M + (long long)r.M * r.P;
+  hipLaunchKernelGGL(small_red_kernel, dim3((unsigned)((slab_q + NT - 1) / NT), r.Q), dim3(NT), 0, s, r, (int)nblk);
 }
