@@ -270,10 +270,13 @@ __global__ __launch_bounds__(NT) void finish_small_kernel(SmallF f) {
   double* X2 = X1 + SM * SLD;
   double* X3 = X2 + SM * SLD;
   double* vec = X3 + SM * SLD;          // [4][SM]: r | K^-1 r | a
-  const int q = blockIdx.x, t = threadIdx.x;
+  // grid (Q, 2): both blocks of a latent form G = K^-1 H K^-1 and K^-1 r (two products: cheaper than a hand-over); block (q, 0)
+  // goes on with the q(u) gradients, block (q, 1) with the K_uu-side ones -- the two tails run on two CUs at once
+  const int q = blockIdx.x, role = blockIdx.y, t = threadIdx.x;
   const int M = f.M, Q = f.Q;
   const long long MM = (long long)M * M, off = (long long)q * MM;
   const double* Hq = f.H + (long long)q * f.per_q;
+  if (role == 1 && !f.want_hz) return;
   // H_q arrives as its lower triangle (row pass / exchange step): mirrored here
   for (int e = t; e < M * M; e += NT) {
     const int i = e / M, j = e - i * M;
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(NT) void finish_small_kernel(SmallF f) {
   sm_load(X1, f.Kuui + off, M, M);
   if (t < M) vec[t] = Hq[f.oR + t], vec[2 * SM + t] = f.a[(long long)q * M + t];
   __syncthreads();
-  if (f.want_hz || f.want_qu) {
+  if (role == 0) {
     for (int e = t; e < M * M; e += NT) {               // (the bundle itself keeps the full symmetric H_q, like launch_mirror_lower)
       const int i = e / M, j = e - i * M;
       if (j > i) f.Hfull[(long long)q * f.per_q + (long long)i * M + j] = X0[i * SLD + j];
@@ -293,8 +296,8 @@ __global__ __launch_bounds__(NT) void finish_small_kernel(SmallF f) {
     double s = 0.0;
     for (int k = 0; k < M; ++k) s = fma(X1[t * SLD + k], vec[k], s);
     vec[SM + t] = s;
-    f.Kr[(long long)q * M + t] = s;
-    if (f.want_qu) {                                                     // dL/dm = K^-1 r - a   (:130,144,168)
+    if (role == 0) f.Kr[(long long)q * M + t] = s;
+    if (role == 0 && f.want_qu) {                                        // dL/dm = K^-1 r - a   (:130,144,168)
       f.gmu[(long long)t * Q + q] = s - vec[2 * SM + t];
       if (f.gmu2) f.gmu2[(long long)t * Q + q] = s - vec[2 * SM + t];
     }
@@ -308,8 +311,8 @@ __global__ __launch_bounds__(NT) void finish_small_kernel(SmallF f) {
     if (j > i) X3[i * SLD + j] = X3[j * SLD + i];
   }
   __syncthreads();
-  sm_store(X3, f.G + off, M);
-  if (f.want_qu) {
+  if (role == 0) sm_store(X3, f.G + off, M);
+  if (role == 0 && f.want_qu) {
     sm_load(X0, f.Sqi + off, M, M);                      // (H is no longer needed)
     __syncthreads();
     for (int e = t; e < M * M; e += NT) {                // dL/dS = G - (K^-1 - S^-1) / 2   (svmogp_inf.py:131,169)
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(NT) void finish_small_kernel(SmallF f) {
     }
     __syncthreads();
   }
-  if (f.want_hz) {
+  if (role == 1) {
     sm_load(X0, f.KiS + off, M, M);
     __syncthreads();
     sm_gemm<false, true>(X3, X0, X2, M);                 // G S K^-1 = G (K^-1 S)^T   (tmp_dv, svmogp_inf.py:151)    X2
@@ -600,7 +603,7 @@ void launch_u_small(const SmallU& u, hipStream_t s) {
 }
 
 void launch_finish_small(const SmallF& f, hipStream_t s) {
-  hipLaunchKernelGGL(finish_small_kernel, dim3(f.Q), dim3(NT), small_lds_bytes(), s, f);
+  hipLaunchKernelGGL(finish_small_kernel, dim3(f.Q, 2), dim3(NT), small_lds_bytes(), s, f);
 }
 
 size_t small_rows_lds_bytes() { return sizeof(double) * (2 * SM * SLD + SM + SM * 4 + RB * 4 + 4 * RB); }
