@@ -593,11 +593,11 @@ def other_configs(args):
         e.update(extra)
         res.append(e)
 
-    def run(name, specs, N, M, Q, P, seed, **extra):
+    def run(name, specs, N, M, Q, P, seed, steps=None, warmup=2, **extra):
         prm, X, Y = make_case(specs, [N] * len(specs), M=M, Q=Q, P=P, seed=seed)
         eng = Engine(specs, Q, M, P, reuse_outputs=True)
         eng.set_data(X, Y)
-        ms, cat, out = _time_steps(eng, prm, K)
+        ms, cat, out = _time_steps(eng, prm, steps or K, warmup=warmup)
         if not np.isfinite(out["elbo"]):
             raise SystemExit("bench.py: non-finite ELBO in " + name)
         return eng, prm, X, Y, ms, cat, out
@@ -605,9 +605,13 @@ def other_configs(args):
 
     # C1 -- the reference's own CPU-runnable case (README usage snippet's likelihood list)
     c1 = [("HetGaussian", {}), ("Bernoulli", {}), ("Categorical", {"K": 3})]
-    eng, prm, X, Y, ms, cat, out = run("C1", c1, 1000, 50, 2, 1, 20260930)
+    # (a sub-millisecond step: 1000 timed evaluations behind 500 warm-ups -- the first ~0.5 s after idle run ~30 % slower)
+    eng, prm, X, Y, ms, cat, out = run("C1", c1, 1000, 50, 2, 1, 20260930, steps=1000, warmup=500)
+    cap, rep = eng.graph_stats()
     entry("C1: T=3 [HetGaussian,Bernoulli,Categorical(3)] Df=5, N_t=1000, M=50, Q=2, full-batch ELBO+gradients", 3000, 2, 50,
-          ms, cat, out, note="launch-latency bound (about 40 kernel launches); compare cpu_baseline_literal.runs[0]",
+          ms, cat, out, steps_timed=1000, hipgraph_captures=cap, hipgraph_replays=rep,
+          note="small-model path: fused LDS kernels (small_model.hip) replayed from a captured hipGraph, 17 kernels per evaluation; "
+               "compare cpu_baseline_literal.runs[0]",
           parity_vs_reference_run=_parity_c1_vs_reference_fixture())
     eng.close()
     # C2 -- the headline mix at M = 512
