@@ -283,11 +283,13 @@ def main():
             line["replicated_ms_per_rank"] = repl_all
         if world == 1 and not args.no_exact_zero_pass:
             line["exact_zero_windows"] = exact_zero_pass(args, prm, X, Y, N, M, Q, P, out)
+        # GPU legs first, CPU legs last: after the full-size CPU baseline (64 worker threads x BLAS threads, ~20 s of all host
+        # cores) the launch-latency-bound chains of the small configurations measured 0.3 ms slower (host-side launch jitter)
+        if world == 1 and not args.no_other_configs:
+            line["other_configs"] = other_configs(args)   # (the headline engine keeps its 40 GB of row workspaces: 288 GB of HBM)
         if world == 1 and not args.no_cpu_baseline:
             line.update(cpu_baselines(args, eng, prm, X, Y, N, M, Q, P))
-        if world == 1 and not args.no_other_configs:
-            eng.close()                                   # give the headline's 40 GB of row workspaces back first
-            line["other_configs"] = other_configs(args)
+            eng.close()
         print(json.dumps(line))
         sys.stdout.flush()
     if world > 1:

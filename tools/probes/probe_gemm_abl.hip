@@ -166,6 +166,94 @@ __global__ __launch_bounds__(NT, 4) void gemm(const double* __restrict__ A, cons
     }
 }
 
+// 16 waves per block, block tile 256 x 128 (one block per CU, 4 waves per SIMD), the cross-barrier fragment loop: twice the MFMA work
+// per tile prologue / epilogue and per B-tile load of the 128 x 128 kernel.  LDS 2 x (256 x 18 + 16 x 144) doubles = 108 KB (dynamic).
+constexpr int BM2 = 256, NT2 = 1024, TILE_A2 = BM2 * RM_LD;
+__global__ __launch_bounds__(NT2, 4) void gemm256(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C,
+                                                  int n, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) double dyn[];
+  double* la0 = dyn;                      // [2][TILE_A2]
+  double* lb0 = dyn + 2 * TILE_A2;        // [2][TILE]
+  const int tiles_n = N / BN;
+  int v = blockIdx.x;
+  const int ntiles = (n / BM2) * tiles_n;
+  if ((ntiles & 7) == 0) { const int cpx = ntiles >> 3; v = (v & 7) * cpx + (v >> 3); }
+  const int ti = v / tiles_n, tj = v - ti * tiles_n, i0 = ti * BM2, j0 = tj * BN;
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), lr = lane & 15, lk = lane >> 4;
+  const int wm = w >> 2, wn = w & 3;
+  f64x4 acc[4][2];
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0, 0, 0, 0};
+  double ra[4], rb[2];
+  const int ar = t >> 2, ak = (t & 3) * 4, bk = t >> 6, bc = (t & 63) * 2;
+  const double* pa = A + (long long)(i0 + ar) * K + ak;
+  const double* pb = B + (long long)bk * N + j0 + bc;
+  auto load = [&](int k0) {
+    const f64x2 x0 = *reinterpret_cast<const f64x2*>(pa + k0), x1 = *reinterpret_cast<const f64x2*>(pa + k0 + 2);
+    ra[0] = x0.x, ra[1] = x0.y, ra[2] = x1.x, ra[3] = x1.y;
+    const f64x2 y0 = *reinterpret_cast<const f64x2*>(pb + (long long)k0 * N);
+    rb[0] = y0.x, rb[1] = y0.y;
+  };
+  auto stage = [&](int buf) {
+    double* sa = la0 + buf * TILE_A2 + ar * RM_LD + ak;
+    *reinterpret_cast<f64x2*>(sa) = f64x2{ra[0], ra[1]};
+    *reinterpret_cast<f64x2*>(sa + 2) = f64x2{ra[2], ra[3]};
+    *reinterpret_cast<f64x2*>(lb0 + buf * TILE + bk * KM_LD + bc) = f64x2{rb[0], rb[1]};
+  };
+  double ga[2][4], gb[2][2];
+  auto frag = [&](int buf, int kk, int s_) {
+    const double* fpa = la0 + buf * TILE_A2 + (wm * 64 + lr) * RM_LD + kk * 4 + lk;
+    const double* fpb = lb0 + buf * TILE + (kk * 4 + lk) * KM_LD + wn * 32 + lr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ga[s_][i] = fpa[i * 16 * RM_LD];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) gb[s_][i] = fpb[i * 16];
+  };
+  auto mm8 = [&](int s_) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[s_][a], gb[s_][b], acc[a][b], 0, 0, 0);
+  };
+  int cur = 0;
+  load(0);
+  stage(0);
+  load(BK);
+  __syncthreads();
+  frag(0, 0, 0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    frag(cur, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mm8(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (k0 + BK < K) stage(cur ^ 1);
+    if (k0 + 2 * BK < K) load(k0 + 2 * BK);
+    __builtin_amdgcn_sched_barrier(0);
+    frag(cur, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mm8(1);
+    __builtin_amdgcn_sched_barrier(0);
+    frag(cur, 3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mm8(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    if (k0 + BK < K) frag(cur ^ 1, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mm8(1);
+    __builtin_amdgcn_sched_barrier(0);
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double* crow = C + (long long)(i0 + wm * 64 + a * 16 + 4 * r + lk) * N + j0 + wn * 32;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) crow[b * 16 + lr] = acc[a][b][r];
+    }
+}
+
 int main() {
   const int n = 131072, N = 1024, K = 1024;
   double *A, *B, *C;
@@ -175,14 +263,15 @@ int main() {
   for (auto& x : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; x = (double)(s >> 11) / 9007199254740992.0 * 2.0 - 1.0; }
   hipMemcpy(A, h.data(), sizeof(double) * (size_t)n * K, hipMemcpyHostToDevice);
   hipMemcpy(B, h.data(), sizeof(double) * (size_t)K * N, hipMemcpyHostToDevice);
+  hipFuncSetAttribute((const void*)gemm256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * (2 * TILE_A2 + 2 * TILE)));
   hipEvent_t e0, e1;
   hipEventCreate(&e0), hipEventCreate(&e1);
   const int blocks = (n / BM) * (N / BN);
   const char* names[] = {"baseline (stage-first)", "no barrier", "no global loads", "no ds_write", "no loads, no ds_write",
                          "no ds_read", "no loads/ds_write/ds_read (MFMA + barrier)", "MFMA only", "no barrier, no loads",
-                         "setprio 3 around MFMAs", "no barrier + no ds_write + no loads", "LDS-counter sync instead of s_barrier", "fragment prefetch carried across the barrier", "same, stage + load behind the first 8 MFMAs", "same + setprio", "same, transposed accumulators (SWAP)"};
+                         "setprio 3 around MFMAs", "no barrier + no ds_write + no loads", "LDS-counter sync instead of s_barrier", "fragment prefetch carried across the barrier", "same, stage + load behind the first 8 MFMAs", "same + setprio", "same, transposed accumulators (SWAP)", "16 waves, 256 x 128 tile, one block per CU, same loop"};
   for (int pass = 0; pass < 2; ++pass)     // pass 0 warms the device up (clocks): only pass 1 is printed
-  for (int variant = 0; variant < 16; ++variant) {
+  for (int variant = 0; variant < 17; ++variant) {
     auto run = [&] {
 #define L(F) hipLaunchKernelGGL(gemm<F>, dim3(blocks), dim3(NT), 0, 0, A, B, C, n, N, K)
       switch (variant) {
@@ -202,6 +291,7 @@ int main() {
         case 13: L(384); break;
         case 14: L(416); break;
         case 15: L(896); break;
+        case 16: hipLaunchKernelGGL(gemm256, dim3((n / BM2) * (N / BN)), dim3(NT2), sizeof(double) * (2 * TILE_A2 + 2 * TILE), 0, A, B, C, n, N, K); break;
       }
     };
     run();
