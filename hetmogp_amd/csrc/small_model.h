@@ -17,6 +17,7 @@ struct SmallU {   // inputs / outputs of u_small_kernel (all device pointers; pe
   double* a = nullptr;             // [Q][M]
   double* klout = nullptr;         // [Q][KL_BLOCKS][5]
   int* info = nullptr;             // [Q] LAPACK info of the factorisation (zeroed by the caller)
+  int stop_after = 0;              // diagnostics (HMOGP_USMALL_STOP): leave block (q, 0) after phase 1..3 -- timing only
   int* flag = nullptr;             // [Q] hand-over flag of S between the two blocks of a latent (zeroed by the caller)
 };
 

@@ -231,6 +231,7 @@ __global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
   for (int e = t; e < KL_BLOCKS * 5; e += NT)          // KL partials: blocks 0 and 1 are written below / by block (q, 1)
     if (e >= 10) o[e] = 0.0;
   __syncthreads();
+  if (u.stop_after == 1) return;
   if (w == 0) {                                        // wave 0: L_uu = chol(K_uu + jitter I) ...
     const int info = sm_potrf_wave(X0, vec, M, lane, &s_progress);
     if (lane == 0) s_info = info;
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
     sm_trtri_follow(X0, vec, X1, M, lane, &s_progress);
   }
   __syncthreads();
+  if (u.stop_after == 2) return;
   if (s_info) {                                          // (the engine falls back to the regular path and its ladder)
     if (t == 0) u.info[q] = s_info;
     return;
@@ -259,6 +261,7 @@ __global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
     u.a[(long long)q * M + t] = sacc;
     ma = vec[SM + t] * sacc;
   }
+  if (u.stop_after == 3) return;
   // ---- joint part: needs S of block (q, 1) ---------------------------------------------------------------------------------
   if (t == 0)
     while (__hip_atomic_load(&u.flag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
@@ -618,7 +621,13 @@ __global__ __launch_bounds__(NT) void small_red_kernel(SmallRows a, int nblk) {
 
 size_t small_lds_bytes() { return sizeof(double) * (4 * SM * SLD + 4 * SM); }
 
-void launch_u_small(const SmallU& u, hipStream_t s) {
+void launch_u_small(const SmallU& u_in, hipStream_t s) {
+  SmallU u = u_in;
+  static const int stop = [] {
+    const char* e = getenv("HMOGP_USMALL_STOP");
+    return e ? atoi(e) : 0;
+  }();
+  u.stop_after = stop;
   static bool attr_set = false;
   if (!attr_set) {   // > 64 KB of dynamic LDS needs the opt-in
     HIP_TRY(hipFuncSetAttribute((const void*)u_small_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes()));
