@@ -419,18 +419,20 @@ class SVMOGP(object):
         self.Xmulti, self.Ymulti = X, Y
 
 
-    def init_q_u_to_prior(self, jitter=1e-6):
-        """q(u_q) := p(u_q) = N(0, K_uu,q) (L_q = chol(K_uu,q + jitter * variance * I), m_q = 0).  Not in the reference, whose
+    def init_q_u_to_prior(self):
+        """q(u_q) := p(u_q) = N(0, K_uu,q) (L_q = jitchol(K_uu,q), m_q = 0; covariance and factorisation on the device:
+        hmogp_rbf_cross_cov + hmogp_jitchol_inv, GPy's jitter ladder if K_uu needs it).  Not in the reference, whose
         constructor starts from S_q = I (svmogp.py:66-69): with many close inducing points K_uu^-1 S K_uu^-1 is then
         enormous, q(f) has variances of 1e3 and more, and the expectations of exp-link likelihoods (Poisson, Gamma) are
         astronomically large -- a natural-gradient (Newton-like) step computed from them diverges.  Adadelta's small
         Euclidean steps survive that start; the natural-gradient loop starts from the prior instead."""
+        from .engine import jitchol_inv
+        dev = self._engine_device()
         r, c = np.tril_indices(self.num_inducing)
-        for q, k in enumerate(self.kern_list):
-            Zq = self.Z.values[:, q * self.Xdim:(q + 1) * self.Xdim]
-            K = k.K(Zq, Zq)
-            K = 0.5 * (K + K.T) + jitter * float(k.variance[0]) * np.eye(self.num_inducing)
-            self.q_u_chols[:, q] = np.linalg.cholesky(K)[r, c]
+        K = np.stack([k.K(self.Z.values[:, q * self.Xdim:(q + 1) * self.Xdim]) for q, k in enumerate(self.kern_list)])
+        L, _, _ = jitchol_inv(0.5 * (K + K.transpose(0, 2, 1)), device=dev)
+        for q in range(self.num_latent_funcs):
+            self.q_u_chols[:, q] = L[q][r, c]
         self.q_u_means[...] = 0.0
         self._dirty = True
         return self
