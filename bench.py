@@ -78,8 +78,8 @@ def _self_launch(ngpus):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=200000, help="rows per task (headline: 200000)")
     ap.add_argument("--inducing", type=int, default=1024, help="M (headline: 1024)")
     ap.add_argument("--latents", type=int, default=3, help="Q (headline: 3)")
@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip C1 / C2 / C3 / C4-share / C5 (N=1 only)")
     ap.add_argument("--other-steps", type=int, default=5, help="timed steps per other configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-wakeup", action="store_true", help="skip the ~0.3 s synthetic device wake-up before the warm-up steps")
     ap.add_argument("--no-exact-zero-pass", action="store_true", help="skip the extra (untimed-for-value) opt-in mode pass")
     args = ap.parse_args()
 
@@ -156,6 +157,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Device wake-up (NOT a step of the workload): ~0.3 s of a synthetic FP64-MFMA contraction.  The first ~0.5 s of kernels after an
+    # idle period run 5-10 % slower (clock ramp): without it a run with few warm-up steps times the ramp, not the path.
+    if not args.no_wakeup:
+        import ctypes as _C
+        from hetmogp_amd._lib import lib as _hl
+        _ms = _C.c_double()
+        _hl.hmogp_bench_contraction(local_rank, 1, 131072, 1024, int(os.environ.get("HMOGP_WAKEUP_ITERS", "70")), _C.byref(_ms))
     for _ in range(args.warmup):
         out = step()
     fence()
@@ -163,15 +171,19 @@ def main():
     if reducer is not None:
         reducer.total_ms, reducer.n_calls = 0.0, 0
     t0 = time.perf_counter()
-    cat_ms, cat_n = {}, {}
+    cat_ms, cat_n, step_walls = {}, {}, []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         out = step()
+        step_walls.append(1e3 * (time.perf_counter() - ts))
         ms, nl = eng.timings()              # HIP-event spans on the engine's streams, per kernel family
         for k in ms:
             cat_ms[k] = cat_ms.get(k, 0.0) + ms[k]
             cat_n[k] = cat_n.get(k, 0) + nl[k]
+    tf = time.perf_counter()
     fence()
     elapsed = time.perf_counter() - t0
+    closing_fence_ms = 1e3 * (time.perf_counter() - tf)
     rows_all = [rows_rank]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -270,6 +282,7 @@ def main():
             "gram_tflops": gram_flops / (cat_ms["gram_gemm"] / 1e3) / 1e12 if cat_ms["gram_gemm"] > 0 else 0.0,
             "replicated_ms": cat_ms["mxm_algebra"] / args.steps,  # M x M algebra every rank repeats (the Amdahl term)
             "rccl_ranks": rccl_ranks,
+            "step_wall_ms": [round(v, 3) for v in step_walls], "closing_fence_ms": round(closing_fence_ms, 3),
             "rows_per_rank": rows_all,
             "elbo": out["elbo"],
         }
