@@ -213,7 +213,8 @@ class SVMOGP(object):
                           (results unchanged).  "auto" turns it on where it can pay off -- 1-D inputs that are
                           sorted within every task (what the reference's own slicing assumes, util.py:52-72) and
                           M <= 8192; unsorted / multi-dimensional inputs stay dense (and even when it is on, the
-                          device falls back to full ranges for rows that are not banded)
+                          device falls back to full ranges for rows that are not banded); M < 128 stays dense too
+                          (nothing to skip at that size, and the small-model kernels need the dense layout)
         quirks            "reference" (default: reproduce the reference's results including its known deviations from the
                           exact gradient) | "exact" (true ELBO gradients) | an int mask of _lib.QUIRK_*
         gradients_of_fixed  batch mode only: also evaluate the gradient groups whose parameters are all fixed (the
@@ -247,7 +248,7 @@ class SVMOGP(object):
         if isinstance(exact_zero_windows, str):
             if exact_zero_windows != "auto":
                 raise ValueError("exact_zero_windows must be False, True or 'auto'")
-            exact_zero_windows = bool(self.Xdim == 1 and self.num_inducing <= 8192 and
+            exact_zero_windows = bool(self.Xdim == 1 and 128 <= self.num_inducing <= 8192 and
                                       all(x.shape[0] < 2 or bool(np.all(np.diff(x[:, 0]) >= 0.0)) for x in self.Xmulti_all))
         self.exact_zero_windows = bool(exact_zero_windows)
         self._engine = Engine(likelihood.specs(), self.num_latent_funcs, self.num_inducing, self.Xdim, device=device,
