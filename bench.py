@@ -164,6 +164,11 @@ def main():
         from hetmogp_amd._lib import lib as _hl
         _ms = _C.c_double()
         _hl.hmogp_bench_contraction(local_rank, 1, 131072, 1024, int(os.environ.get("HMOGP_WAKEUP_ITERS", "70")), _C.byref(_ms))
+    # (the interpreter's cyclic garbage collector is kept out of the timed region: with torch imported a generation-2 collection
+    #  walks ~1e6 objects and stalls the host thread for 30-40 ms -- seen as ONE 158 ms step among twenty 120.7 ms ones)
+    import gc
+    gc.collect()
+    gc.disable()
     for _ in range(args.warmup):
         out = step()
     fence()
@@ -184,6 +189,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     closing_fence_ms = 1e3 * (time.perf_counter() - tf)
+    # (the collector stays off for the other timed loops of this process; they collect explicitly between workloads)
     rows_all = [rows_rank]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -576,6 +582,8 @@ def _parity_c1_vs_reference_fixture():
 
 def _time_steps(eng, prm, steps, warmup=2, **kw):
     """Wall ms per `elbo_grad` (synchronous at return) and the per-family kernel ms of the last `steps` calls."""
+    import gc
+    gc.collect()              # (automatic collection is off in this process, see main(): collect between workloads instead)
     for _ in range(warmup):
         out = eng.elbo_grad(**dict(prm, **kw))
     t0, cat = time.perf_counter(), {}
@@ -683,6 +691,8 @@ def svi_config(args, K):
     from hetmogp_amd.engine import Engine
     from hetmogp_amd.kern import RBF
     from hetmogp_amd.synthetic import make_case
+    import gc
+    gc.collect()
     N_all, B, M, Q, P = 1000000, 8192, 1024, 3, 1
     prm, X, Y = make_case(SPECS, [N_all] * 4, M=M, Q=Q, P=P, seed=20260932)
     # (a) one full-gradient evaluation of a minibatch (all groups) straight through the C ABI
