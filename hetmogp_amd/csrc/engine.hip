@@ -825,6 +825,9 @@ struct hmogp_engine {
       }
       return;
     }
+    // (in-place updates of the resident q(u) -- Adadelta, natural gradient -- run on the main stream without a host
+    //  synchronisation: whatever touches q(u) on the third stream next is ordered behind them; one stream in small-problem mode)
+    if (!small_mode) HIP_TRY(hipStreamWaitEvent(st3, ev_qu, 0));
     if (small_mode && M <= 128) {     // one image, one copy: [ hypers | Z | (m_u | L_flat unless q(u) is resident) ]
       std::memcpy(h_small + oZ, p->Z, sizeof(double) * M * Q * P);
       long long n_up = oMu;
@@ -842,8 +845,6 @@ struct hmogp_engine {
       if (!resident) HIP_TRY(hipMemcpyAsync(dLflat.p, p->L_flat, sizeof(double) * Mtri * Q, hipMemcpyHostToDevice, st3));
       HIP_TRY(hipMemcpyAsync(dsmall.p, h_small, sizeof(double) * n_small, hipMemcpyHostToDevice, st));
     }
-    // (an in-place natural-gradient update of the resident q(u); one stream in small-problem mode: already ordered)
-    if (resident && !small_mode) HIP_TRY(hipStreamWaitEvent(st3, ev_qu, 0));
     HIP_TRY(hipEventRecord(ev_params, st));   // what the second stream has to wait for before it reads Z / the hypers
   }
 
@@ -1589,7 +1590,9 @@ struct hmogp_engine {
     const bool has = phase == 1 && (group_mask & HMOGP_GROUP_QU) != 0;
     launch_adadelta(dmu.d(), ad_gms_m.d(), ad_sms_m.d(), ad_step_m.d(), ad_pend_m.d(), has ? gmu.d() : nullptr, -1.0, nm, phase, rate, m, d, omd, o, st);
     launch_adadelta(dLflat.d(), ad_gms_L.d(), ad_sms_L.d(), ad_step_L.d(), ad_pend_L.d(), has ? gL.d() : nullptr, -1.0, nl, phase, rate, m, d, omd, o, st);
-    HIP_TRY(hipStreamSynchronize(st));
+    // (no host synchronisation: every consumer of the resident q(u) is ordered behind this stream -- the next evaluation's q(u)
+    //  chain on the third stream waits for ev_qu, hmogp_qu_read / hmogp_qu_natgrad run on this stream)
+    HIP_TRY(hipEventRecord(ev_qu, st));
   }
 
   // Inner-protocol debug export (include/hetmogp_hip.h: hmogp_debug_raw_grads): the gradient dictionary of
