@@ -1686,29 +1686,29 @@ struct hmogp_engine {
     ng_mq.ensure(sizeof(double) * M * Q), ng_lflat.ensure(sizeof(double) * Mtri * Q);
     if (!h_info2) HIP_TRY(hipHostMalloc((void**)&h_info2, sizeof(int) * 2 * HMOGP_MAXQ, hipHostMallocDefault));
     HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));                                     // the q(u) tail of the evaluation (third stream)
-    launch_natgrad_prec(Sqi.d(), dLdS.d(), gamma, HK.d(), Q, M, st);                 // Lambda = S^-1 - 2 gamma dL/dS: new precision
+    // Lambda = S^-1 - 2 gamma dL/dS is the new precision.  It is factorised REVERSED (rows and columns): J Lambda J = R R^T
+    // gives Lambda = U U^T with U = J R J upper triangular, hence S_new = Lambda^-1 = U^-T U^-1 and L_new = U^-T = the
+    // anti-transpose of R^-1 is the lower Cholesky factor of S_new (unique: positive diagonal) -- one factorisation and one
+    // triangular inverse, no product R^-T R^-1 and no second factorisation.
+    launch_natgrad_prec(Sqi.d(), dLdS.d(), gamma, G.d(), Q, M, true, st);
     launch_gemv_batched(Sqi.d(), dmu.d(), ng_t1.d(), Q, M, 1, Q, st);                // S^-1 m
     launch_gemv_batched(dLdS.d(), dmu.d(), ng_t2.d(), Q, M, 1, Q, st);               // dL/dS m
     launch_natgrad_theta1(ng_t1.d(), ng_t2.d(), gmu.d(), gamma, ng_th.d(), Q, M, st);
-    HIP_TRY(hipMemcpyAsync(G.p, HK.p, sizeof(double) * (long long)M * M * Q, hipMemcpyDeviceToDevice, st));
-    launch_potrf_batched(G.d(), Q, M, dinfo.as<int>(), dscr.d(), st);                // Lambda = R R^T
+    launch_potrf_batched(G.d(), Q, M, dinfo.as<int>(), dscr.d(), st);                // J Lambda J = R R^T
     HIP_TRY(hipMemcpyAsync(h_info2, dinfo.p, sizeof(int) * Q, hipMemcpyDeviceToHost, st));
     // (speculative, like the K_uu chain of an evaluation: a failed factorisation makes the launches below no-ops on garbage
     //  that is never committed)
-    launch_trtri_batched(G.d(), tmpA.d(), tmpB.d(), Q, M, st);
-    launch_ltl_batched(tmpA.d(), GSK.d(), Q, M, st);                                 // S_new = Lambda^-1
-    launch_gemv_batched(GSK.d(), ng_th.d(), ng_mnew.d(), Q, M, M, 1, st);            // m_new = S_new theta1
-    launch_potrf_batched(GSK.d(), Q, M, dinfo.as<int>(), dscr.d(), st);              // L_new = chol(S_new)
-    HIP_TRY(hipMemcpyAsync(h_info2 + HMOGP_MAXQ, dinfo.p, sizeof(int) * Q, hipMemcpyDeviceToHost, st));
+    launch_trtri_batched(G.d(), tmpA.d(), tmpB.d(), Q, M, st);                       // R^-1
+    launch_antitranspose(tmpA.d(), GSK.d(), Q, M, st);                               // L_new[i][j] = R^-1[M-1-j][M-1-i]
+    launch_gemv_t_batched(GSK.d(), ng_th.d(), ng_t1.d(), Q, M, st);                  // L^T theta1
+    launch_gemv_batched(GSK.d(), ng_t1.d(), ng_mnew.d(), Q, M, M, 1, st);            // m_new = S_new theta1 = L (L^T theta1)
     launch_pack_tril(GSK.d(), ng_lflat.d(), Q, M, 1.0, st);
     launch_scatter_mq(ng_mnew.d(), ng_mq.d(), Q, M, st);
     HIP_TRY(hipStreamSynchronize(st));
-    // (a failed step has only written scratch -- HK, G, GSK, tmpA, tmpB -- none of which is an input of the step: the caller
+    // (a failed step has only written scratch -- G, GSK, tmpA, tmpB -- none of which is an input of the step: the caller
     //  may retry with a smaller gamma straight away, no new evaluation needed)
-    for (int q = 0; q < Q; ++q) {
+    for (int q = 0; q < Q; ++q)
       if (h_info2[q] != 0) throw EngineError{HMOGP_E_NOT_PD, "natural-gradient step leaves the positive-definite cone (reduce gamma)"};
-      if (h_info2[HMOGP_MAXQ + q] != 0) throw EngineError{HMOGP_E_NOT_PD, "natural-gradient step: new covariance not positive definite"};
-    }
     evaluated = false;  // q(u) moves on: posterior / predict / another step need a fresh evaluation
   }
   // Natural-gradient update of q(u_q) = N(m_q, S_q) from the gradients of the last evaluation (the

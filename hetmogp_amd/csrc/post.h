@@ -21,7 +21,10 @@ void launch_kzz_rows(const double* dKmm, const double* Z, int ldz, int P, const 
 void launch_qf_combine(const double* p, const double* c, long long ldn, long long N, int Q, int Df, const double* W,
                        const double* kappa, const double* var, double* m, double* v, hipStream_t s);
 // natural-gradient step of q(u)
-void launch_natgrad_prec(const double* Sqi, const double* dLdS, double gamma, double* out, int Q, int M, hipStream_t s);
+void launch_natgrad_prec(const double* Sqi, const double* dLdS, double gamma, double* out, int Q, int M, bool reversed,
+                         hipStream_t s);
+void launch_antitranspose(const double* T, double* L, int Q, int M, hipStream_t s);  // L[i][j] = T[M-1-j][M-1-i]
+void launch_gemv_t_batched(const double* A, const double* x, double* y, int Q, int M, hipStream_t s);  // y = A^T x, [Q][M]
 void launch_natgrad_theta1(const double* t1, const double* t2, const double* gm, double gamma, double* out, int Q, int M,
                            hipStream_t s);
 void launch_pack_tril(const double* T, double* out, int Q, int M, double scale, hipStream_t s);

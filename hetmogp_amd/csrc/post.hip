@@ -200,12 +200,52 @@ __global__ void qf_combine_kernel(const double* __restrict__ p, const double* __
 }
 
 // natural-gradient precision update: out = sym(Sqi - 2 gamma dLdS)            
+// rev != 0 writes J Lambda J (rows and columns reversed): its lower Cholesky factor R gives Lambda = U U^T with U = J R J
+// UPPER triangular, so that L = U^-T is the lower Cholesky factor of S = Lambda^-1 -- one factorisation instead of two
 __global__ void natgrad_prec_kernel(const double* __restrict__ Sqi, const double* __restrict__ dLdS, double gamma,
-                                    double* __restrict__ out, int M) {
+                                    double* __restrict__ out, int M, int rev) {
   const int q = blockIdx.z, i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= M) return;
   const long long b = (long long)q * M * M, ij = b + (long long)i * M + j, ji = b + (long long)j * M + i;
-  out[ij] = 0.5 * ((Sqi[ij] - 2.0 * gamma * dLdS[ij]) + (Sqi[ji] - 2.0 * gamma * dLdS[ji]));
+  const double v = 0.5 * ((Sqi[ij] - 2.0 * gamma * dLdS[ij]) + (Sqi[ji] - 2.0 * gamma * dLdS[ji]));
+  out[rev ? b + (long long)(M - 1 - i) * M + (M - 1 - j) : ij] = v;
+}
+// L[q][i][j] = T[q][M-1-j][M-1-i]  (transpose about the anti-diagonal; 32 x 32 tiles through LDS, coalesced both ways)
+__global__ __launch_bounds__(256) void antitranspose_kernel(const double* __restrict__ T, double* __restrict__ L, int M) {
+  __shared__ double tile[32][33];
+  const int q = blockIdx.z, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const double* t = T + (long long)q * M * M;
+  double* l = L + (long long)q * M * M;
+  const int sr0 = blockIdx.y * 32, sc0 = blockIdx.x * 32;  // source tile
+  for (int k = ty; k < 32; k += 8) {
+    const int r = sr0 + k, c = sc0 + tx;
+    tile[k][tx] = (r < M && c < M) ? t[(long long)r * M + c] : 0.0;
+  }
+  __syncthreads();
+  // source (r, c) lands at (M-1-c, M-1-r): destination rows run over the tile's columns, reversed
+  for (int k = ty; k < 32; k += 8) {
+    const int c = sc0 + k, r = sr0 + (31 - tx);  // consecutive tx -> consecutive destination columns M-1-r
+    if (r < M && c < M) l[(long long)(M - 1 - c) * M + (M - 1 - r)] = tile[31 - tx][k];
+  }
+}
+// y[q][j] = sum_i A[q][i][j] x[q][i]   (A^T x: 64 columns per block, a wave per 1/16 of the rows -- coalesced across the
+// wave -- and a fixed-order LDS reduction, so the result is reproducible)
+__global__ __launch_bounds__(1024) void gemv_t_kernel(const double* __restrict__ A, const double* __restrict__ x,
+                                                      double* __restrict__ y, int M) {
+  __shared__ double part[16][64];
+  const int q = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = blockIdx.x * 64 + lane;
+  const double* a = A + (long long)q * M * M;
+  const double* xv = x + (long long)q * M;
+  double s = 0.0;
+  if (j < M)
+    for (int i = w; i < M; i += 16) s += a[(long long)i * M + j] * xv[i];
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && j < M) {
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += part[k][lane];
+    y[(long long)q * M + j] = t;
+  }
 }
 // theta1[q][i] = t1[q][i] + gamma * (g_m[i*Q+q] - 2 t2[q][i])       with t1 = Sqi m, t2 = dLdS m
 __global__ void natgrad_theta1_kernel(const double* __restrict__ t1, const double* __restrict__ t2,
@@ -227,8 +267,15 @@ __global__ void scatter_mq_kernel(const double* __restrict__ v, double* __restri
 
 }  // namespace
 
-void launch_natgrad_prec(const double* Sqi, const double* dLdS, double gamma, double* out, int Q, int M, hipStream_t s) {
-  hipLaunchKernelGGL(natgrad_prec_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, Sqi, dLdS, gamma, out, M);
+void launch_natgrad_prec(const double* Sqi, const double* dLdS, double gamma, double* out, int Q, int M, bool reversed,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(natgrad_prec_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, Sqi, dLdS, gamma, out, M, reversed ? 1 : 0);
+}
+void launch_antitranspose(const double* T, double* L, int Q, int M, hipStream_t s) {
+  hipLaunchKernelGGL(antitranspose_kernel, dim3((M + 31) / 32, (M + 31) / 32, Q), dim3(256), 0, s, T, L, M);
+}
+void launch_gemv_t_batched(const double* A, const double* x, double* y, int Q, int M, hipStream_t s) {
+  hipLaunchKernelGGL(gemv_t_kernel, dim3((M + 63) / 64, Q), dim3(1024), 0, s, A, x, y, M);
 }
 void launch_natgrad_theta1(const double* t1, const double* t2, const double* gm, double gamma, double* out, int Q, int M,
                            hipStream_t s) {
