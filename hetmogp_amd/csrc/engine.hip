@@ -297,7 +297,8 @@ struct hmogp_engine {
   unsigned group_mask = HMOGP_GROUP_ALL;
   DevBuf dZ, dmu, dLflat, dvar, dell, dW, dkap, dsmall, dparams;
   double* h_small = nullptr;
-  long long n_small = 0, oZ = 0, oMu = 0, oLf = 0, n_params = 0, oJit = 0, oW0 = 0, oBs = 0;
+  long long n_small = 0, oZ = 0, oMu = 0, oLf = 0, n_params = 0, oJit = 0, oW0 = 0, oBs = 0, oSeq = 0;
+  int eval_seq = 0;            // evaluation counter of the small path (u_small_kernel's hand-over flags compare against it)
   // M x M (each Q*M*M)
   DevBuf Kuu, Luu, Kuui, L, S, KiS, KSK, C, Ctri, Sqi, tmpA, tmpB, HK, G, GSK, dKmm, dLdS;
   DevBuf a, Kr, gmu, gL, klout, rowout, dinfo, djit, dscr;
@@ -715,9 +716,9 @@ struct hmogp_engine {
     // ALL parameters live in ONE device block [ hypers + jitter | Z | m_u | L_flat ] (segments 16-byte aligned): large models fill
     // the segments by separate copies straight from the caller's arrays, small-problem mode by ONE copy from a page-locked image
     // (a host-bound small-model step pays ~4-8 us of API time and ~4 us of device time per hipMemcpyAsync)
-    // variance | lengthscale | W | kappa | jitter of the small path | chain-factor W0 (quirk Q3) | batch scales
-    oJit = 2 * Q + 2 * Q * Df, oW0 = oJit + Q, oBs = oW0 + Q * Df;
-    n_small = oBs + T;
+    // variance | lengthscale | W | kappa | jitter of the small path | chain-factor W0 (quirk Q3) | batch scales | evaluation counter
+    oJit = 2 * Q + 2 * Q * Df, oW0 = oJit + Q, oBs = oW0 + Q * Df, oSeq = oBs + T;
+    n_small = oSeq + 1;
     auto even = [](long long n) { return (n + 1) & ~1LL; };
     const long long nZ = (long long)M * Q * P, nmu = (long long)M * Q, nL = ((long long)M * (M + 1) / 2) * Q;
     oZ = even(n_small), oMu = oZ + even(nZ), oLf = oMu + even(nmu), n_params = oLf + even(nL);
@@ -764,7 +765,7 @@ struct hmogp_engine {
     drop_graphs(true);   // (the evaluation that grows the workspaces runs normally to its end: its key stays warm)
     for (DevBuf* b : {&vp, &vc, &vpt, &vct, &valpha, &vbeta, &valpha0, &vbeta0}) b->ensure(nv, true);
     colpart.ensure(sizeof(double) * std::max((rows + 255) / 256, (std::min<long long>(rows, 16384) + 31) / 32) * M * (1 + P) * Q);
-    quadpart.ensure(sizeof(double) * (rows * 64 / 256 + 1) * HMOGP_MAXSCAL);
+    quadpart.ensure(sizeof(double) * (rows * 64 / 256 + 1 + HMOGP_QUAD_MULTI) * HMOGP_MAXSCAL);
     fwdpart.ensure(sizeof(double) * 4 * FWD_PARTS * ((M + 127) / 128) * rows * Q);  // 4 statistics x FWD_PARTS wave columns per tile
     if (use_windows) {
       const size_t tiles = (rows + 127) / 128, ncb = (M + 127) / 128;
@@ -817,6 +818,8 @@ struct hmogp_engine {
       h_small[oJit + q] = rung[q] >= 0 ? h_var[q] * 1e-6 * std::pow(10.0, rung[q]) : 0.0;
     std::copy(h_W0.begin(), h_W0.end(), h_small + oW0);
     std::copy(h_bs.begin(), h_bs.end(), h_small + oBs);
+    eval_seq = eval_seq >= (1 << 30) ? 1 : eval_seq + 1;
+    h_small[oSeq] = (double)eval_seq;
     if (!enqueue) {                   // replay of a captured graph: the page-locked image is all the graph's upload node reads
       std::memcpy(h_small + oZ, p->Z, sizeof(double) * M * Q * P);
       if (!resident) {
@@ -873,9 +876,9 @@ struct hmogp_engine {
     // (the jitter of a forced rung went up with the hyper-parameter block: upload_params)
     for (int q = 0; q < Q; ++q)
       if (rung[q] == -2) rung[q] = -1;
-    HIP_TRY(hipMemsetAsync(dinfo.p, 0, sizeof(int) * 2 * HMOGP_MAXQ, st));     // info words + the hand-over flags of u_small_kernel
+    // (no memsets: u_small_kernel always writes the info words, compares its hand-over flags with the evaluation counter of the
+    //  parameter block, and zeroes the statistic bundle the row pass accumulates into)
     if (!pools.empty()) {
-      HIP_TRY(hipMemsetAsync(stats.p, 0, sizeof(double) * nstats, st));
       stage_pool_inputs(pools[0], st);
       if (!small_rows) kuf_pool(pools[0], st);      // (the fused forward kernel builds K^ itself)
       kuf_prefetched = true;
@@ -886,6 +889,8 @@ struct hmogp_engine {
     u.Z = dZ.d(), u.var = dvar.d(), u.ell = dell.d(), u.jit = dsmall.d() + oJit, u.mu = dmu.d(), u.Lflat = dLflat.d();
     u.Kuu = Kuu.d(), u.Luu = Luu.d(), u.Kuui = Kuui.d(), u.L = L.d(), u.S = S.d(), u.KiS = KiS.d(), u.KSK = KSK.d(), u.C = C.d();
     u.Ctri = Ctri.d(), u.Sqi = Sqi.d(), u.a = a.d(), u.klout = klout.d(), u.info = dinfo.as<int>(), u.flag = dinfo.as<int>() + HMOGP_MAXQ;
+    u.seq = dsmall.d() + oSeq;
+    u.zero = stats.d(), u.nzero = nstats;   // (also without rows: hmogp_step_finish reads the bundle)
     launch_u_small(u, st);
     HIP_TRY(hipMemcpyAsync(h_info, dinfo.p, sizeof(int) * Q, hipMemcpyDeviceToHost, st));
     small_info_pending = true;
@@ -1213,7 +1218,32 @@ struct hmogp_engine {
                                want_hyper ? vpt.d() + off : nullptr, want_hyper ? vct.d() + off : nullptr, st, Q, sPart, ldn);
         }
       }
-      {
+      // small models: every segment of the pool in ONE quadrature launch, its block partials summed by small_red_kernel
+      SmallQuadRed qred;
+      long long qblocks = 0;
+      for (auto& sg : pl) qblocks += quad_blocks(tasks[sg.t].lik, sg.n);
+      const bool quad_multi = small_rows && (int)pl.size() <= HMOGP_QUAD_MULTI && qblocks <= 2048;
+      if (quad_multi) {
+        Scope sc(this, CAT_QUAD, 1);
+        QuadMulti qm;
+        qm.nseg = (int)pl.size(), qm.Q = Q, qm.Df = Df, qm.ldn = ldn;
+        qm.p = vp.d(), qm.c = vc.d(), qm.pt = want_hyper ? vpt.d() : nullptr, qm.ct = want_hyper ? vct.d() : nullptr;
+        qm.Wd = dW.d(), qm.W0d = dsmall.d() + oW0, qm.kapd = dkap.d(), qm.vard = dvar.d(), qm.scale_base = dsmall.d() + oBs;
+        qm.quirks = quirks;
+        qm.alpha = valpha.d(), qm.beta = vbeta.d(), qm.alpha0 = valpha0.d(), qm.beta0 = vbeta0.d(), qm.partials = quadpart.d();
+        long long part = 0;
+        for (size_t i = 0; i < pl.size(); ++i) {
+          const Seg& sg = pl[i];
+          Task& k = tasks[sg.t];
+          QuadSeg& g = qm.seg[i];
+          g.lik = k.lik, g.dimf = k.dimf, g.d0 = k.d0, g.t = sg.t, g.lik_param = k.param, g.N = sg.n, g.off = sg.off;
+          g.y = k.Y.d() + sg.r0, g.yaux = k.Yaux.p ? k.Yaux.d() + sg.r0 : nullptr;
+          auto& r = qred.s[qred.nseg++];
+          r.part = quadpart.d() + part, r.nrows = quad_blocks(k.lik, sg.n), r.nscal = k.nscal, r.off = k.offsets.as<long long>();
+          part += r.nrows * k.nscal;
+        }
+        launch_quad_multi(qm, st);
+      } else {
         Scope sc(this, CAT_QUAD, 2 * (int)pl.size());
         for (auto& sg : pl) quad_segment(sg);
       }
@@ -1224,7 +1254,7 @@ struct hmogp_engine {
       // stand-alone time either way.)
       if (small_rows) {
         Scope sc(this, CAT_GRAM, 2);
-        launch_small_bwd(sr, st);      // H_q, r_q, dZ_q: block partials + their ordered sum into the bundle
+        launch_small_bwd(sr, st, quad_multi ? &qred : nullptr);   // H_q, r_q, dZ_q: block partials + their ordered sum into the bundle
         continue;
       }
       colstats_rows(0, n, 0);
@@ -1399,8 +1429,8 @@ struct hmogp_engine {
       f.H = Hq(0), f.Hfull = Hq(0), f.Kuui = Kuui.d(), f.KiS = KiS.d(), f.KSK = KSK.d(), f.Sqi = Sqi.d(), f.L = L.d(), f.a = a.d();
       f.G = G.d(), f.GSK = GSK.d(), f.dLdS = dLdS.d(), f.dKmm = dKmm.d(), f.Kr = Kr.d(), f.gL = gL.d(), f.gmu = gmu.d();
       if (qu_out) f.gmu2 = dstage.d() + n_all, f.gL2 = dstage.d() + n_all + n_gmu;
-      launch_finish_small(f, st);
-      if (want_hz) launch_kzz_rows(dKmm.d(), dZ.d(), Q * P, P, dvar.d(), dell.d(), Q, M, rowout.d(), st);
+      if (want_hz) f.Z = dZ.d(), f.var = dvar.d(), f.ell = dell.d(), f.P = P, f.ldz = Q * P, f.rowout = rowout.d();
+      launch_finish_small(f, st);    // (+ the K_zz-weighted row sums of dL_dKmm: kzz_rows_kernel's arithmetic)
       HIP_TRY(hipEventRecord(ev_join, st));
     } else
     {

@@ -41,6 +41,27 @@ struct QuadArgs {
   double* out_gv = nullptr;
 };
 
+// [r4] every segment (task x row range) of a pool in one launch -- small models only: the weights are read from device memory
+#define HMOGP_QUAD_MULTI 8
+struct QuadSeg {
+  int lik = 0, dimf = 1, d0 = 0, t = 0;  // likelihood id, functions, first function column, task (index of its batch scale)
+  double lik_param = 0.0;
+  long long N = 0, off = 0;              // rows, first row within the pool's row vectors
+  const double* y = nullptr;
+  const double* yaux = nullptr;
+  unsigned blk0 = 0;                     // first block of the segment        } filled by launch_quad_multi
+  long long part0 = 0;                   // its first word in `partials`      }
+};
+struct QuadMulti {
+  int nseg = 0, Q = 1, Df = 0;
+  long long ldn = 0;
+  const double *p = nullptr, *c = nullptr, *pt = nullptr, *ct = nullptr;
+  const double *Wd = nullptr, *W0d = nullptr, *kapd = nullptr, *vard = nullptr, *scale_base = nullptr;
+  unsigned quirks = 0x1fu;
+  double *alpha = nullptr, *beta = nullptr, *alpha0 = nullptr, *beta0 = nullptr, *partials = nullptr;
+  QuadSeg seg[HMOGP_QUAD_MULTI];
+};
+
 // per-latent strides of the batched (grid.z = latent) row kernels
 struct RbfBatch {
   int nq = 1;
@@ -56,6 +77,7 @@ struct ColBatch {
 
 long long quad_blocks(int lik, long long N);
 void launch_quad(const QuadArgs& a, hipStream_t s);
+void launch_quad_multi(const QuadMulti& m, hipStream_t s);   // fills blk0 / part0 of the segments; partials laid out segment by segment
 void launch_var_exp(int lik, int J, double param, long long N, const double* y, const double* m, const double* v, double* ve,
                     double* dm, double* dv, hipStream_t s, unsigned quirks = 0x1fu);
 // K[n][m] = var * exp(-r2/2); X rows have stride ldx, Z rows stride ldz (block q of the M x Q*P inducing array)

@@ -218,31 +218,44 @@ __global__ __launch_bounds__(256) void window_fix_kernel(int* __restrict__ rowwi
 }
 
 // ---- quad -----------------------------------------------------------------------------------------------
-template <int LIK, int CATD = 0>
-__global__ __launch_bounds__(256) void quad_kernel(QuadArgs a) {
-  constexpr int G = lik_lanes(LIK);
-  __shared__ double etab[4][HMOGP_ETAB];
-  __shared__ double red[4][HMOGP_MAXSCAL];
+// LDS of one quadrature block
+struct QuadShared {
+  double etab[4][HMOGP_ETAB];
+  double red[4][HMOGP_MAXSCAL];
   // mixing weights of this task's functions: from the kernel arguments, or (captured-graph replays) from device memory
-  __shared__ double s_w[HMOGP_MAXQ][HMOGP_MAXJ], s_w0[HMOGP_MAXQ][HMOGP_MAXJ], s_kap[HMOGP_MAXQ][HMOGP_MAXJ], s_var[HMOGP_MAXQ];
-  __shared__ double s_scale;
+  double w[HMOGP_MAXQ][HMOGP_MAXJ], w0[HMOGP_MAXQ][HMOGP_MAXJ], kap[HMOGP_MAXQ][HMOGP_MAXJ], var[HMOGP_MAXQ];
+  double scale;
+};
+
+// The quadrature of one block of rows (block `blk` of the segment `a` describes).  DEVONLY: the by-value weights of `a` do not
+// exist (quad_multi_kernel).
+template <int LIK, int CATD, bool DEVONLY>
+__device__ __forceinline__ void quad_body(const QuadArgs& a, unsigned blk, QuadShared& sh) {
+  constexpr int G = lik_lanes(LIK);
+  auto& etab = sh.etab;
+  auto& red = sh.red;
+  auto& s_w = sh.w;
+  auto& s_w0 = sh.w0;
+  auto& s_kap = sh.kap;
+  auto& s_var = sh.var;
+  double& s_scale = sh.scale;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   if (t < HMOGP_MAXQ * HMOGP_MAXJ) {
     const int q = t / HMOGP_MAXJ, j = t % HMOGP_MAXJ;
     const bool in = q < a.Q && j < a.dimf;
-    if (a.Wd) {
+    if (DEVONLY || a.Wd) {
       const long long o = (long long)q * a.Df + a.d0 + j;
       s_w[q][j] = in ? a.Wd[o] : 0.0, s_w0[q][j] = in ? a.W0d[o] : 0.0, s_kap[q][j] = in ? a.kapd[o] : 0.0;
       if (j == 0) s_var[q] = q < a.Q ? a.vard[q] : 0.0;
       if (t == 0) s_scale = a.scaled[0];
-    } else {
+    } else if (!DEVONLY) {
       s_w[q][j] = a.w[q][j], s_w0[q][j] = a.w0[q][j], s_kap[q][j] = a.kap[q][j];
       if (j == 0) s_var[q] = a.var[q];
       if (t == 0) s_scale = a.scale;
     }
   }
   __syncthreads();
-  const long long n = ((long long)blockIdx.x * 256 + t) / G;
+  const long long n = ((long long)blk * 256 + t) / G;
   const bool valid = n < a.N;                       // uniform per wave when G == 64
   const bool lead = valid && (G == 1 || lane == 0);  // the lane that owns the row's outputs
   const int Q = a.Q, J = a.dimf;
@@ -340,8 +353,60 @@ __global__ __launch_bounds__(256) void quad_kernel(QuadArgs a) {
   for (int j = 0; j < HMOGP_MAXJ; ++j)
     if (j < J) emit(2 + 2 * Q + j, o.gv[j]);  // sgv[j]
   __syncthreads();
-  if (t < nscal) a.partials[(long long)blockIdx.x * nscal + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+  if (t < nscal) a.partials[(long long)blk * nscal + t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
 }
+
+template <int LIK, int CATD = 0>
+__global__ __launch_bounds__(256) void quad_kernel(QuadArgs a) {
+  __shared__ QuadShared sh;
+  quad_body<LIK, CATD, false>(a, blockIdx.x, sh);
+}
+
+// All segments of a pool in ONE launch (small models: three likelihood families of ~1000 rows each are three launches of a few
+// blocks otherwise); block -> segment by the prefix of block counts, likelihood by a block-uniform switch.
+__global__ __launch_bounds__(256) void quad_multi_kernel(QuadMulti m) {
+  __shared__ QuadShared sh;
+  int s = 0;
+  while (s + 1 < m.nseg && blockIdx.x >= m.seg[s + 1].blk0) ++s;
+  const QuadSeg& g = m.seg[s];
+  QuadArgs a;
+  a.lik = g.lik, a.lik_param = g.lik_param, a.dimf = g.dimf, a.Q = m.Q, a.N = g.N;
+  a.y = g.y, a.yaux = g.yaux;
+  a.p = m.p + g.off, a.c = m.c + g.off, a.pt = m.pt ? m.pt + g.off : nullptr, a.ct = m.ct ? m.ct + g.off : nullptr;
+  a.ldn = m.ldn;
+  a.Wd = m.Wd, a.W0d = m.W0d, a.kapd = m.kapd, a.vard = m.vard, a.scaled = m.scale_base + g.t;
+  a.Df = m.Df, a.d0 = g.d0;
+  a.quirks = m.quirks;
+  a.alpha = m.alpha + g.off, a.beta = m.beta + g.off, a.alpha0 = m.alpha0 + g.off, a.beta0 = m.beta0 + g.off;
+  a.partials = m.partials + g.part0;
+  a.out_mu = a.out_v = a.out_gm = a.out_gv = nullptr;
+  const unsigned blk = blockIdx.x - g.blk0;
+#define QB(L) quad_body<L, 0, true>(a, blk, sh)
+#define QBC(D) quad_body<HMOGP_LIK_CATEGORICAL, D, true>(a, blk, sh)
+  switch (g.lik) {
+    case HMOGP_LIK_GAUSSIAN: QB(HMOGP_LIK_GAUSSIAN); break;
+    case HMOGP_LIK_BERNOULLI: QB(HMOGP_LIK_BERNOULLI); break;
+    case HMOGP_LIK_HETGAUSSIAN: QB(HMOGP_LIK_HETGAUSSIAN); break;
+    case HMOGP_LIK_POISSON: QB(HMOGP_LIK_POISSON); break;
+    case HMOGP_LIK_EXPONENTIAL: QB(HMOGP_LIK_EXPONENTIAL); break;
+    case HMOGP_LIK_GAMMA: QB(HMOGP_LIK_GAMMA); break;
+    case HMOGP_LIK_BETA: QB(HMOGP_LIK_BETA); break;
+    default:
+      switch (g.dimf) {
+        case 1: QBC(1); break;
+        case 2: QBC(2); break;
+        case 3: QBC(3); break;
+        case 4: QBC(4); break;
+        case 5: QBC(5); break;
+        case 6: QBC(6); break;
+        case 7: QBC(7); break;
+        default: QBC(8); break;
+      }
+  }
+#undef QB
+#undef QBC
+}
+
 
 // ---- colstats: thread = 2 columns, block = 512 columns x `rows` rows ----------------------------------------
 template <int P>
@@ -747,6 +812,23 @@ void launch_quad(const QuadArgs& a, hipStream_t s) {
   }
 #undef QK
 #undef QKC
+}
+
+void launch_quad_multi(const QuadMulti& m_in, hipStream_t s) {
+  QuadMulti m = m_in;
+  unsigned blocks = 0;
+  long long part = 0;
+  for (int i = 0; i < m.nseg; ++i) {
+    QuadSeg& g = m.seg[i];
+    if (g.lik == HMOGP_LIK_CATEGORICAL && (g.dimf < 1 || g.dimf > 8))
+      throw HipError{hipErrorInvalidValue, "Categorical needs 2 <= K <= 9", __FILE__, __LINE__};
+    g.blk0 = blocks, g.part0 = part;
+    const long long nb = quad_blocks(g.lik, g.N);
+    blocks += (unsigned)nb;
+    part += nb * (2 + 2 * m.Q + g.dimf + m.Q * g.dimf);
+  }
+  if (blocks == 0) return;
+  hipLaunchKernelGGL(quad_multi_kernel, dim3(blocks), dim3(256), 0, s, m);
 }
 
 void launch_var_exp(int lik, int J, double param, long long N, const double* y, const double* m, const double* v, double* ve,

@@ -16,9 +16,12 @@ struct SmallU {   // inputs / outputs of u_small_kernel (all device pointers; pe
          *Ctri = nullptr, *Sqi = nullptr;
   double* a = nullptr;             // [Q][M]
   double* klout = nullptr;         // [Q][KL_BLOCKS][5]
-  int* info = nullptr;             // [Q] LAPACK info of the factorisation (zeroed by the caller)
+  int* info = nullptr;             // [Q] LAPACK info of the factorisation (always written: 0 = fine)
   int stop_after = 0;              // diagnostics (HMOGP_USMALL_STOP): leave block (q, 0) after phase 1..3 -- timing only
-  int* flag = nullptr;             // [Q] hand-over flag of S between the two blocks of a latent (zeroed by the caller)
+  int* flag = nullptr;             // [Q] hand-over flag of S between the two blocks of a latent: set to *seq when S is in HBM
+  const double* seq = nullptr;     // evaluation counter in the parameter block (a new value per evaluation: no memset of the flags)
+  double* zero = nullptr;          // the statistic bundle, zeroed here by the blocks (q, 1) (the row pass accumulates into it) ...
+  long long nzero = 0;             // ... its length (0: leave it alone)
 };
 
 struct SmallF {   // finish_small_kernel
@@ -31,6 +34,21 @@ struct SmallF {   // finish_small_kernel
   double* gL = nullptr;            // [M(M+1)/2][Q]
   double* gmu = nullptr;           // [M][Q]
   double *gL2 = nullptr, *gmu2 = nullptr;   // optional second copies (the engine's D2H staging block: one copy for all results)
+  // gradients_X / update_gradients_full of dL_dKmm reduced against K_zz (post.hip kzz_rows_kernel, same arithmetic), by block (q, 1)
+  const double *Z = nullptr, *var = nullptr, *ell = nullptr;
+  int P = 1, ldz = 0;
+  double* rowout = nullptr;        // [Q][M][2 + P] (nullptr: not wanted)
+};
+
+// the quadrature's block partials of every segment of the pool, summed into the bundle by small_red_kernel's extra plane
+struct SmallQuadRed {
+  int nseg = 0;
+  struct {
+    const double* part = nullptr;  // [nrows][nscal]
+    long long nrows = 0;
+    int nscal = 0;
+    const long long* off = nullptr;   // [nscal] slot -> bundle offset (distinct within a segment)
+  } s[8];
 };
 
 struct SmallRows {   // small_fwd_kernel / small_bwd_kernel / small_red_kernel: the row pass of one pool of n rows, 64 rows per block
@@ -50,7 +68,8 @@ struct SmallRows {   // small_fwd_kernel / small_bwd_kernel / small_red_kernel: 
 };
 size_t small_rows_lds_bytes();
 void launch_small_fwd(const SmallRows& r, hipStream_t s);
-void launch_small_bwd(const SmallRows& r, hipStream_t s);    // block partials + their deterministic sum into the bundle
+// block partials + their deterministic sum into the bundle (+ the quadrature's partials, when given)
+void launch_small_bwd(const SmallRows& r, hipStream_t s, const SmallQuadRed* qr = nullptr);
 
 size_t small_lds_bytes();
 void launch_u_small(const SmallU& u, hipStream_t s);

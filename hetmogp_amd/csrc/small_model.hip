@@ -59,17 +59,42 @@ __device__ __forceinline__ void sm_gemm(const double* __restrict__ A, const doub
       if (r0 + i < M && c0 + j < M) C[(r0 + i) * SLD + c0 + j] = acc[i][j];
 }
 
-__device__ __forceinline__ void sm_load(double* __restrict__ X, const double* __restrict__ g, int M, long long ldg) {
-  for (int e = threadIdx.x; e < M * M; e += NT) {
-    const int i = e / M, j = e - i * M;
-    X[i * SLD + j] = g[(long long)i * ldg + j];
+// Element loops over an M x M matrix: a lane per column, NT / 64 rows per step, SM_IT steps (fixed count: fully unrolled, no
+// integer divisions).  Global loads go through sm_fill, which issues all of a thread's loads before the first LDS store -- one
+// memory latency per matrix instead of one per element (a runtime-count loop is not software-pipelined by the compiler).
+constexpr int SM_RS = NT / 64, SM_IT = SM / SM_RS;
+__device__ __forceinline__ bool sm_ij(int it, int M, int& i, int& j) {
+  j = threadIdx.x & 63;
+  i = (threadIdx.x >> 6) + SM_RS * it;
+  return i < M && j < M;
+}
+template <class LD>
+__device__ __forceinline__ void sm_fill(double* __restrict__ X, int M, LD&& ld) {
+  double v[SM_IT];
+#pragma unroll
+  for (int it = 0; it < SM_IT; ++it) {
+    int i, j;
+    v[it] = sm_ij(it, M, i, j) ? ld(i, j) : 0.0;
+  }
+#pragma unroll
+  for (int it = 0; it < SM_IT; ++it) {
+    int i, j;
+    if (sm_ij(it, M, i, j)) X[i * SLD + j] = v[it];
   }
 }
-__device__ __forceinline__ void sm_store(const double* __restrict__ X, double* __restrict__ g, int M) {
-  for (int e = threadIdx.x; e < M * M; e += NT) {
-    const int i = e / M, j = e - i * M;
-    g[(long long)i * M + j] = X[i * SLD + j];
+template <class F>
+__device__ __forceinline__ void sm_each(int M, F&& f) {
+#pragma unroll
+  for (int it = 0; it < SM_IT; ++it) {
+    int i, j;
+    if (sm_ij(it, M, i, j)) f(i, j);
   }
+}
+__device__ __forceinline__ void sm_load(double* __restrict__ X, const double* __restrict__ g, int M, long long ldg) {
+  sm_fill(X, M, [&](int i, int j) { return g[(long long)i * ldg + j]; });
+}
+__device__ __forceinline__ void sm_store(const double* __restrict__ X, double* __restrict__ g, int M) {
+  sm_each(M, [&](int i, int j) { g[(long long)i * M + j] = X[i * SLD + j]; });
 }
 
 // Lower Cholesky of X (in place, lower triangle; the strict upper triangle is left as it was), by ONE wave, left-looking, one
@@ -184,21 +209,19 @@ __global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
   const long long MM = (long long)M * M, off = (long long)q * MM;
   double* o = u.klout + (long long)q * KL_BLOCKS * 5;
 
+  const int seq = (int)u.seq[0];
   if (role == 1) {
     // ---- q(u) chain: L = flat_to_triang(L_flat) (svmogp_inf.py:193), S = L L^T (:194-195), S^-1 = dpotri(L) (:124) ------------
-    for (int e = t; e < M * M; e += NT) {
-      const int r = e / M, c = e - r * M;
-      const double v = (c <= r) ? u.Lflat[((long long)r * (r + 1) / 2 + c) * Q + q] : 0.0;
-      X2[r * SLD + c] = v;
-      u.L[off + e] = v;
-    }
+    for (long long e = (long long)q * NT + t; e < u.nzero; e += (long long)Q * NT) u.zero[e] = 0.0;   // (the bundle: see SmallU)
+    sm_fill(X2, M, [&](int r, int c) { return (c <= r) ? u.Lflat[((long long)r * (r + 1) / 2 + c) * Q + q] : 0.0; });
     __syncthreads();
+    sm_store(X2, u.L + off, M);
     sm_gemm<false, true>(X2, X2, X0, M, 2);                // S = L L^T  -> X0
     __syncthreads();
     sm_store(X0, u.S + off, M);
     __threadfence();                                       // S is in HBM (agent scope) ...
     __syncthreads();
-    if (t == 0) __hip_atomic_store(&u.flag[q], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... before block (q, 0) may read it
+    if (t == 0) __hip_atomic_store(&u.flag[q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... before block (q, 0) may read it
     double l2 = 0.0, ninf = 0.0;
     if (t < M) l2 = log(fabs(X2[t * SLD + t]));
     if (w == 0) sm_trtri_wave(X2, X3, M, lane);            // L^-1 -> X3 (one wave)
@@ -206,7 +229,7 @@ __global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
     sm_gemm<true, false>(X3, X3, X1, M, 1);                // S^-1 = L^-T L^-1  -> X1
     __syncthreads();
     sm_store(X1, u.Sqi + off, M);
-    for (int e = t; e < M * M; e += NT) ninf += isinf(X1[(e / M) * SLD + (e % M)]) ? 1.0 : 0.0;
+    sm_each(M, [&](int i, int j) { ninf += isinf(X1[i * SLD + j]) ? 1.0 : 0.0; });
     l2 = block_sum(l2, red);
     ninf = block_sum(ninf, red);
     if (t == 0) o[5 + 0] = 0.0, o[5 + 1] = 0.0, o[5 + 2] = 0.0, o[5 + 3] = l2, o[5 + 4] = ninf;   // KL partial "block 1"
@@ -216,17 +239,21 @@ __global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
   // ---- K_uu chain ------------------------------------------------------------------------------------------------------------
   const double var = u.var[q], ell = u.ell[q], jit = u.jit[q];
   // K_uu = k_q(Z_q, Z_q), both arguments passed (util.py:197): GPy's rounding order, no forced diagonal
-  for (int e = t; e < M * M; e += NT) {
-    const int i = e / M, j = e - i * M;
-    double zi[P], zj[P];
+  {
+    double* zs = X3;                                     // (free until the joint part) inducing inputs of the latent: [M][P]
+    for (int e = t; e < M * P; e += NT) zs[e] = u.Z[(long long)(e / P) * u.ldz + q * P + (e % P)];
+    if (t < M) vec[SM + t] = u.mu[(long long)t * Q + q];
+    __syncthreads();
+    sm_each(M, [&](int i, int j) {
+      double zi[P], zj[P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) zi[p] = u.Z[(long long)i * u.ldz + q * P + p], zj[p] = u.Z[(long long)j * u.ldz + q * P + p];
-    const double r2 = rbf_r2<P>(zi, sumsq<P>(zi), zj, sumsq<P>(zj), ell);
-    const double k = var * exp(-0.5 * r2);
-    u.Kuu[off + e] = k;
-    X0[i * SLD + j] = k + ((i == j) ? jit : 0.0);     // the factorised copy carries the jitter (GPy jitchol)
+      for (int p = 0; p < P; ++p) zi[p] = zs[i * P + p], zj[p] = zs[j * P + p];
+      const double r2 = rbf_r2<P>(zi, sumsq<P>(zi), zj, sumsq<P>(zj), ell);
+      const double k = var * exp(-0.5 * r2);
+      u.Kuu[off + (long long)i * M + j] = k;
+      X0[i * SLD + j] = k + ((i == j) ? jit : 0.0);     // the factorised copy carries the jitter (GPy jitchol)
+    });
   }
-  if (t < M) vec[SM + t] = u.mu[(long long)t * Q + q];
   if (t == 0) s_info = 0, s_progress = 0;
   for (int e = t; e < KL_BLOCKS * 5; e += NT)          // KL partials: blocks 0 and 1 are written below / by block (q, 1)
     if (e >= 10) o[e] = 0.0;
@@ -239,15 +266,11 @@ __global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
     sm_trtri_follow(X0, vec, X1, M, lane, &s_progress);
   }
   __syncthreads();
+  if (t == 0) u.info[q] = s_info;                        // (non-zero: the engine falls back to the regular path and its ladder)
   if (u.stop_after == 2) return;
-  if (s_info) {                                          // (the engine falls back to the regular path and its ladder)
-    if (t == 0) u.info[q] = s_info;
-    return;
-  }
-  for (int e = t; e < M * M; e += NT) {                  // L_uu with an explicit zero upper triangle (potrf_finalize)
-    const int i = e / M, j = e - i * M;
-    u.Luu[off + e] = (j <= i) ? X0[i * SLD + j] : 0.0;
-  }
+  if (s_info) return;
+  // L_uu with an explicit zero upper triangle (potrf_finalize)
+  sm_each(M, [&](int i, int j) { u.Luu[off + (long long)i * M + j] = (j <= i) ? X0[i * SLD + j] : 0.0; });
   double l1 = 0.0;
   if (t < M) l1 = log(fabs(X0[t * SLD + t]));
   __syncthreads();
@@ -264,35 +287,73 @@ __global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
   if (u.stop_after == 3) return;
   // ---- joint part: needs S of block (q, 1) ---------------------------------------------------------------------------------
   if (t == 0)
-    while (__hip_atomic_load(&u.flag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+    while (__hip_atomic_load(&u.flag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) __builtin_amdgcn_s_sleep(2);
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   sm_load(X3, u.S + off, M, M);
   __syncthreads();
-  for (int e = t; e < M * M; e += NT) {
-    const int i = e / M, j = e - i * M;
-    tr += X0[i * SLD + j] * X3[i * SLD + j];
-  }
+  sm_each(M, [&](int i, int j) { tr += X0[i * SLD + j] * X3[i * SLD + j]; });
   sm_gemm<false, false>(X0, X3, X1, M);                  // K^-1 S                                                         -> X1
   __syncthreads();
   sm_store(X1, u.KiS + off, M);
   sm_gemm<false, false>(X1, X0, X2, M);                  // K^-1 S K^-1                                                    -> X2
   __syncthreads();
   sm_store(X2, u.KSK + off, M);
-  for (int e = t; e < M * M; e += NT) {                  // C = K^-1 S K^-1 - K^-1 ; T = tril(C) + tril(C^T, -1)
-    const int i = e / M, j = e - i * M;
+  sm_each(M, [&](int i, int j) {                         // C = K^-1 S K^-1 - K^-1 ; T = tril(C) + tril(C^T, -1)
     const double cij = X2[i * SLD + j] - X0[i * SLD + j];
-    u.C[off + e] = cij;
+    u.C[off + (long long)i * M + j] = cij;
     double tv = 0.0;
     if (j == i) tv = cij;
     else if (j < i) tv = cij + (X2[j * SLD + i] - X0[j * SLD + i]);
-    u.Ctri[off + e] = tv;
-  }
+    u.Ctri[off + (long long)i * M + j] = tv;
+  });
   // KL partials (svmogp_inf.py:245-249), kl_terms_kernel's layout: "block 0" of the latent
   tr = block_sum(tr, red);
   ma = block_sum(ma, red);
   l1 = block_sum(l1, red);
   if (t == 0) o[0] = tr, o[1] = ma, o[2] = l1, o[3] = 0.0, o[4] = 0.0;
+}
+
+// rowout[q][m] = { sum_j EK_mj, sum_j EK_mj r2_mj, sum_j (EK_mj + EK_jm)(z_j - z_m)[p] }, EK = dKmm .* K_zz: kzz_rows_kernel's
+// arithmetic (one wave per row, lanes stride over j, wave_sum), dKmm read from LDS
+template <int P>
+__device__ __forceinline__ void sm_kzz_rows(const SmallF& f, const double* __restrict__ D, int q) {
+  const int M = f.M, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const double* Zq = f.Z + (long long)q * P;
+  const double v = f.var[q], l = f.ell[q];
+  for (int m = w; m < M; m += NT / 64) {
+    double zm[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) zm[p] = Zq[(long long)m * f.ldz + p];
+    const double zmsq = sumsq<P>(zm);
+    double s1 = 0.0, s2 = 0.0, gz[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) gz[p] = 0.0;
+    for (int j = lane; j < M; j += 64) {
+      double zj[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) zj[p] = Zq[(long long)j * f.ldz + p];
+      double r2 = rbf_r2<P>(zm, zmsq, zj, sumsq<P>(zj), l);
+      if (j == m) r2 = 0.0;
+      const double kz = v * exp(-0.5 * r2);
+      const double ek = D[m * SLD + j] * kz, ekt = D[j * SLD + m] * kz;
+      s1 += ek;
+      s2 += ek * r2;
+#pragma unroll
+      for (int p = 0; p < P; ++p) gz[p] += (ek + ekt) * (zj[p] - zm[p]);
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+#pragma unroll
+    for (int p = 0; p < P; ++p) gz[p] = wave_sum(gz[p]);
+    if (lane == 0) {
+      double* o = f.rowout + ((long long)q * M + m) * (2 + P);
+      o[0] = s1;
+      o[1] = s2;
+#pragma unroll
+      for (int p = 0; p < P; ++p) o[2 + p] = gz[p];
+    }
+  }
 }
 
 __global__ __launch_bounds__(NT) void finish_small_kernel(SmallF f) {
@@ -310,18 +371,15 @@ __global__ __launch_bounds__(NT) void finish_small_kernel(SmallF f) {
   const double* Hq = f.H + (long long)q * f.per_q;
   if (role == 1 && !f.want_hz) return;
   // H_q arrives as its lower triangle (row pass / exchange step): mirrored here
-  for (int e = t; e < M * M; e += NT) {
-    const int i = e / M, j = e - i * M;
-    X0[i * SLD + j] = (j <= i) ? Hq[(long long)i * M + j] : Hq[(long long)j * M + i];
-  }
+  sm_fill(X0, M, [&](int i, int j) { return (j <= i) ? Hq[(long long)i * M + j] : Hq[(long long)j * M + i]; });
   sm_load(X1, f.Kuui + off, M, M);
   if (t < M) vec[t] = Hq[f.oR + t], vec[2 * SM + t] = f.a[(long long)q * M + t];
   __syncthreads();
   if (role == 0) {
-    for (int e = t; e < M * M; e += NT) {               // (the bundle itself keeps the full symmetric H_q, like launch_mirror_lower)
-      const int i = e / M, j = e - i * M;
+    // (the bundle itself keeps the full symmetric H_q, like launch_mirror_lower)
+    sm_each(M, [&](int i, int j) {
       if (j > i) f.Hfull[(long long)q * f.per_q + (long long)i * M + j] = X0[i * SLD + j];
-    }
+    });
   }
   sm_gemm<false, false>(X0, X1, X2, M);                  // H K^-1                                                X2
   if (t < M) {                                           // K^-1 r  (dVE_dmu, svmogp_inf.py:144)
@@ -338,34 +396,31 @@ __global__ __launch_bounds__(NT) void finish_small_kernel(SmallF f) {
   sm_gemm<false, false>(X1, X2, X3, M);                  // G = K^-1 (H K^-1)  (dVE_dS, svmogp_inf.py:148)          X3
   __syncthreads();
   // The regular path forms the lower tiles of G = K^-1 H K^-1 and mirrors them: exactly symmetric.  Same here.
-  for (int e = t; e < M * M; e += NT) {
-    const int i = e / M, j = e - i * M;
+  sm_each(M, [&](int i, int j) {
     if (j > i) X3[i * SLD + j] = X3[j * SLD + i];
-  }
+  });
   __syncthreads();
   if (role == 0) sm_store(X3, f.G + off, M);
   if (role == 0 && f.want_qu) {
     sm_load(X0, f.Sqi + off, M, M);                      // (H is no longer needed)
     __syncthreads();
-    for (int e = t; e < M * M; e += NT) {                // dL/dS = G - (K^-1 - S^-1) / 2   (svmogp_inf.py:131,169)
-      const int i = e / M, j = e - i * M;
+    sm_each(M, [&](int i, int j) {                       // dL/dS = G - (K^-1 - S^-1) / 2   (svmogp_inf.py:131,169)
       const double v = X3[i * SLD + j] - 0.5 * (X1[i * SLD + j] - X0[i * SLD + j]);
       X2[i * SLD + j] = v;
-      f.dLdS[off + e] = v;
-    }
+      f.dLdS[off + (long long)i * M + j] = v;
+    });
     __syncthreads();
     sm_load(X0, f.L + off, M, M);
     __syncthreads();
     sm_gemm<false, false>(X2, X0, X1, M);                // dL/dS L (:175-177)  [X1: K^-1 is re-read from HBM below]
     __syncthreads();
-    for (int e = t; e < M * M; e += NT) {                // GPy triang_to_flat of 2 dL/dS L
-      const int r = e / M, c = e - r * M;
+    sm_each(M, [&](int r, int c) {                       // GPy triang_to_flat of 2 dL/dS L
       if (c <= r) {
         const long long o = ((long long)r * (r + 1) / 2 + c) * Q + q;
         f.gL[o] = 2.0 * X1[r * SLD + c];
         if (f.gL2) f.gL2[o] = 2.0 * X1[r * SLD + c];
       }
-    }
+    });
     __syncthreads();
   }
   if (role == 1) {
@@ -375,14 +430,25 @@ __global__ __launch_bounds__(NT) void finish_small_kernel(SmallF f) {
     __syncthreads();
     sm_store(X2, f.GSK + off, M);
     // dL_dKmm (svmogp_inf.py:130-133,151-154,166,170): dkmm_kernel's formula
-    for (int e = t; e < M * M; e += NT) {
-      const int i = e / M, j = e - i * M;
+    sm_load(X0, f.KSK + off, M, M);                      // (K^-1 S is no longer needed; K^-1 is still in X1)
+    __syncthreads();
+    sm_each(M, [&](int i, int j) {
       const double kri = vec[SM + i], krj = vec[SM + j], ai = vec[2 * SM + i], aj = vec[2 * SM + j];
       const double xij = X3[i * SLD + j] - X2[i * SLD + j] - X2[j * SLD + i] - kri * aj;
       const double xji = X3[j * SLD + i] - X2[j * SLD + i] - X2[i * SLD + j] - krj * ai;
       const double dve = 0.5 * (xij + xji);
-      const double dkl = 0.5 * f.Kuui[off + e] - 0.5 * f.KSK[off + e] - 0.5 * (ai * aj);
-      f.dKmm[off + e] = dve - dkl;
+      const double dkl = 0.5 * X1[i * SLD + j] - 0.5 * X0[i * SLD + j] - 0.5 * (ai * aj);
+      f.dKmm[off + (long long)i * M + j] = dve - dkl;
+      X0[i * SLD + j] = dve - dkl;
+    });
+    if (f.rowout) {
+      __syncthreads();
+      switch (f.P) {
+        case 1: sm_kzz_rows<1>(f, X0, q); break;
+        case 2: sm_kzz_rows<2>(f, X0, q); break;
+        case 3: sm_kzz_rows<3>(f, X0, q); break;
+        default: sm_kzz_rows<4>(f, X0, q); break;
+      }
     }
   }
 }
@@ -414,24 +480,27 @@ __global__ __launch_bounds__(NT) void small_fwd_kernel(SmallRows a) {
     const int q = blockIdx.y;
     const double var = a.var[q], ell = a.ell[q], il2 = 1.0 / (ell * ell), inv_l = 1.0 / ell;
     const double* Cq = a.C + (long long)q * M * M;
-    for (int e = t; e < M * M; e += NT) Cs[(e / M) * SLD + (e % M)] = Cq[e];
+    sm_load(Cs, Cq, M, M);
     if (t < M) av[t] = a.a[(long long)q * M + t];
     for (int e = t; e < M * P; e += NT) zs[e] = a.Z[(long long)(e / P) * a.ldz + q * P + (e % P)];
     for (int e = t; e < RB * P; e += NT) xs[e] = (e / P < nr) ? a.X[(n0 + e / P) * P + (e % P)] : 0.0;
     __syncthreads();
     double* Khq = a.Kh + (long long)q * a.ldn * M;
-    for (int e = t; e < RB * M; e += NT) {      // K^ tile: rbf_kernel<P, false>'s arithmetic (clip(r2) / l^2, no sqrt / divide)
-      const int r = e / M, m = e - r * M;
-      double k = 0.0;
-      if (r < nr) {
-        double xv[P], zv[P];
 #pragma unroll
-        for (int p = 0; p < P; ++p) xv[p] = xs[r * P + p], zv[p] = zs[m * P + p];
-        const double r2 = rbf_r2_fast<P>(xv, sumsq<P>(xv), zv, sumsq<P>(zv), il2);
-        k = var * exp(-0.5 * r2);
-        Khq[(n0 + r) * M + m] = k;
+    for (int it = 0; it < SM_IT; ++it) {        // K^ tile: rbf_kernel<P, false>'s arithmetic (clip(r2) / l^2, no sqrt / divide)
+      const int m = t & 63, r = (t >> 6) + SM_RS * it;
+      if (m < M) {
+        double k = 0.0;
+        if (r < nr) {
+          double xv[P], zv[P];
+#pragma unroll
+          for (int p = 0; p < P; ++p) xv[p] = xs[r * P + p], zv[p] = zs[m * P + p];
+          const double r2 = rbf_r2_fast<P>(xv, sumsq<P>(xv), zv, sumsq<P>(zv), il2);
+          k = var * exp(-0.5 * r2);
+          Khq[(n0 + r) * M + m] = k;
+        }
+        Kt[r * SLD + m] = k;
       }
-      Kt[r * SLD + m] = k;
     }
     __syncthreads();
     // P~ micro-tile: rows r0..r0+3 of the block, columns c0..c0+3
@@ -524,10 +593,23 @@ __global__ __launch_bounds__(NT) void small_bwd_kernel(SmallRows a) {
     const int q = blockIdx.y;
     const double* Khq = a.Kh + (long long)q * a.ldn * M;
     const double* Ptq = a.Pt + (long long)q * a.ldn * M;
-    for (int e = t; e < RB * M; e += NT) {
-      const int r = e / M, m = e - r * M;
-      Kt[r * SLD + m] = (r < nr) ? Khq[(n0 + r) * M + m] : 0.0;
-      if (a.want_z) Pl[r * SLD + m] = (r < nr) ? Ptq[(n0 + r) * M + m] : 0.0;
+    {                                       // K^ (and P~) rows of the block: all loads of a thread in flight at once
+      double kv[SM_IT], pv[SM_IT];
+#pragma unroll
+      for (int it = 0; it < SM_IT; ++it) {
+        const int m = t & 63, r = (t >> 6) + SM_RS * it;
+        const bool in = m < M && r < nr;
+        kv[it] = in ? Khq[(n0 + r) * M + m] : 0.0;
+        pv[it] = (in && a.want_z) ? Ptq[(n0 + r) * M + m] : 0.0;
+      }
+#pragma unroll
+      for (int it = 0; it < SM_IT; ++it) {
+        const int m = t & 63, r = (t >> 6) + SM_RS * it;
+        if (m < M) {
+          Kt[r * SLD + m] = kv[it];
+          if (a.want_z) Pl[r * SLD + m] = pv[it];
+        }
+      }
     }
     if (t < M) av[t] = a.a[(long long)q * M + t];
     for (int e = t; e < M * P; e += NT) zs[e] = a.Z[(long long)(e / P) * a.ldz + q * P + (e % P)];
@@ -590,7 +672,24 @@ __global__ __launch_bounds__(NT) void small_bwd_kernel(SmallRows a) {
 }
 
 // bundle += sum over the blocks' partials, block by block in order (deterministic); one thread per output element
-__global__ __launch_bounds__(NT) void small_red_kernel(SmallRows a, int nblk) {
+__global__ __launch_bounds__(NT) void small_red_kernel(SmallRows a, int nblk, SmallQuadRed qr) {
+  if (blockIdx.y == a.Q) {
+    // the quadrature's scalars: one wave per (segment, slot), lanes stride over the segment's blocks, fixed-order wave sum; the
+    // segments one after the other (two tasks may add to the same slot of the bundle)
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int sg = 0; sg < qr.nseg; ++sg) {
+      const auto& g = qr.s[sg];
+      for (int k = w; k < g.nscal; k += NT / 64) {
+        double s = 0.0;
+        for (long long b = lane; b < g.nrows; b += 64) s += g.part[b * g.nscal + k];
+        s = wave_sum(s);
+        if (lane == 0) a.stats[g.off[k]] += s;
+      }
+      __syncthreads();
+    }
+    return;
+  }
   const int q = blockIdx.y, M = a.M, P = a.P;
   const long long slab_q = (long long)M * M + M + (long long)M * P;
   const long long e = (long long)blockIdx.x * NT + threadIdx.x;
@@ -668,11 +767,13 @@ void launch_small_fwd(const SmallRows& r, hipStream_t s) {
   DISPATCH_P(r.P, hipLaunchKernelGGL((small_fwd_kernel<PP>), dim3(nblk, r.Q), dim3(NT), small_rows_lds_bytes(), s, r));
 }
 
-void launch_small_bwd(const SmallRows& r, hipStream_t s) {
+void launch_small_bwd(const SmallRows& r, hipStream_t s, const SmallQuadRed* qr) {
   if (r.n <= 0) return;
   small_rows_attr();
   const unsigned nblk = (unsigned)((r.n + 63) / 64);
   DISPATCH_P(r.P, hipLaunchKernelGGL((small_bwd_kernel<PP>), dim3(nblk, r.Q), dim3(NT), small_rows_lds_bytes(), s, r));
   const long long slab_q = (long long)r.M * r.M + r.M + (long long)r.M * r.P;
-  hipLaunchKernelGGL(small_red_kernel, dim3((unsigned)((slab_q + NT - 1) / NT), r.Q), dim3(NT), 0, s, r, (int)nblk);
+  SmallQuadRed none;
+  hipLaunchKernelGGL(small_red_kernel, dim3((unsigned)((slab_q + NT - 1) / NT), r.Q + (qr && qr->nseg ? 1 : 0)), dim3(NT), 0, s, r,
+                     (int)nblk, qr ? *qr : none);
 }
