@@ -337,7 +337,8 @@ struct hmogp_engine {
   // ... and with M <= HMOGP_SMALL_M the replicated M x M algebra runs as TWO fused kernels, one block per latent with every matrix
   // in LDS (small_model.hip), instead of ~30 launches.  A factorisation that needs GPy's jitter ladder is repeated on the regular
   // path (small_veto), which owns the ladder.
-  bool small_path = false, small_veto = false, small_info_pending = false;
+  bool small_path = false, small_veto = false, small_info_pending = false, info_early = false;
+  double* hstage_dev = nullptr;   // hstage as the device addresses it (finish_small_kernel writes the results there itself)
   bool small_rows = false;     // ... and its row pass as the two fused kernels of small_model.hip (small_fwd / small_bwd)
   DevBuf smallslab;
   struct RetryRegular {};
@@ -733,7 +734,7 @@ struct hmogp_engine {
     gL.ensure(sizeof(double) * ((long long)M * (M + 1) / 2) * Q);
     klout.ensure(sizeof(double) * Q * KL_BLOCKS * 5);
     rowout.ensure(sizeof(double) * Q * M * (2 + P));
-    dinfo.ensure(sizeof(int) * 2 * HMOGP_MAXQ), djit.ensure(sizeof(double) * Q), dscr.ensure(sizeof(double) * Q * M * M);
+    dinfo.ensure(sizeof(int) * (2 * HMOGP_MAXQ + 2), true), djit.ensure(sizeof(double) * Q), dscr.ensure(sizeof(double) * Q * M * M);
     rung.assign(Q, -1);
   }
 
@@ -892,7 +893,9 @@ struct hmogp_engine {
     u.seq = dsmall.d() + oSeq;
     u.zero = stats.d(), u.nzero = nstats;   // (also without rows: hmogp_step_finish reads the bundle)
     launch_u_small(u, st);
-    HIP_TRY(hipMemcpyAsync(h_info, dinfo.p, sizeof(int) * Q, hipMemcpyDeviceToHost, st));
+    // (the info words reach the host with the results of hmogp_step_finish -- its last block gathers them -- unless the caller
+    //  needs them behind hmogp_step_begin already)
+    if (info_early) HIP_TRY(hipMemcpyAsync(h_info, dinfo.p, sizeof(int) * Q, hipMemcpyDeviceToHost, st));
     small_info_pending = true;
     HIP_TRY(hipEventRecord(ev_join, st));    // (what hmogp_step_finish orders itself behind on the regular path)
   }
@@ -1344,6 +1347,7 @@ struct hmogp_engine {
     pool_used = 0;
     for (int c = 0; c < NCAT; ++c) ms[c] = 0.0, launches[c] = 0;
     decide_mode(p);
+    info_early = sync || will_exchange;
     upload_params(p);
     HIP_TRY(hipEventRecord(ev_begin0, st));
     plan_pools();
@@ -1375,7 +1379,7 @@ struct hmogp_engine {
     small_info_pending = false;
     bool failed = false;
     for (int q = 0; q < Q; ++q)
-      if (h_info[q] != 0) {
+      if ((info_early ? h_info[q] : (int)hstage[fl.n_stage + q]) != 0) {
         if (rung_request[q] != -2) throw EngineError{HMOGP_E_NOT_PD, "Cholesky failed at the forced jitter rung"};
         failed = true;
       }
@@ -1399,11 +1403,13 @@ struct hmogp_engine {
     fl.n_gmu = fl.qu_out ? (size_t)M * Q : 0, fl.n_gl = fl.qu_out ? (size_t)Mtri * Q : 0;
     fl.n_stage = fl.n_all + fl.n_gmu + fl.n_gl;
     dstage.ensure(sizeof(double) * fl.n_stage);
-    if (hstage_cap < fl.n_stage) {
+    if (hstage_cap < fl.n_stage + HMOGP_MAXQ) {      // (+ the info words of the small path)
       if (hstage) (void)hipHostFree(hstage);
-      hstage = nullptr, hstage_cap = 0;
-      HIP_TRY(hipHostMalloc((void**)&hstage, sizeof(double) * fl.n_stage, hipHostMallocDefault));
-      hstage_cap = fl.n_stage;
+      hstage = nullptr, hstage_cap = 0, hstage_dev = nullptr;
+      drop_graphs(true);                             // (captured kernels hold the old block's address)
+      HIP_TRY(hipHostMalloc((void**)&hstage, sizeof(double) * (fl.n_stage + HMOGP_MAXQ), hipHostMallocDefault));
+      HIP_TRY(hipHostGetDevicePointer((void**)&hstage_dev, hstage, 0));
+      hstage_cap = fl.n_stage + HMOGP_MAXQ;
     }
   }
   void finish(hmogp_outputs* out) {
@@ -1430,6 +1436,10 @@ struct hmogp_engine {
       f.G = G.d(), f.GSK = GSK.d(), f.dLdS = dLdS.d(), f.dKmm = dKmm.d(), f.Kr = Kr.d(), f.gL = gL.d(), f.gmu = gmu.d();
       if (qu_out) f.gmu2 = dstage.d() + n_all, f.gL2 = dstage.d() + n_all + n_gmu;
       if (want_hz) f.Z = dZ.d(), f.var = dvar.d(), f.ell = dell.d(), f.P = P, f.ldz = Q * P, f.rowout = rowout.d();
+      // the last block to finish writes every small result straight into the page-locked host block
+      f.stage = hstage_dev, f.g_stats = stats.d(), f.g_kl = klout.d(), f.g_extra = dstage.d() + n_all, f.g_info = dinfo.as<int>();
+      f.n_hg = (long long)n_hg, f.n_kl = (long long)n_kl, f.n_tail = per_q - oDZ, f.oDZ = oDZ, f.n_row = (long long)n_row;
+      f.n_extra = (long long)(n_stage - n_all), f.NG = NG, f.counter = dinfo.as<int>() + 2 * HMOGP_MAXQ;
       launch_finish_small(f, st);    // (+ the K_zz-weighted row sums of dL_dKmm: kzz_rows_kernel's arithmetic)
       HIP_TRY(hipEventRecord(ev_join, st));
     } else
@@ -1478,7 +1488,7 @@ struct hmogp_engine {
     // ---- device -> host ------------------------------------------------------------------------------
     // the small results (head of the bundle, KL partials, per-latent tails, K_uu-side rows) are gathered device-side and
     // leave in ONE copy into a page-locked buffer: ten separate pageable copies cost 0.3 ms of gaps
-    {
+    if (!small_path) {
       double* d = dstage.d();
       launch_gather_small(stats.d(), (long long)n_hg, klout.d(), (long long)n_kl, per_q, oDZ, per_q - oDZ, Q, rowout.d(),
                           (long long)n_row, d, st);

@@ -38,6 +38,14 @@ struct SmallF {   // finish_small_kernel
   const double *Z = nullptr, *var = nullptr, *ell = nullptr;
   int P = 1, ldz = 0;
   double* rowout = nullptr;        // [Q][M][2 + P] (nullptr: not wanted)
+  // The results of the evaluation, gathered by the LAST block of the grid to finish straight into the caller's page-locked host
+  // block (no gather launch, no copy node):  [ head of the bundle (n_hg) | KL partials (n_kl) | per-latent tails (Q x n_tail, from
+  // bundle + n_hg' + q per_q + oDZ) | rowout (n_row) | extra (n_extra: the q(u) gradients of gmu2 / gL2) | info (Q, as doubles) ]
+  double* stage = nullptr;         // device-visible address of the host block (nullptr: no gather)
+  const double *g_stats = nullptr, *g_kl = nullptr, *g_extra = nullptr;
+  const int* g_info = nullptr;
+  long long n_hg = 0, n_kl = 0, n_tail = 0, oDZ = 0, n_row = 0, n_extra = 0, NG = 0;
+  int* counter = nullptr;          // blocks finished so far (zero between launches: the last block resets it)
 };
 
 // the quadrature's block partials of every segment of the pool, summed into the bundle by small_red_kernel's extra plane

@@ -356,8 +356,7 @@ __device__ __forceinline__ void sm_kzz_rows(const SmallF& f, const double* __res
   }
 }
 
-__global__ __launch_bounds__(NT) void finish_small_kernel(SmallF f) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+__device__ __forceinline__ void finish_small_body(const SmallF& f, double* lds) {
   double* X0 = lds;
   double* X1 = X0 + SM * SLD;
   double* X2 = X1 + SM * SLD;
@@ -451,6 +450,36 @@ __global__ __launch_bounds__(NT) void finish_small_kernel(SmallF f) {
       }
     }
   }
+}
+
+__global__ __launch_bounds__(NT) void finish_small_kernel(SmallF f) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ int s_last;
+  finish_small_body(f, lds);
+  if (!f.stage) return;
+  // ---- the last block to get here gathers the results into the host block -------------------------------------------------------
+  __threadfence();
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t == 0) s_last = atomicAdd(f.counter, 1) == (int)(gridDim.x * gridDim.y) - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // (other blocks' results: not from a stale L1 line)
+  const long long n_tails = f.n_tail * f.Q, n_all = f.n_hg + f.n_kl + n_tails + f.n_row + f.n_extra + f.Q;
+  for (long long i = t; i < n_all; i += NT) {
+    long long k = i;
+    double v;
+    if (k < f.n_hg) v = f.g_stats[k];
+    else if ((k -= f.n_hg) < f.n_kl) v = f.g_kl[k];
+    else if ((k -= f.n_kl) < n_tails) {
+      const long long q = k / f.n_tail, e = k - q * f.n_tail;
+      v = f.g_stats[f.NG + q * f.per_q + f.oDZ + e];
+    } else if ((k -= n_tails) < f.n_row) v = f.rowout[k];
+    else if ((k -= f.n_row) < f.n_extra) v = f.g_extra[k];
+    else v = (double)f.g_info[k - f.n_extra];
+    f.stage[i] = v;
+  }
+  if (t == 0) *f.counter = 0;
 }
 
 

@@ -101,8 +101,12 @@ class Engine(object):
         self.N = [0] * self.T
         self.last = None
         # reuse_outputs=True: g_m_u / g_L_u / g_Z are returned as views of page-locked arrays owned by the engine (DMA
-        # without the driver's staging copy); they are overwritten by the next evaluation -- copy what must persist.
+        # without the driver's staging copy), and the small outputs as engine-owned arrays too (the hmogp_outputs struct is
+        # built once: ~25 us of ctypes work per call otherwise); ALL are overwritten by the next evaluation -- copy what
+        # must persist.
         self.reuse_outputs = bool(reuse_outputs)
+        self._pcache = None
+        self._ocache = {}
         self._pinned_out = None
 
     def close(self):
@@ -131,33 +135,42 @@ class Engine(object):
     # ------------------------------------------------------------------------------------------ params
     def _params(self, Z, m_u, L_flat, variance, lengthscale, W, kappa, W0=None, kappa0=None, batch_scale=None,
                 row_begin=None, row_end=None, forced_rung=None, group_mask=_lib.GROUP_ALL):
-        keep = []
-
-        def arr(a, shape, dtype=np.float64):
-            if a is None:
-                return None
-            b = np.ascontiguousarray(a, dtype=dtype).reshape(shape)
-            keep.append(b)
-            return b
-
+        """hmogp_params for one call.  The struct and the addresses of the arrays it points to are kept between calls: an
+        argument that is THE SAME C-contiguous array object as last time (an optimiser updating its parameters in place) costs
+        one identity check; anything else is converted (copied if it has to be) and its address taken again."""
         Q, M, P, Df, T = self.Q, self.M, self.P, self.Df, self.T
-        a = dict(Z=arr(Z, (M, Q * P)), m_u=arr(m_u, (M, Q)), L_flat=arr(L_flat, (self.Mtri, Q)),
-                 variance=arr(variance, (Q,)), lengthscale=arr(lengthscale, (Q,)), W=arr(W, (Q, Df)),
-                 kappa=arr(kappa, (Q, Df)), W0=arr(W0, (Q, Df)), kappa0=arr(kappa0, (Q, Df)),
-                 batch_scale=arr(batch_scale, (T,)))
-        rbg, ren = arr(row_begin, (T,), np.int64), arr(row_end, (T,), np.int64)
-        fr = arr(forced_rung, (Q,), np.int32)
-        p = _lib.Params()
-        for k, v in a.items():
-            setattr(p, k, _p(v) if v is not None else None)
-        p.row_begin = rbg.ctypes.data_as(_lib.c_int64_p) if rbg is not None else None
-        p.row_end = ren.ctypes.data_as(_lib.c_int64_p) if ren is not None else None
-        p.forced_rung = fr.ctypes.data_as(_lib.c_int32_p) if fr is not None else None
+        if self._pcache is None:
+            f8, i8, i4 = np.dtype(np.float64), np.dtype(np.int64), np.dtype(np.int32)
+            spec = dict(Z=(M * Q * P, f8), m_u=(M * Q, f8), L_flat=(self.Mtri * Q, f8), variance=(Q, f8), lengthscale=(Q, f8),
+                        W=(Q * Df, f8), kappa=(Q * Df, f8), W0=(Q * Df, f8), kappa0=(Q * Df, f8), batch_scale=(T, f8),
+                        row_begin=(T, i8), row_end=(T, i8), forced_rung=(Q, i4))
+            self._pcache = (_lib.Params(), spec, {k: None for k in spec}, {})
+        p, spec, last, keep = self._pcache
+        for k, a in (("Z", Z), ("m_u", m_u), ("L_flat", L_flat), ("variance", variance), ("lengthscale", lengthscale), ("W", W),
+                     ("kappa", kappa), ("W0", W0), ("kappa0", kappa0), ("batch_scale", batch_scale), ("row_begin", row_begin),
+                     ("row_end", row_end), ("forced_rung", forced_rung)):
+            if a is last[k] and a is not None:
+                continue
+            if a is None:
+                setattr(p, k, None)
+                last[k] = keep[k] = None
+                continue
+            size, dt = spec[k]
+            b = a if (type(a) is np.ndarray and a.dtype == dt and a.flags.c_contiguous) else np.ascontiguousarray(a, dtype=dt)
+            if b.size != size:
+                raise ValueError("%s: expected %d elements, got an array of shape %s" % (k, size, np.shape(a)))
+            setattr(p, k, b.ctypes.data)
+            keep[k] = b
+            last[k] = a if b is a else None      # (a converted copy does not follow later in-place changes of `a`: convert again)
         p.group_mask = int(group_mask)
         return p, keep
 
     def _outputs(self, want_dL_dS=False, skip_qu=False):
         Q, M, P, Df = self.Q, self.M, self.P, self.Df
+        key = (bool(want_dL_dS), bool(skip_qu))
+        if self.reuse_outputs and key in self._ocache:     # every output array is owned by the engine and overwritten by the
+            c, o = self._ocache[key]                        # next evaluation; the struct pointing at them is built once
+            return c, dict(o)
         if self.reuse_outputs:      # page-locked arrays owned by the engine, overwritten by the next evaluation
             if self._pinned_out is None:
                 self._pinned_out = dict(g_m_u=pinned_empty((M, Q)), g_L_u=pinned_empty((self.Mtri, Q)),
@@ -173,16 +186,18 @@ class Engine(object):
         flags = np.zeros(1, dtype=np.uint32)
         c = _lib.Outputs()
         for k, v in o.items():
-            setattr(c, k, _p(v))
+            setattr(c, k, v.ctypes.data)
         if not want_dL_dS:
             c.dL_dS = None
         if skip_qu:                  # q(u) is device-resident: its gradient stays in HBM for hmogp_qu_adadelta
             c.g_m_u = None
             c.g_L_u = None
             o["g_m_u"] = o["g_L_u"] = None
-        c.rung = rung.ctypes.data_as(_lib.c_int32_p)
-        c.flags = flags.ctypes.data_as(_lib.c_uint32_p)
+        c.rung = rung.ctypes.data
+        c.flags = flags.ctypes.data
         o["rung"], o["flags"] = rung, flags
+        if self.reuse_outputs:
+            self._ocache[key] = (c, dict(o))
         return c, o
 
     def _wrap(self, o):
