@@ -17,6 +17,8 @@ struct SmallU {   // inputs / outputs of u_small_kernel (all device pointers; pe
   double* a = nullptr;             // [Q][M]
   double* klout = nullptr;         // [Q][KL_BLOCKS][5]
   int* info = nullptr;             // [Q] LAPACK info of the factorisation (always written: 0 = fine)
+  long long* stamps = nullptr;     // diagnostics (HMOGP_USMALL_STAMPS): [Q][2][16] s_memtime at the phase boundaries of each block
+  int regs = 1;                    // the wave-level chains with their matrix in registers (0: in LDS)
   int stop_after = 0;              // diagnostics (HMOGP_USMALL_STOP): leave block (q, 0) after phase 1..3 -- timing only
   int* flag = nullptr;             // [Q] hand-over flag of S between the two blocks of a latent: set to *seq when S is in HBM
   const double* seq = nullptr;     // evaluation counter in the parameter block (a new value per evaluation: no memset of the flags)

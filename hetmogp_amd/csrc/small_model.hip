@@ -15,6 +15,7 @@
 // A failed factorisation (GPy's jitter ladder is needed) only sets info[q]: the engine then repeats the evaluation on the
 // regular path, which owns the ladder.  Arithmetic: plain FP64 FMAs on 4 x 4 register micro-tiles (a 64^3 product is
 // ~4 us on one CU; MFMA tiles would not be faster at one block per latent) -- results agree with the blocked kernels to rounding.
+#include <cstdio>
 #include "common.h"
 #include "post.h"
 #include "rbf_device.h"
@@ -190,18 +191,138 @@ __device__ __forceinline__ void sm_trtri_wave(const double* __restrict__ L, doub
   }
 }
 
+// ---- the same three wave-level chains with the wave's matrix in REGISTERS --------------------------------------------------------
+// The LDS versions above pay an LDS round trip (~100+ cycles) for every dependent step: ~1100 cycles per column / row at M = 50
+// (27 us for the factorisation, 25 us for a triangular inverse).  Here lane i keeps row i of the factorised matrix (lane c:
+// column c of the inverse) in 64 registers, the loops are fully unrolled (register indices are compile-time constants), and LDS
+// only carries what crosses lanes: the finished column (one write, broadcast reads) / the finished rows of L.
+typedef __attribute__((address_space(3))) const double sm_lds_cd;   // LDS pointer that stays one (ds_read, not flat_load)
+__device__ __forceinline__ double sm_readlane(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void sm_wave_sync() {   // LDS operations of one wave are processed in order: only the compiler must not reorder
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Lower Cholesky factor of X (M x M in LDS; in place: lower triangle + diagonal, zeros above), right-looking, by one wave.
+// `col` is a 64-double LDS scratch.  diag[] receives the pivots, `progress` counts finished columns (-1: failed) for a follower.
+// Returns LAPACK's info.
+__device__ __forceinline__ void sm_sqrt_pair(double d, double& sq, double& rs) {
+  // sqrt(d) and 1 / sqrt(d) from the hardware estimate and two coupled (Goldschmidt) refinements -- ~10 dependent operations
+  // instead of the ~45 of an IEEE sqrt followed by an IEEE division.  Both results are within 1 ulp; pivots of a covariance
+  // matrix are nowhere near the ends of the exponent range.
+  const double y = __builtin_amdgcn_rsq(d);
+  double g = d * y, h = 0.5 * y;
+  double e = fma(-h, g, 0.5);
+  g = fma(g, e, g), h = fma(h, e, h);
+  e = fma(-h, g, 0.5);
+  g = fma(g, e, g), h = fma(h, e, h);
+  sq = g, rs = h + h;
+}
+// `col`: 2 x 64 doubles of LDS scratch (the finished column, double-buffered); rdiag[] receives the reciprocal pivots.
+__device__ __forceinline__ int sm_potrf_regs(double* X, double* diag, double* rdiag, double* col, int M, int lane, int* progress) {
+  double a[SM];
+#pragma unroll
+  for (int k = 0; k < SM; ++k) a[k] = (lane < M && k < M) ? X[lane * SLD + k] : 0.0;
+  sm_lds_cd* colv = (sm_lds_cd*)col;                     // (an opaque base register: LDS offsets beyond 64 KB do not fit the
+  asm volatile("" : "+v"(colv));                         //  instruction's offset field and would be materialised per read)
+  int info = 0;
+  double d = sm_readlane(a[0], 0), sq, rs;
+  if (!(d > 0.0)) info = 1;
+  sm_sqrt_pair(d, sq, rs);
+#pragma unroll
+  for (int j = 0; j < SM; ++j) {
+    if (j >= M || info) continue;                        // (uniform; no early exit: the loop must unroll completely)
+    const double l = (lane > j) ? a[j] * rs : 0.0;       // column j below the diagonal (zero in the lanes above it)
+    a[j] = (lane == j) ? sq : l;
+    X[lane * SLD + j] = a[j];                            // column j of L (explicit zeros above the diagonal)
+    col[(j & 1) * SM + lane] = l;
+    if (lane == j) diag[j] = sq, rdiag[j] = rs;
+    sm_wave_sync();
+    if (progress && lane == 0) __hip_atomic_store(progress, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    sm_lds_cd* cj = colv + (j & 1) * SM;
+    double c[SM];
+#pragma unroll
+    for (int k = j + 1; k < SM; ++k) c[k] = cj[k];       // broadcast reads of the column: all in flight ...
+    __builtin_amdgcn_sched_barrier(0);                   // ... before the first FMA (the scheduler would serialise them otherwise)
+    // look-ahead: the next column's own element first, then its pivot and the refinement chain -- independent of the rest of the
+    // trailing update below, which hides their latency (one wave, in-order issue: the compiler interleaves the two)
+    if (j + 1 < SM) {
+      a[j + 1] = fma(-l, c[j + 1], a[j + 1]);
+      d = sm_readlane(a[j + 1], j + 1);
+      sm_sqrt_pair(d, sq, rs);
+    }
+#pragma unroll
+    for (int k = j + 2; k < SM; ++k) a[k] = fma(-l, c[k], a[k]);   // trailing update
+    if (j + 1 < M && !(d > 0.0)) info = j + 2;
+  }
+  if (info && progress && lane == 0) __hip_atomic_store(progress, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return info;
+}
+// spins until the factorisation has finished column r; false: it failed
+__device__ __noinline__ bool sm_wait_progress(int* progress, int r) {
+  for (;;) {
+    const int p = __builtin_amdgcn_readfirstlane(__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if (p < 0) return false;
+    if (p > r) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+  return true;
+}
+// `rdiag`: the reciprocals of L's diagonal in LDS (the factorisation's by-product, or sm_rdiag).
+template <bool FOLLOW>
+__device__ __forceinline__ void sm_trtri_regs(const double* L, const double* rdiag, double* Xi, int M, int lane, int* progress) {
+  double x[SM];
+  bool dead = false;
+  sm_lds_cd* Lv = (sm_lds_cd*)L;                         // (opaque base register: see sm_potrf_regs)
+  asm volatile("" : "+v"(Lv));
+#pragma unroll
+  for (int r = 0; r < SM; ++r) {
+    if (r >= M || dead) continue;                        // (uniform; no early exit: the loop must unroll completely)
+    if (FOLLOW) {
+      dead = !sm_wait_progress(progress, r);
+      if (dead) continue;
+    }
+    sm_lds_cd* lr = Lv + r * SLD;
+    double s0 = (lane == r) ? 1.0 : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int k = 0; k < r; ++k) {
+      const double t = lr[k];
+      if (k >= (r & ~3) || (k & 3) == 0) s0 = fma(-t, x[k], s0);
+      else if ((k & 3) == 1) s1 = fma(-t, x[k], s1);
+      else if ((k & 3) == 2) s2 = fma(-t, x[k], s2);
+      else s3 = fma(-t, x[k], s3);
+    }
+    if (FOLLOW) {     // (the row of L only exists now: all of its reads in flight before the first FMA)
+      __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 80, 0);
+    }
+    const double v = (lane <= r) ? ((s0 + s1) + (s2 + s3)) * rdiag[r] : 0.0;
+    x[r] = v;
+    Xi[r * SLD + lane] = v;
+  }
+}
+
 // grid (Q, 2): block (q, 0) runs the K_uu chain and then the joint part, block (q, 1) the q(u) chain -- the two sequential
 // wave-level chains (Cholesky + triangular inverse of K_uu; triangular inverse of L) run on two CUs at once.  Block (q, 0) needs
 // S from block (q, 1): handed over through HBM behind an agent-scope release / acquire on flag[q] (2 Q <= 16 blocks: always
 // co-resident; S is published first thing, so the wait is never taken in practice).
+#define SM_STAMP(i)                                                                                   \
+  do {                                                                                                \
+    if (u.stamps && threadIdx.x == 0) u.stamps[((long long)blockIdx.x * 2 + blockIdx.y) * 16 + (i)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+
 template <int P>
-__global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void u_small_kernel(SmallU u) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* X0 = lds;
   double* X1 = X0 + SM * SLD;
   double* X2 = X1 + SM * SLD;
   double* X3 = X2 + SM * SLD;
-  double* vec = X3 + SM * SLD;          // [4][SM]: diag pivots | m | a | scratch
+  double* vec = X3 + SM * SLD;          // [6][SM]: diag pivots | m | a | scratch (2) | reciprocal pivots
   __shared__ double red[16];
   __shared__ int s_info, s_progress;
   const int q = blockIdx.x, role = blockIdx.y, t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -210,29 +331,43 @@ __global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
   double* o = u.klout + (long long)q * KL_BLOCKS * 5;
 
   const int seq = (int)u.seq[0];
+  SM_STAMP(0);
   if (role == 1) {
     // ---- q(u) chain: L = flat_to_triang(L_flat) (svmogp_inf.py:193), S = L L^T (:194-195), S^-1 = dpotri(L) (:124) ------------
     for (long long e = (long long)q * NT + t; e < u.nzero; e += (long long)Q * NT) u.zero[e] = 0.0;   // (the bundle: see SmallU)
     sm_fill(X2, M, [&](int r, int c) { return (c <= r) ? u.Lflat[((long long)r * (r + 1) / 2 + c) * Q + q] : 0.0; });
     __syncthreads();
+    SM_STAMP(1);
     sm_store(X2, u.L + off, M);
     sm_gemm<false, true>(X2, X2, X0, M, 2);                // S = L L^T  -> X0
     __syncthreads();
+    SM_STAMP(2);
     sm_store(X0, u.S + off, M);
     __threadfence();                                       // S is in HBM (agent scope) ...
     __syncthreads();
     if (t == 0) __hip_atomic_store(&u.flag[q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... before block (q, 0) may read it
+    SM_STAMP(3);
     double l2 = 0.0, ninf = 0.0;
     if (t < M) l2 = log(fabs(X2[t * SLD + t]));
-    if (w == 0) sm_trtri_wave(X2, X3, M, lane);            // L^-1 -> X3 (one wave)
+    if (w == 0) {                                          // L^-1 -> X3 (one wave)
+      if (u.regs) {
+        if (lane < M) vec[5 * SM + lane] = 1.0 / X2[lane * SLD + lane];   // reciprocal pivots: one division for all rows
+        sm_wave_sync();
+        sm_trtri_regs<false>(X2, vec + 5 * SM, X3, M, lane, nullptr);
+      } else
+        sm_trtri_wave(X2, X3, M, lane);
+    }
     __syncthreads();
+    SM_STAMP(4);
     sm_gemm<true, false>(X3, X3, X1, M, 1);                // S^-1 = L^-T L^-1  -> X1
     __syncthreads();
+    SM_STAMP(5);
     sm_store(X1, u.Sqi + off, M);
     sm_each(M, [&](int i, int j) { ninf += isinf(X1[i * SLD + j]) ? 1.0 : 0.0; });
     l2 = block_sum(l2, red);
     ninf = block_sum(ninf, red);
     if (t == 0) o[5 + 0] = 0.0, o[5 + 1] = 0.0, o[5 + 2] = 0.0, o[5 + 3] = l2, o[5 + 4] = ninf;   // KL partial "block 1"
+    SM_STAMP(6);
     return;
   }
 
@@ -258,16 +393,35 @@ __global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
   for (int e = t; e < KL_BLOCKS * 5; e += NT)          // KL partials: blocks 0 and 1 are written below / by block (q, 1)
     if (e >= 10) o[e] = 0.0;
   __syncthreads();
+  SM_STAMP(1);
   if (u.stop_after == 1) return;
+  if (u.stop_after == 6) return;
   if (w == 0) {                                        // wave 0: L_uu = chol(K_uu + jitter I) ...
-    const int info = sm_potrf_wave(X0, vec, M, lane, &s_progress);
+    const int info = u.regs ? sm_potrf_regs(X0, vec, vec + 5 * SM, vec + 3 * SM, M, lane, &s_progress)
+                            : sm_potrf_wave(X0, vec, M, lane, &s_progress);
     if (lane == 0) s_info = info;
-  } else if (w == 1) {                                 // ... wave 1, one row behind it: L_uu^-1 -> X1
-    sm_trtri_follow(X0, vec, X1, M, lane, &s_progress);
+  } else if (w == 1 && u.stop_after != 5) {            // ... wave 1, one row behind it: L_uu^-1 -> X1
+    if (u.regs) sm_trtri_regs<true>(X0, vec + 5 * SM, X1, M, lane, &s_progress);
+    else sm_trtri_follow(X0, vec, X1, M, lane, &s_progress);
+  } else if (w == 2) {                                 // ... wave 2 meanwhile: S of block (q, 1) (published first thing) -> X3
+    if (lane == 0)
+      while (__hip_atomic_load(&u.flag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const double* Sg = u.S + off;
+    for (int i0 = 0; i0 < M; i0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (i0 + e < M && lane < M) ? Sg[(long long)(i0 + e) * M + lane] : 0.0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (i0 + e < M && lane < M) X3[(i0 + e) * SLD + lane] = v[e];
+    }
   }
   __syncthreads();
+  SM_STAMP(2);
   if (t == 0) u.info[q] = s_info;                        // (non-zero: the engine falls back to the regular path and its ladder)
-  if (u.stop_after == 2) return;
+  if (u.stop_after == 2 || u.stop_after == 5) return;
   if (s_info) return;
   // L_uu with an explicit zero upper triangle (potrf_finalize)
   sm_each(M, [&](int i, int j) { u.Luu[off + (long long)i * M + j] = (j <= i) ? X0[i * SLD + j] : 0.0; });
@@ -276,6 +430,7 @@ __global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
   __syncthreads();
   sm_gemm<true, false>(X1, X1, X0, M, 1);                // K_uu^-1 = L_uu^-T L_uu^-1            (util.py:199)            -> X0
   __syncthreads();
+  SM_STAMP(3);
   sm_store(X0, u.Kuui + off, M);
   double ma = 0.0, tr = 0.0;
   if (t < M) {                                           // a = K_uu^-1 m
@@ -284,20 +439,18 @@ __global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
     u.a[(long long)q * M + t] = sacc;
     ma = vec[SM + t] * sacc;
   }
+  SM_STAMP(4);
   if (u.stop_after == 3) return;
-  // ---- joint part: needs S of block (q, 1) ---------------------------------------------------------------------------------
-  if (t == 0)
-    while (__hip_atomic_load(&u.flag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) __builtin_amdgcn_s_sleep(2);
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  sm_load(X3, u.S + off, M, M);
-  __syncthreads();
+  // ---- joint part: needs S of block (q, 1) -- in X3 since the factorisation (wave 2) -------------------------------------------
+  SM_STAMP(5);
   sm_each(M, [&](int i, int j) { tr += X0[i * SLD + j] * X3[i * SLD + j]; });
   sm_gemm<false, false>(X0, X3, X1, M);                  // K^-1 S                                                         -> X1
   __syncthreads();
+  SM_STAMP(6);
   sm_store(X1, u.KiS + off, M);
   sm_gemm<false, false>(X1, X0, X2, M);                  // K^-1 S K^-1                                                    -> X2
   __syncthreads();
+  SM_STAMP(7);
   sm_store(X2, u.KSK + off, M);
   sm_each(M, [&](int i, int j) {                         // C = K^-1 S K^-1 - K^-1 ; T = tril(C) + tril(C^T, -1)
     const double cij = X2[i * SLD + j] - X0[i * SLD + j];
@@ -312,6 +465,7 @@ __global__ __launch_bounds__(NT) void u_small_kernel(SmallU u) {
   ma = block_sum(ma, red);
   l1 = block_sum(l1, red);
   if (t == 0) o[0] = tr, o[1] = ma, o[2] = l1, o[3] = 0.0, o[4] = 0.0;
+  SM_STAMP(8);
 }
 
 // rowout[q][m] = { sum_j EK_mj, sum_j EK_mj r2_mj, sum_j (EK_mj + EK_jm)(z_j - z_m)[p] }, EK = dKmm .* K_zz: kzz_rows_kernel's
@@ -747,7 +901,7 @@ __global__ __launch_bounds__(NT) void small_red_kernel(SmallRows a, int nblk, Sm
 }
 }  // namespace
 
-size_t small_lds_bytes() { return sizeof(double) * (4 * SM * SLD + 4 * SM); }
+size_t small_lds_bytes() { return sizeof(double) * (4 * SM * SLD + 6 * SM); }
 
 void launch_u_small(const SmallU& u_in, hipStream_t s) {
   SmallU u = u_in;
@@ -756,6 +910,32 @@ void launch_u_small(const SmallU& u_in, hipStream_t s) {
     return e ? atoi(e) : 0;
   }();
   u.stop_after = stop;
+  static const int regs = [] {   // HMOGP_SMALL_REGS=0: the LDS-resident factorisation / inverses (A/B runs)
+    const char* e = getenv("HMOGP_SMALL_REGS");
+    return e ? atoi(e) : 1;
+  }();
+  u.regs = regs;
+  // HMOGP_USMALL_STAMPS=1: shader-clock stamps at the phase boundaries of every block, printed every 1000 launches
+  static long long* stamps = [] {
+    long long* p = nullptr;
+    const char* e = getenv("HMOGP_USMALL_STAMPS");
+    if (e && atoi(e)) (void)hipHostMalloc((void**)&p, sizeof(long long) * 8 * 2 * 16, hipHostMallocDefault);
+    return p;
+  }();
+  static int n_launch = 0;
+  if (stamps) {
+    if (++n_launch % 1000 == 0) {
+      (void)hipStreamSynchronize(s);
+      for (int q = 0; q < u.Q; ++q)
+        for (int r = 0; r < 2; ++r) {
+          const long long* t = stamps + (q * 2 + r) * 16;
+          std::fprintf(stderr, "u_small block (%d, %d): start %+lld vs (0,0);", q, r, t[0] - stamps[0]);
+          for (int i = 1; i <= (r ? 6 : 8); ++i) std::fprintf(stderr, " %d:%lld", i, t[i] - t[0]);
+          std::fprintf(stderr, "\n");
+        }
+    }
+    u.stamps = stamps;
+  }
   static bool attr_set = false;
   if (!attr_set) {   // > 64 KB of dynamic LDS needs the opt-in
     HIP_TRY(hipFuncSetAttribute((const void*)u_small_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds_bytes()));
