@@ -8,13 +8,16 @@
 //
 //   u_small_kernel       K_uu (GPy rounding order) -> + jitter -> Cholesky -> L_uu^-1 -> K_uu^-1 ; a = K_uu^-1 m ;
 //                        L = tril(flat) ; S = L L^T ; K^-1 S ; K^-1 S K^-1 ; C ; tril-fold(C) ; S^-1 ; KL partials
-//   finish_small_kernel  H mirrored ; G = K^-1 H K^-1 ; K^-1 r ; dL/dS ; dL/dL (packed) ; dL/dm ; G S K^-1 ; dL/dKmm
+//   finish_small_kernel  H mirrored ; G = K^-1 H K^-1 ; K^-1 r ; dL/dS ; dL/dL (packed) ; dL/dm ; G S K^-1 ; dL/dKmm ; its K_zz-weighted
+//                        row sums ; the last block to finish gathers every small result into the caller's page-locked host block
 //
 // Both write the SAME global buffers as the regular path (engine.hip: Kuu, Luu, Kuui, L, S, KiS, KSK, C, Ctri, Sqi, a, klout /
 // G, GSK, dLdS, gL, gmu, Kr, dKmm), so posterior_u / predict_f / natgrad / the debug export work unchanged behind them.
 // A failed factorisation (GPy's jitter ladder is needed) only sets info[q]: the engine then repeats the evaluation on the
 // regular path, which owns the ladder.  Arithmetic: plain FP64 FMAs on 4 x 4 register micro-tiles (a 64^3 product is
 // ~4 us on one CU; MFMA tiles would not be faster at one block per latent) -- results agree with the blocked kernels to rounding.
+// The sequential chains (Cholesky, triangular inverses) run on single waves with the matrix in registers: sm_potrf_regs /
+// sm_trtri_regs; the LDS-resident versions stay for A/B runs (HMOGP_SMALL_REGS=0).  DESIGN.md 11e has the step-by-step timings.
 #include <cstdio>
 #include "common.h"
 #include "post.h"

@@ -146,7 +146,10 @@ def test_exact_mode_matches_oracle_and_finite_differences(tag, specs, Ns, M, Q, 
     for key, gkey in (("m_u", "g_m_u"), ("L_flat", "g_L_u"), ("lengthscale", "g_lengthscale"), ("Z", "g_Z"),
                       ("variance", "g_variance"), ("W", "g_W"), ("kappa", "g_kappa")):
         d = rng.randn(*np.shape(prm[key]))
-        eps = (1e-7 if key == "Z" else 1e-6) * np.abs(prm[key]).max()
+        # (L_flat: the ELBO's rounding noise, ~1e-14 relative through an ill-conditioned K_uu, divided by 2 eps is 2e-6 .. 1e-5
+        #  of this derivative at the 1e-6 step on every path -- tools/fd_noise.py; the 1e-5 step has 10x less of it and a
+        #  truncation error far below the tolerance)
+        eps = {"Z": 1e-7, "L_flat": 1e-5}.get(key, 1e-6) * np.abs(prm[key]).max()
         p1, p2 = dict(prm), dict(prm)
         p1[key], p2[key] = prm[key] + eps * d, prm[key] - eps * d
         fd = (run(e, p1)["elbo"] - run(e, p2)["elbo"]) / (2 * eps)
