@@ -206,3 +206,34 @@ def test_graph_replay_tracks_parameter_values_and_keys():
         assert rel(a["elbo"], b["elbo"]) < 1e-11 and rel(a["g_L_u"], b["g_L_u"]) < 1e-9
     assert es.graph_stats()[0] == 5 and es.graph_stats()[1] >= 8
     es.close(), er.close()
+
+
+def test_quadrature_launch_variants_agree():
+    """The one-launch quadrature of the small path (quad_multi_kernel, <= 8 segments and <= 2048 blocks per pool) against its two
+    fall-backs -- per-segment launches for more tasks than a launch carries, and for more blocks -- and against the regular path;
+    and a pool plan with several pools (chunk_rows smaller than the batch): the statistic bundle, zeroed once by u_small_kernel,
+    accumulates over the pools."""
+    from hetmogp_amd.engine import Engine
+    # (a) 9 tasks -> per-segment launches on the small path
+    specs9 = [("Gaussian", {"sigma": 0.4 + 0.05 * i}) if i % 3 == 0 else (("Bernoulli", {}) if i % 3 == 1 else ("Poisson", {}))
+              for i in range(9)]
+    prm, prob, X, Y = _synth(911, specs9, [60 + 7 * i for i in range(9)], 24, 2, 1, (1.0, 1.2))
+    es, er = _pair(prob, X, Y)
+    a, b = es.elbo_grad(**_args(prm)), er.elbo_grad(**_args(prm))
+    for k in KEYS:
+        assert rel(a[k], b[k]) < 1e-9, ("nine tasks", k, rel(a[k], b[k]))
+    es.close(), er.close()
+    # (b) a wave-per-row likelihood with more than 2048 quadrature blocks (9000 rows x 64 lanes / 256) beside a thread-per-row one
+    specs = [("Categorical", {"K": 3}), ("Gaussian", {"sigma": 0.5})]
+    prm, prob, X, Y = _synth(912, specs, [9000, 500], 32, 2, 1, (1.0, 1.2))
+    es, er = _pair(prob, X, Y)
+    a, b = es.elbo_grad(**_args(prm)), er.elbo_grad(**_args(prm))
+    for k in KEYS:
+        assert rel(a[k], b[k]) < 1e-9, ("many blocks", k, rel(a[k], b[k]))
+    # (c) the same problem in pools of 2048 rows (five pools), one-launch quadrature in each
+    ec = Engine(prob["specs"], prob["Q"], prob["M"], prob["P"], chunk_rows=2048)
+    ec.set_data(X, Y)
+    c = ec.elbo_grad(**_args(prm))
+    for k in KEYS:
+        assert rel(c[k], b[k]) < 1e-9, ("several pools", k, rel(c[k], b[k]))
+    es.close(), er.close(), ec.close()
