@@ -546,27 +546,40 @@ class SVMOGP(object):
             self._opt_buf[...] = x
         return self._opt_buf
 
+    def _free_plan(self):
+        """(params, positive mask over the optimiser vector) of the free parameters, rebuilt when a fix() / unfix() changes the
+        set: the transforms below then run ONCE over the whole vector instead of once per parameter (an objective evaluation
+        of a notebook-sized model takes 0.2 ms on the device: per-parameter NumPy calls were a third of the wall time)."""
+        params = [p for _, p in self._named_params()]
+        sig = tuple((id(p), p.is_fixed, p.size) for p in params)
+        plan = getattr(self, "_plan", None)
+        if plan is None or plan[0] != sig:
+            free = [p for p in params if not p.is_fixed]
+            mask = np.concatenate([np.full(p.size, bool(p.positive)) for p in free]) if free else np.zeros(0, bool)
+            plan = self._plan = (sig, free, mask, bool(mask.any()))
+        return plan
+
     @optimizer_array.setter
     def optimizer_array(self, x):
         x = np.asarray(x, dtype=float)
+        _, free, mask, any_pos = self._free_plan()
+        vals = np.where(mask, logexp_f(x), x) if any_pos else x
         i = 0
-        for _, p in self._named_params():
-            if p.is_fixed:
-                continue
+        for p in free:
             n = p.size
-            v = x[i:i + n].reshape(p.shape)
-            p[...] = logexp_f(v) if p.positive else v
+            np.ndarray.__setitem__(p, Ellipsis, vals[i:i + n].reshape(p.shape))   # (no per-parameter notification: ...
             i += n
-        self.parameters_changed()
+        self.parameters_changed()                                                  # ... one evaluation for the whole vector)
 
     def _transformed_gradient(self):
-        parts = []
-        for _, p in self._named_params():
-            if p.is_fixed:
-                continue
-            g = np.asarray(p.gradient, dtype=float).ravel()
-            parts.append(g * logexp_gradfactor(p.values.ravel()) if p.positive else g)
-        return np.concatenate(parts) if parts else np.zeros(0)
+        _, free, mask, any_pos = self._free_plan()
+        if not free:
+            return np.zeros(0)
+        g = np.concatenate([np.asarray(p.gradient, dtype=float).ravel() for p in free])
+        if any_pos:
+            theta = np.concatenate([p.values.ravel() for p in free])
+            g = np.where(mask, g * logexp_gradfactor(theta), g)
+        return g
 
     def _grads(self, x):
         """paramz Model._grads: set the optimiser vector (fires parameters_changed) and return the gradient of the
