@@ -622,20 +622,19 @@ __global__ __launch_bounds__(NT) void finish_small_kernel(SmallF f) {
   __syncthreads();
   if (!s_last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // (other blocks' results: not from a stale L1 line)
-  const long long n_tails = f.n_tail * f.Q, n_all = f.n_hg + f.n_kl + n_tails + f.n_row + f.n_extra + f.Q;
-  for (long long i = t; i < n_all; i += NT) {
-    long long k = i;
-    double v;
-    if (k < f.n_hg) v = f.g_stats[k];
-    else if ((k -= f.n_hg) < f.n_kl) v = f.g_kl[k];
-    else if ((k -= f.n_kl) < n_tails) {
-      const long long q = k / f.n_tail, e = k - q * f.n_tail;
-      v = f.g_stats[f.NG + q * f.per_q + f.oDZ + e];
-    } else if ((k -= n_tails) < f.n_row) v = f.rowout[k];
-    else if ((k -= f.n_row) < f.n_extra) v = f.g_extra[k];
-    else v = (double)f.g_info[k - f.n_extra];
-    f.stage[i] = v;
-  }
+  // (plain copy loops, unrolled: a thread's loads of a segment are in flight together -- one branchy loop over the whole block
+  //  pays a memory latency per element)
+  auto copy = [&](double* __restrict__ dst, const double* __restrict__ src, long long n) {
+#pragma unroll 8
+    for (long long i = t; i < n; i += NT) dst[i] = src[i];
+  };
+  double* d = f.stage;
+  copy(d, f.g_stats, f.n_hg), d += f.n_hg;
+  copy(d, f.g_kl, f.n_kl), d += f.n_kl;
+  for (int q = 0; q < f.Q; ++q) copy(d, f.g_stats + f.NG + q * f.per_q + f.oDZ, f.n_tail), d += f.n_tail;
+  copy(d, f.rowout, f.n_row), d += f.n_row;
+  copy(d, f.g_extra, f.n_extra), d += f.n_extra;
+  if (t < f.Q) d[t] = (double)f.g_info[t];
   if (t == 0) *f.counter = 0;
 }
 
