@@ -23,6 +23,7 @@
 #include "post.h"
 #include "rbf_device.h"
 #include "small_model.h"
+#include "rowpass.h"
 
 namespace {
 
@@ -859,20 +860,18 @@ __global__ __launch_bounds__(NT) void small_bwd_kernel(SmallRows a) {
 // bundle += sum over the blocks' partials, block by block in order (deterministic); one thread per output element
 __global__ __launch_bounds__(NT) void small_red_kernel(SmallRows a, int nblk, SmallQuadRed qr) {
   if (blockIdx.y == a.Q) {
-    // the quadrature's scalars: one wave per (segment, slot), lanes stride over the segment's blocks, fixed-order wave sum; the
-    // segments one after the other (two tasks may add to the same slot of the bundle)
-    if (blockIdx.x != 0) return;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int sg = 0; sg < qr.nseg; ++sg) {
-      const auto& g = qr.s[sg];
-      for (int k = w; k < g.nscal; k += NT / 64) {
+    // the quadrature's scalars: one wave per SLOT (over the whole plane of blocks), the segments one after the other -- two tasks
+    // add to the same word of the bundle only through the same slot (sum ve, #(v<0), sa_q, sl_q), so the order is fixed
+    const int lane = threadIdx.x & 63, gw = blockIdx.x * (NT / 64) + (threadIdx.x >> 6), nw = gridDim.x * (NT / 64);
+    for (int k = gw; k < HMOGP_MAXSCAL; k += nw)
+      for (int sg = 0; sg < qr.nseg; ++sg) {
+        const auto& g = qr.s[sg];
+        if (k >= g.nscal) continue;
         double s = 0.0;
         for (long long b = lane; b < g.nrows; b += 64) s += g.part[b * g.nscal + k];
         s = wave_sum(s);
         if (lane == 0) a.stats[g.off[k]] += s;
       }
-      __syncthreads();
-    }
     return;
   }
   const int q = blockIdx.y, M = a.M, P = a.P;
@@ -890,16 +889,20 @@ __global__ __launch_bounds__(NT) void small_red_kernel(SmallRows a, int nblk, Sm
     if (!a.want_z) return;
     dst = a.NG + q * a.per_q + a.oDZ + (e - (long long)M * M - M);
   }
-  // four interleaved partial sums in a FIXED order (blocks b = i mod 4): independent loads in flight, same bits every run
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  // eight interleaved partial sums in a FIXED order (blocks b = i mod 8): eight independent loads in flight, same bits every run
+  double sacc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   const double* src = a.slab + (long long)q * slab_q + e;
   const long long st = (long long)a.Q * slab_q;
   int b = 0;
-  for (; b + 4 <= nblk; b += 4) {
-    s0 += src[(long long)b * st], s1 += src[(long long)(b + 1) * st], s2 += src[(long long)(b + 2) * st], s3 += src[(long long)(b + 3) * st];
+  for (; b + 8 <= nblk; b += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(long long)(b + u) * st];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sacc[u] += v[u];
   }
-  for (; b < nblk; ++b) s0 += src[(long long)b * st];
-  a.stats[dst] += (s0 + s1) + (s2 + s3);
+  for (; b < nblk; ++b) sacc[0] += src[(long long)b * st];
+  a.stats[dst] += ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) + ((sacc[4] + sacc[5]) + (sacc[6] + sacc[7]));
 }
 }  // namespace
 
