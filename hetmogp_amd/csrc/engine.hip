@@ -439,6 +439,7 @@ struct hmogp_engine {
       for (int q = 0; q < Q; ++q)
         if (rung[q] == -2) rung[q] = -1;
       small_info_pending = true;
+      info_early = false;            // (the captured evaluation delivers its info words with the results)
       began = true;
       fin_layout(out);
       ++graph_replays;

@@ -237,3 +237,32 @@ def test_quadrature_launch_variants_agree():
     for k in KEYS:
         assert rel(c[k], b[k]) < 1e-9, ("several pools", k, rel(c[k], b[k]))
     es.close(), er.close(), ec.close()
+
+
+def test_replayed_graph_detects_a_failed_factorisation():
+    """A graph is captured on well-conditioned parameters; a later REPLAY gets inducing inputs whose K_uu needs GPy's jitter
+    ladder.  The info words of a replay arrive with the results (the last block of finish_small_kernel writes them into the
+    page-locked block) -- also when a three-call evaluation, whose info words travel by their own early copy, ran in between --
+    and the evaluation must be repeated on the regular path: same rung and same numbers as the regular engine."""
+    specs = [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {})]
+    prm, prob, X, Y = _synth(13, specs, [300, 200], 24, 2, 1, (4.0, 5.0))
+    bad = dict(prm)
+    bad["Z"] = np.tile(np.linspace(0, 1, 24)[:, None], (1, 2))      # (the ladder case of the test above)
+    good = dict(prm)
+    good["lengthscale"] = np.asarray(prm["lengthscale"]) * 0.02     # short lengthscale: K_uu close to diagonal
+    good["Z"] = bad["Z"]
+    es, er = _pair(prob, X, Y)
+    for _ in range(3):                                               # normal, capture, replay
+        a = es.elbo_grad(**_args(good))
+    assert a["rungs"] == [-1, -1] and es.graph_stats() == (1, 1)
+    es.step_begin(**_args(good))                                     # a three-call evaluation in between
+    es.step_finish()
+    a, b = es.elbo_grad(**_args(bad)), er.elbo_grad(**_args(bad))    # replay of the captured graph with a K_uu that fails
+    assert min(b["rungs"]) >= 0 and a["rungs"] == b["rungs"]
+    for k in KEYS:
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+    a = es.elbo_grad(**_args(good))                                  # and the graph is still good for the next call
+    c = er.elbo_grad(**_args(good))
+    for k in KEYS:
+        assert rel(a[k], c[k]) < 1e-9, k
+    es.close(), er.close()
