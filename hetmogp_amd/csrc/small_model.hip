@@ -33,7 +33,7 @@ constexpr int SM = HMOGP_SMALL_M, SLD = SM + 2, NT = 256;   // even leading dime
 // Rows / columns beyond M hold garbage that is never stored.  KLO / KHI trim the k-range for triangular operands:
 //   tri == 0: k in [0, M);  tri == 1: k <= min(i, j) style handled by the caller through `kmax_of_tile`.
 template <bool TA, bool TB>
-__device__ __forceinline__ void sm_gemm(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int M,
+__device__ __forceinline__ void sm_gemm_fma(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int M,
                                         int kbeg_mode = 0) {
   const int t = threadIdx.x, r0 = 4 * (t >> 4), c0 = 4 * (t & 15);
   if (r0 >= M || c0 >= M) return;
@@ -63,6 +63,86 @@ __device__ __forceinline__ void sm_gemm(const double* __restrict__ A, const doub
     for (int j = 0; j < 4; ++j)
       if (r0 + i < M && c0 + j < M) C[(r0 + i) * SLD + c0 + j] = acc[i][j];
 }
+
+// The same product on the matrix cores: four waves, each a 32 x 32 quadrant = 2 x 2 tiles of v_mfma_f64_16x16x4_f64 (A fragment:
+// row = lane & 15, k = lane >> 4; B fragment: k = lane >> 4, column = lane & 15; D: column = lane & 15, row = (lane >> 4) + 4 reg --
+// gemm_small.hip's conventions).  k beyond M would bring in the buffers' garbage: those fragment entries are zeros.  Triangular
+// k-trimming per quadrant (the operands carry explicit zeros there).  Measured at M = 50 (u_small_kernel's phase stamps): 4.4 us per
+// product for the FMA micro-tiles (bound by their LDS reads: 8 ds_read_b64 per 16 FMAs), 4.4 us for a plain MFMA loop (the LDS
+// latency of every step exposed), 2.9 us with the fragments of the next 16 k read ahead -- one wave per SIMD issues FP64 MFMAs at
+// half rate (135 cycles each here), so 512-thread blocks would halve it again.  HMOGP_SM_GEMM_FMA (compile time) restores the
+// micro-tiles.
+template <bool TA, bool TB>
+__device__ __forceinline__ void sm_gemm(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int M,
+                                        int kbeg_mode = 0) {
+#ifdef HMOGP_SM_GEMM_FMA
+  sm_gemm_fma<TA, TB>(A, B, C, M, kbeg_mode);
+#else
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wm = w >> 1, wn = w & 1, lr = lane & 15, lk = lane >> 4;
+  if (wm * 32 >= M || wn * 32 >= M) return;
+  const int kb = kbeg_mode == 1 ? max(wm, wn) * 32 : 0;
+  const int ke = kbeg_mode == 2 ? min(M, min(wm, wn) * 32 + 32) : M;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+  // chunks of 16 k (4 MFMA steps): the fragments of the next chunk are read from LDS before the 16 MFMAs of the current one
+  // (a step's four reads issued right in front of its MFMAs expose the LDS latency 13 times: 4.4 us per product instead of 1.5)
+  auto load_chunk = [&](int kc, double (&fa)[4][2], double (&fb)[4][2]) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int k = kc + 4 * st + lk;
+      const bool kin = k < ke;
+      const int ka = kin ? k : kb;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = wm * 32 + i * 16 + lr, col = wn * 32 + i * 16 + lr;
+        const double av = TA ? A[ka * SLD + row] : A[row * SLD + ka];
+        const double bv = TB ? B[col * SLD + ka] : B[ka * SLD + col];
+        fa[st][i] = kin ? av : 0.0;
+        fb[st][i] = kin ? bv : 0.0;
+      }
+    }
+  };
+  auto mfma_chunk = [&](int kc, const double (&fa)[4][2], const double (&fb)[4][2]) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+      if (kc + 4 * st < ke) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[st][a], fb[st][b], acc[a][b], 0, 0, 0);
+      }
+  };
+  double fa0[4][2], fb0[4][2], fa1[4][2], fb1[4][2];
+  if (kb < ke) load_chunk(kb, fa0, fb0);
+  for (int kc = kb; kc < ke; kc += 32) {
+    const bool more = kc + 16 < ke;
+    if (more) load_chunk(kc + 16, fa1, fb1);
+    mfma_chunk(kc, fa0, fb0);
+    if (more) {
+      if (kc + 32 < ke) load_chunk(kc + 32, fa0, fb0);
+      mfma_chunk(kc + 16, fa1, fb1);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = wm * 32 + a * 16 + 4 * r + lk;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int j = wn * 32 + b * 16 + lr;
+        if (i < M && j < M) C[i * SLD + j] = acc[a][b][r];
+      }
+    }
+#endif
+}
+
+// Block barrier that orders LDS only: __syncthreads() also waits for the block's outstanding GLOBAL stores (the results every phase
+// streams out to HBM), a round trip of microseconds per phase at this kernel's clocks; nothing inside a block reads those back.
+__device__ __forceinline__ void sm_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Element loops over an M x M matrix: a lane per column, NT / 64 rows per step, SM_IT steps (fixed count: fully unrolled, no
 // integer divisions).  Global loads go through sm_fill, which issues all of a thread's loads before the first LDS store -- one
@@ -340,11 +420,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // ---- q(u) chain: L = flat_to_triang(L_flat) (svmogp_inf.py:193), S = L L^T (:194-195), S^-1 = dpotri(L) (:124) ------------
     for (long long e = (long long)q * NT + t; e < u.nzero; e += (long long)Q * NT) u.zero[e] = 0.0;   // (the bundle: see SmallU)
     sm_fill(X2, M, [&](int r, int c) { return (c <= r) ? u.Lflat[((long long)r * (r + 1) / 2 + c) * Q + q] : 0.0; });
-    __syncthreads();
+    sm_barrier();
     SM_STAMP(1);
     sm_store(X2, u.L + off, M);
     sm_gemm<false, true>(X2, X2, X0, M, 2);                // S = L L^T  -> X0
-    __syncthreads();
+    sm_barrier();
     SM_STAMP(2);
     sm_store(X0, u.S + off, M);
     __threadfence();                                       // S is in HBM (agent scope) ...
@@ -361,10 +441,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       } else
         sm_trtri_wave(X2, X3, M, lane);
     }
-    __syncthreads();
+    sm_barrier();
     SM_STAMP(4);
     sm_gemm<true, false>(X3, X3, X1, M, 1);                // S^-1 = L^-T L^-1  -> X1
-    __syncthreads();
+    sm_barrier();
     SM_STAMP(5);
     sm_store(X1, u.Sqi + off, M);
     sm_each(M, [&](int i, int j) { ninf += isinf(X1[i * SLD + j]) ? 1.0 : 0.0; });
@@ -382,7 +462,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     double* zs = X3;                                     // (free until the joint part) inducing inputs of the latent: [M][P]
     for (int e = t; e < M * P; e += NT) zs[e] = u.Z[(long long)(e / P) * u.ldz + q * P + (e % P)];
     if (t < M) vec[SM + t] = u.mu[(long long)t * Q + q];
-    __syncthreads();
+    sm_barrier();
     sm_each(M, [&](int i, int j) {
       double zi[P], zj[P];
 #pragma unroll
@@ -396,7 +476,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   if (t == 0) s_info = 0, s_progress = 0;
   for (int e = t; e < KL_BLOCKS * 5; e += NT)          // KL partials: blocks 0 and 1 are written below / by block (q, 1)
     if (e >= 10) o[e] = 0.0;
-  __syncthreads();
+  sm_barrier();
   SM_STAMP(1);
   if (u.stop_after == 1) return;
   if (u.stop_after == 6) return;
@@ -422,7 +502,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (i0 + e < M && lane < M) X3[(i0 + e) * SLD + lane] = v[e];
     }
   }
-  __syncthreads();
+  sm_barrier();
   SM_STAMP(2);
   if (t == 0) u.info[q] = s_info;                        // (non-zero: the engine falls back to the regular path and its ladder)
   if (u.stop_after == 2 || u.stop_after == 5) return;
@@ -431,9 +511,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   sm_each(M, [&](int i, int j) { u.Luu[off + (long long)i * M + j] = (j <= i) ? X0[i * SLD + j] : 0.0; });
   double l1 = 0.0;
   if (t < M) l1 = log(fabs(X0[t * SLD + t]));
-  __syncthreads();
+  sm_barrier();
   sm_gemm<true, false>(X1, X1, X0, M, 1);                // K_uu^-1 = L_uu^-T L_uu^-1            (util.py:199)            -> X0
-  __syncthreads();
+  sm_barrier();
   SM_STAMP(3);
   sm_store(X0, u.Kuui + off, M);
   double ma = 0.0, tr = 0.0;
@@ -449,11 +529,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   SM_STAMP(5);
   sm_each(M, [&](int i, int j) { tr += X0[i * SLD + j] * X3[i * SLD + j]; });
   sm_gemm<false, false>(X0, X3, X1, M);                  // K^-1 S                                                         -> X1
-  __syncthreads();
+  sm_barrier();
   SM_STAMP(6);
   sm_store(X1, u.KiS + off, M);
   sm_gemm<false, false>(X1, X0, X2, M);                  // K^-1 S K^-1                                                    -> X2
-  __syncthreads();
+  sm_barrier();
   SM_STAMP(7);
   sm_store(X2, u.KSK + off, M);
   sm_each(M, [&](int i, int j) {                         // C = K^-1 S K^-1 - K^-1 ; T = tril(C) + tril(C^T, -1)
@@ -531,7 +611,7 @@ __device__ __forceinline__ void finish_small_body(const SmallF& f, double* lds) 
   sm_fill(X0, M, [&](int i, int j) { return (j <= i) ? Hq[(long long)i * M + j] : Hq[(long long)j * M + i]; });
   sm_load(X1, f.Kuui + off, M, M);
   if (t < M) vec[t] = Hq[f.oR + t], vec[2 * SM + t] = f.a[(long long)q * M + t];
-  __syncthreads();
+  sm_barrier();
   if (role == 0) {
     // (the bundle itself keeps the full symmetric H_q, like launch_mirror_lower)
     sm_each(M, [&](int i, int j) {
@@ -549,28 +629,28 @@ __device__ __forceinline__ void finish_small_body(const SmallF& f, double* lds) 
       if (f.gmu2) f.gmu2[(long long)t * Q + q] = s - vec[2 * SM + t];
     }
   }
-  __syncthreads();
+  sm_barrier();
   sm_gemm<false, false>(X1, X2, X3, M);                  // G = K^-1 (H K^-1)  (dVE_dS, svmogp_inf.py:148)          X3
-  __syncthreads();
+  sm_barrier();
   // The regular path forms the lower tiles of G = K^-1 H K^-1 and mirrors them: exactly symmetric.  Same here.
   sm_each(M, [&](int i, int j) {
     if (j > i) X3[i * SLD + j] = X3[j * SLD + i];
   });
-  __syncthreads();
+  sm_barrier();
   if (role == 0) sm_store(X3, f.G + off, M);
   if (role == 0 && f.want_qu) {
     sm_load(X0, f.Sqi + off, M, M);                      // (H is no longer needed)
-    __syncthreads();
+    sm_barrier();
     sm_each(M, [&](int i, int j) {                       // dL/dS = G - (K^-1 - S^-1) / 2   (svmogp_inf.py:131,169)
       const double v = X3[i * SLD + j] - 0.5 * (X1[i * SLD + j] - X0[i * SLD + j]);
       X2[i * SLD + j] = v;
       f.dLdS[off + (long long)i * M + j] = v;
     });
-    __syncthreads();
+    sm_barrier();
     sm_load(X0, f.L + off, M, M);
-    __syncthreads();
+    sm_barrier();
     sm_gemm<false, false>(X2, X0, X1, M);                // dL/dS L (:175-177)  [X1: K^-1 is re-read from HBM below]
-    __syncthreads();
+    sm_barrier();
     sm_each(M, [&](int r, int c) {                       // GPy triang_to_flat of 2 dL/dS L
       if (c <= r) {
         const long long o = ((long long)r * (r + 1) / 2 + c) * Q + q;
@@ -578,17 +658,17 @@ __device__ __forceinline__ void finish_small_body(const SmallF& f, double* lds) 
         if (f.gL2) f.gL2[o] = 2.0 * X1[r * SLD + c];
       }
     });
-    __syncthreads();
+    sm_barrier();
   }
   if (role == 1) {
     sm_load(X0, f.KiS + off, M, M);
-    __syncthreads();
+    sm_barrier();
     sm_gemm<false, true>(X3, X0, X2, M);                 // G S K^-1 = G (K^-1 S)^T   (tmp_dv, svmogp_inf.py:151)    X2
-    __syncthreads();
+    sm_barrier();
     sm_store(X2, f.GSK + off, M);
     // dL_dKmm (svmogp_inf.py:130-133,151-154,166,170): dkmm_kernel's formula
     sm_load(X0, f.KSK + off, M, M);                      // (K^-1 S is no longer needed; K^-1 is still in X1)
-    __syncthreads();
+    sm_barrier();
     sm_each(M, [&](int i, int j) {
       const double kri = vec[SM + i], krj = vec[SM + j], ai = vec[2 * SM + i], aj = vec[2 * SM + j];
       const double xij = X3[i * SLD + j] - X2[i * SLD + j] - X2[j * SLD + i] - kri * aj;
@@ -599,7 +679,7 @@ __device__ __forceinline__ void finish_small_body(const SmallF& f, double* lds) 
       X0[i * SLD + j] = dve - dkl;
     });
     if (f.rowout) {
-      __syncthreads();
+      sm_barrier();
       switch (f.P) {
         case 1: sm_kzz_rows<1>(f, X0, q); break;
         case 2: sm_kzz_rows<2>(f, X0, q); break;
@@ -670,7 +750,7 @@ __global__ __launch_bounds__(NT) void small_fwd_kernel(SmallRows a) {
     if (t < M) av[t] = a.a[(long long)q * M + t];
     for (int e = t; e < M * P; e += NT) zs[e] = a.Z[(long long)(e / P) * a.ldz + q * P + (e % P)];
     for (int e = t; e < RB * P; e += NT) xs[e] = (e / P < nr) ? a.X[(n0 + e / P) * P + (e % P)] : 0.0;
-    __syncthreads();
+    sm_barrier();
     double* Khq = a.Kh + (long long)q * a.ldn * M;
 #pragma unroll
     for (int it = 0; it < SM_IT; ++it) {        // K^ tile: rbf_kernel<P, false>'s arithmetic (clip(r2) / l^2, no sqrt / divide)
@@ -688,7 +768,7 @@ __global__ __launch_bounds__(NT) void small_fwd_kernel(SmallRows a) {
         Kt[r * SLD + m] = k;
       }
     }
-    __syncthreads();
+    sm_barrier();
     // P~ micro-tile: rows r0..r0+3 of the block, columns c0..c0+3
     double acc[4][4];
 #pragma unroll
@@ -757,7 +837,7 @@ __global__ __launch_bounds__(NT) void small_fwd_kernel(SmallRows a) {
           for (int j = 0; j < 4; ++j)
             if (c0 + j < M) Ptq[(n0 + r0 + i) * M + c0 + j] = acc[i][j];
     }
-    __syncthreads();
+    sm_barrier();
   }
 }
 
@@ -806,7 +886,7 @@ __global__ __launch_bounds__(NT) void small_bwd_kernel(SmallRows a) {
       wt[t] = in ? a.alpha[o] : 0.0, wt[RB + t] = in ? a.beta[o] : 0.0;
       wt[2 * RB + t] = in ? a.alpha0[o] : 0.0, wt[3 * RB + t] = in ? a.beta0[o] : 0.0;
     }
-    __syncthreads();
+    sm_barrier();
     double* out = a.slab + ((long long)blockIdx.x * a.Q + q) * slab_q;
     // H_q partial: lower micro-tiles only (the bundle carries the lower triangle between begin and finish)
     if (m0 < M && c0 < M && c0 <= m0 + 3) {
@@ -853,7 +933,7 @@ __global__ __launch_bounds__(NT) void small_bwd_kernel(SmallRows a) {
 #pragma unroll
       for (int p = 0; p < P; ++p) out[(long long)M * M + M + (long long)m * P + p] = dz[p];
     }
-    __syncthreads();
+    sm_barrier();
   }
 }
 
