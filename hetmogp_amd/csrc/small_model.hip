@@ -140,9 +140,25 @@ __device__ __forceinline__ void sm_gemm(const double* __restrict__ A, const doub
 #endif
 }
 
+// Block-wide sums of up to three values at once (one pair of barriers instead of one per value); results valid in thread 0.
+// `scratch` >= 3 * NT / 64 doubles.
+__device__ __forceinline__ void sm_block_sum3(double& a, double& b, double& c, double* scratch);
+
 // Block barrier that orders LDS only: __syncthreads() also waits for the block's outstanding GLOBAL stores (the results every phase
 // streams out to HBM), a round trip of microseconds per phase at this kernel's clocks; nothing inside a block reads those back.
 __device__ __forceinline__ void sm_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ void sm_block_sum3(double& a, double& b, double& c, double* scratch) {
+  a = wave_sum(a), b = wave_sum(b), c = wave_sum(c);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  sm_barrier();                                         // (scratch may still be read from a previous call)
+  if (lane == 0) scratch[w] = a, scratch[NT / 64 + w] = b, scratch[2 * (NT / 64) + w] = c;
+  sm_barrier();
+  if (threadIdx.x == 0) {
+    a = b = c = 0.0;
+    for (int i = 0; i < NT / 64; ++i) a += scratch[i], b += scratch[NT / 64 + i], c += scratch[2 * (NT / 64) + i];
+  }
+}
 
 // Element loops over an M x M matrix: a lane per column, NT / 64 rows per step, SM_IT steps (fixed count: fully unrolled, no
 // integer divisions).  Global loads go through sm_fill, which issues all of a thread's loads before the first LDS store -- one
@@ -448,8 +464,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     SM_STAMP(5);
     sm_store(X1, u.Sqi + off, M);
     sm_each(M, [&](int i, int j) { ninf += isinf(X1[i * SLD + j]) ? 1.0 : 0.0; });
-    l2 = block_sum(l2, red);
-    ninf = block_sum(ninf, red);
+    double unused = 0.0;
+    sm_block_sum3(l2, ninf, unused, red);
     if (t == 0) o[5 + 0] = 0.0, o[5 + 1] = 0.0, o[5 + 2] = 0.0, o[5 + 3] = l2, o[5 + 4] = ninf;   // KL partial "block 1"
     SM_STAMP(6);
     return;
@@ -545,9 +561,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     u.Ctri[off + (long long)i * M + j] = tv;
   });
   // KL partials (svmogp_inf.py:245-249), kl_terms_kernel's layout: "block 0" of the latent
-  tr = block_sum(tr, red);
-  ma = block_sum(ma, red);
-  l1 = block_sum(l1, red);
+  sm_block_sum3(tr, ma, l1, red);
   if (t == 0) o[0] = tr, o[1] = ma, o[2] = l1, o[3] = 0.0, o[4] = 0.0;
   SM_STAMP(8);
 }
