@@ -144,16 +144,12 @@ __device__ __forceinline__ void sm_gemm(const double* __restrict__ A, const doub
 // `scratch` >= 3 * NT / 64 doubles.
 __device__ __forceinline__ void sm_block_sum3(double& a, double& b, double& c, double* scratch);
 
-// Block barrier that orders LDS only: __syncthreads() also waits for the block's outstanding GLOBAL stores (the results every phase
-// streams out to HBM), a round trip of microseconds per phase at this kernel's clocks; nothing inside a block reads those back.
-__device__ __forceinline__ void sm_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 __device__ __forceinline__ void sm_block_sum3(double& a, double& b, double& c, double* scratch) {
   a = wave_sum(a), b = wave_sum(b), c = wave_sum(c);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  sm_barrier();                                         // (scratch may still be read from a previous call)
+  __syncthreads();                                         // (scratch may still be read from a previous call)
   if (lane == 0) scratch[w] = a, scratch[NT / 64 + w] = b, scratch[2 * (NT / 64) + w] = c;
-  sm_barrier();
+  __syncthreads();
   if (threadIdx.x == 0) {
     a = b = c = 0.0;
     for (int i = 0; i < NT / 64; ++i) a += scratch[i], b += scratch[NT / 64 + i], c += scratch[2 * (NT / 64) + i];
@@ -436,11 +432,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // ---- q(u) chain: L = flat_to_triang(L_flat) (svmogp_inf.py:193), S = L L^T (:194-195), S^-1 = dpotri(L) (:124) ------------
     for (long long e = (long long)q * NT + t; e < u.nzero; e += (long long)Q * NT) u.zero[e] = 0.0;   // (the bundle: see SmallU)
     sm_fill(X2, M, [&](int r, int c) { return (c <= r) ? u.Lflat[((long long)r * (r + 1) / 2 + c) * Q + q] : 0.0; });
-    sm_barrier();
+    __syncthreads();
     SM_STAMP(1);
     sm_store(X2, u.L + off, M);
     sm_gemm<false, true>(X2, X2, X0, M, 2);                // S = L L^T  -> X0
-    sm_barrier();
+    __syncthreads();
     SM_STAMP(2);
     sm_store(X0, u.S + off, M);
     __threadfence();                                       // S is in HBM (agent scope) ...
@@ -457,10 +453,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       } else
         sm_trtri_wave(X2, X3, M, lane);
     }
-    sm_barrier();
+    __syncthreads();
     SM_STAMP(4);
     sm_gemm<true, false>(X3, X3, X1, M, 1);                // S^-1 = L^-T L^-1  -> X1
-    sm_barrier();
+    __syncthreads();
     SM_STAMP(5);
     sm_store(X1, u.Sqi + off, M);
     sm_each(M, [&](int i, int j) { ninf += isinf(X1[i * SLD + j]) ? 1.0 : 0.0; });
@@ -478,7 +474,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     double* zs = X3;                                     // (free until the joint part) inducing inputs of the latent: [M][P]
     for (int e = t; e < M * P; e += NT) zs[e] = u.Z[(long long)(e / P) * u.ldz + q * P + (e % P)];
     if (t < M) vec[SM + t] = u.mu[(long long)t * Q + q];
-    sm_barrier();
+    __syncthreads();
     sm_each(M, [&](int i, int j) {
       double zi[P], zj[P];
 #pragma unroll
@@ -492,7 +488,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   if (t == 0) s_info = 0, s_progress = 0;
   for (int e = t; e < KL_BLOCKS * 5; e += NT)          // KL partials: blocks 0 and 1 are written below / by block (q, 1)
     if (e >= 10) o[e] = 0.0;
-  sm_barrier();
+  __syncthreads();
   SM_STAMP(1);
   if (u.stop_after == 1) return;
   if (u.stop_after == 6) return;
@@ -518,7 +514,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (i0 + e < M && lane < M) X3[(i0 + e) * SLD + lane] = v[e];
     }
   }
-  sm_barrier();
+  __syncthreads();
   SM_STAMP(2);
   if (t == 0) u.info[q] = s_info;                        // (non-zero: the engine falls back to the regular path and its ladder)
   if (u.stop_after == 2 || u.stop_after == 5) return;
@@ -527,9 +523,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   sm_each(M, [&](int i, int j) { u.Luu[off + (long long)i * M + j] = (j <= i) ? X0[i * SLD + j] : 0.0; });
   double l1 = 0.0;
   if (t < M) l1 = log(fabs(X0[t * SLD + t]));
-  sm_barrier();
+  __syncthreads();
   sm_gemm<true, false>(X1, X1, X0, M, 1);                // K_uu^-1 = L_uu^-T L_uu^-1            (util.py:199)            -> X0
-  sm_barrier();
+  __syncthreads();
   SM_STAMP(3);
   sm_store(X0, u.Kuui + off, M);
   double ma = 0.0, tr = 0.0;
@@ -545,11 +541,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   SM_STAMP(5);
   sm_each(M, [&](int i, int j) { tr += X0[i * SLD + j] * X3[i * SLD + j]; });
   sm_gemm<false, false>(X0, X3, X1, M);                  // K^-1 S                                                         -> X1
-  sm_barrier();
+  __syncthreads();
   SM_STAMP(6);
   sm_store(X1, u.KiS + off, M);
   sm_gemm<false, false>(X1, X0, X2, M);                  // K^-1 S K^-1                                                    -> X2
-  sm_barrier();
+  __syncthreads();
   SM_STAMP(7);
   sm_store(X2, u.KSK + off, M);
   sm_each(M, [&](int i, int j) {                         // C = K^-1 S K^-1 - K^-1 ; T = tril(C) + tril(C^T, -1)
@@ -625,7 +621,7 @@ __device__ __forceinline__ void finish_small_body(const SmallF& f, double* lds) 
   sm_fill(X0, M, [&](int i, int j) { return (j <= i) ? Hq[(long long)i * M + j] : Hq[(long long)j * M + i]; });
   sm_load(X1, f.Kuui + off, M, M);
   if (t < M) vec[t] = Hq[f.oR + t], vec[2 * SM + t] = f.a[(long long)q * M + t];
-  sm_barrier();
+  __syncthreads();
   if (role == 0) {
     // (the bundle itself keeps the full symmetric H_q, like launch_mirror_lower)
     sm_each(M, [&](int i, int j) {
@@ -643,28 +639,28 @@ __device__ __forceinline__ void finish_small_body(const SmallF& f, double* lds) 
       if (f.gmu2) f.gmu2[(long long)t * Q + q] = s - vec[2 * SM + t];
     }
   }
-  sm_barrier();
+  __syncthreads();
   sm_gemm<false, false>(X1, X2, X3, M);                  // G = K^-1 (H K^-1)  (dVE_dS, svmogp_inf.py:148)          X3
-  sm_barrier();
+  __syncthreads();
   // The regular path forms the lower tiles of G = K^-1 H K^-1 and mirrors them: exactly symmetric.  Same here.
   sm_each(M, [&](int i, int j) {
     if (j > i) X3[i * SLD + j] = X3[j * SLD + i];
   });
-  sm_barrier();
+  __syncthreads();
   if (role == 0) sm_store(X3, f.G + off, M);
   if (role == 0 && f.want_qu) {
     sm_load(X0, f.Sqi + off, M, M);                      // (H is no longer needed)
-    sm_barrier();
+    __syncthreads();
     sm_each(M, [&](int i, int j) {                       // dL/dS = G - (K^-1 - S^-1) / 2   (svmogp_inf.py:131,169)
       const double v = X3[i * SLD + j] - 0.5 * (X1[i * SLD + j] - X0[i * SLD + j]);
       X2[i * SLD + j] = v;
       f.dLdS[off + (long long)i * M + j] = v;
     });
-    sm_barrier();
+    __syncthreads();
     sm_load(X0, f.L + off, M, M);
-    sm_barrier();
+    __syncthreads();
     sm_gemm<false, false>(X2, X0, X1, M);                // dL/dS L (:175-177)  [X1: K^-1 is re-read from HBM below]
-    sm_barrier();
+    __syncthreads();
     sm_each(M, [&](int r, int c) {                       // GPy triang_to_flat of 2 dL/dS L
       if (c <= r) {
         const long long o = ((long long)r * (r + 1) / 2 + c) * Q + q;
@@ -672,17 +668,17 @@ __device__ __forceinline__ void finish_small_body(const SmallF& f, double* lds) 
         if (f.gL2) f.gL2[o] = 2.0 * X1[r * SLD + c];
       }
     });
-    sm_barrier();
+    __syncthreads();
   }
   if (role == 1) {
     sm_load(X0, f.KiS + off, M, M);
-    sm_barrier();
+    __syncthreads();
     sm_gemm<false, true>(X3, X0, X2, M);                 // G S K^-1 = G (K^-1 S)^T   (tmp_dv, svmogp_inf.py:151)    X2
-    sm_barrier();
+    __syncthreads();
     sm_store(X2, f.GSK + off, M);
     // dL_dKmm (svmogp_inf.py:130-133,151-154,166,170): dkmm_kernel's formula
     sm_load(X0, f.KSK + off, M, M);                      // (K^-1 S is no longer needed; K^-1 is still in X1)
-    sm_barrier();
+    __syncthreads();
     sm_each(M, [&](int i, int j) {
       const double kri = vec[SM + i], krj = vec[SM + j], ai = vec[2 * SM + i], aj = vec[2 * SM + j];
       const double xij = X3[i * SLD + j] - X2[i * SLD + j] - X2[j * SLD + i] - kri * aj;
@@ -693,7 +689,7 @@ __device__ __forceinline__ void finish_small_body(const SmallF& f, double* lds) 
       X0[i * SLD + j] = dve - dkl;
     });
     if (f.rowout) {
-      sm_barrier();
+      __syncthreads();
       switch (f.P) {
         case 1: sm_kzz_rows<1>(f, X0, q); break;
         case 2: sm_kzz_rows<2>(f, X0, q); break;
@@ -764,7 +760,7 @@ __global__ __launch_bounds__(NT) void small_fwd_kernel(SmallRows a) {
     if (t < M) av[t] = a.a[(long long)q * M + t];
     for (int e = t; e < M * P; e += NT) zs[e] = a.Z[(long long)(e / P) * a.ldz + q * P + (e % P)];
     for (int e = t; e < RB * P; e += NT) xs[e] = (e / P < nr) ? a.X[(n0 + e / P) * P + (e % P)] : 0.0;
-    sm_barrier();
+    __syncthreads();
     double* Khq = a.Kh + (long long)q * a.ldn * M;
 #pragma unroll
     for (int it = 0; it < SM_IT; ++it) {        // K^ tile: rbf_kernel<P, false>'s arithmetic (clip(r2) / l^2, no sqrt / divide)
@@ -782,7 +778,7 @@ __global__ __launch_bounds__(NT) void small_fwd_kernel(SmallRows a) {
         Kt[r * SLD + m] = k;
       }
     }
-    sm_barrier();
+    __syncthreads();
     // P~ micro-tile: rows r0..r0+3 of the block, columns c0..c0+3
     double acc[4][4];
 #pragma unroll
@@ -851,7 +847,7 @@ __global__ __launch_bounds__(NT) void small_fwd_kernel(SmallRows a) {
           for (int j = 0; j < 4; ++j)
             if (c0 + j < M) Ptq[(n0 + r0 + i) * M + c0 + j] = acc[i][j];
     }
-    sm_barrier();
+    __syncthreads();
   }
 }
 
@@ -900,7 +896,7 @@ __global__ __launch_bounds__(NT) void small_bwd_kernel(SmallRows a) {
       wt[t] = in ? a.alpha[o] : 0.0, wt[RB + t] = in ? a.beta[o] : 0.0;
       wt[2 * RB + t] = in ? a.alpha0[o] : 0.0, wt[3 * RB + t] = in ? a.beta0[o] : 0.0;
     }
-    sm_barrier();
+    __syncthreads();
     double* out = a.slab + ((long long)blockIdx.x * a.Q + q) * slab_q;
     // H_q partial: lower micro-tiles only (the bundle carries the lower triangle between begin and finish)
     if (m0 < M && c0 < M && c0 <= m0 + 3) {
@@ -947,7 +943,7 @@ __global__ __launch_bounds__(NT) void small_bwd_kernel(SmallRows a) {
 #pragma unroll
       for (int p = 0; p < P; ++p) out[(long long)M * M + M + (long long)m * P + p] = dz[p];
     }
-    sm_barrier();
+    __syncthreads();
   }
 }
 
