@@ -240,6 +240,20 @@ __device__ __forceinline__ void quad_body(const QuadArgs& a, unsigned blk, QuadS
   auto& s_var = sh.var;
   double& s_scale = sh.scale;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const long long n = ((long long)blk * 256 + t) / G;
+  const bool valid = n < a.N;                       // uniform per wave when G == 64
+  const bool lead = valid && (G == 1 || lane == 0);  // the lane that owns the row's outputs
+  const int Q = a.Q, J = a.dimf;
+  const int nscal = 2 + 2 * Q + J + Q * J;
+  // the row's inputs are requested BEFORE the weights are staged: one memory round trip for both (small models: the kernel is
+  // a chain of latencies)
+  double mu[HMOGP_MAXJ], vv[HMOGP_MAXJ], pq[HMOGP_MAXQ], cq[HMOGP_MAXQ];
+#pragma unroll
+  for (int q = 0; q < HMOGP_MAXQ; ++q) {
+    pq[q] = (valid && q < Q) ? a.p[q * a.ldn + n] : 0.0;
+    cq[q] = (valid && q < Q) ? a.c[q * a.ldn + n] : 0.0;
+  }
+  const double yv = valid ? a.y[n] : 0.0, yauxv = (valid && a.yaux) ? a.yaux[n] : 0.0;
   if (t < HMOGP_MAXQ * HMOGP_MAXJ) {
     const int q = t / HMOGP_MAXJ, j = t % HMOGP_MAXJ;
     const bool in = q < a.Q && j < a.dimf;
@@ -255,23 +269,11 @@ __device__ __forceinline__ void quad_body(const QuadArgs& a, unsigned blk, QuadS
     }
   }
   __syncthreads();
-  const long long n = ((long long)blk * 256 + t) / G;
-  const bool valid = n < a.N;                       // uniform per wave when G == 64
-  const bool lead = valid && (G == 1 || lane == 0);  // the lane that owns the row's outputs
-  const int Q = a.Q, J = a.dimf;
-  const int nscal = 2 + 2 * Q + J + Q * J;
   // contribution of this lane to block scalar `slot` (uniform slot; every lane of the wave calls)
   auto emit = [&](int slot, double val) {
     const double s = (G == 1) ? wave_sum(val) : val;
     if (lane == 0) red[w][slot] = s;
   };
-
-  double mu[HMOGP_MAXJ], vv[HMOGP_MAXJ], pq[HMOGP_MAXQ], cq[HMOGP_MAXQ];
-#pragma unroll
-  for (int q = 0; q < HMOGP_MAXQ; ++q) {
-    pq[q] = (valid && q < Q) ? a.p[q * a.ldn + n] : 0.0;
-    cq[q] = (valid && q < Q) ? a.c[q * a.ldn + n] : 0.0;
-  }
   bool neg = false;
 #pragma unroll
   for (int j = 0; j < HMOGP_MAXJ; ++j) {
@@ -293,7 +295,7 @@ __device__ __forceinline__ void quad_body(const QuadArgs& a, unsigned blk, QuadS
   o.ve = 0.0;
 #pragma unroll
   for (int j = 0; j < HMOGP_MAXJ; ++j) o.gm[j] = o.gv[j] = 0.0;
-  if (valid) lik_eval<LIK, CATD>(a.y[n], a.yaux ? a.yaux[n] : 0.0, mu, vv, a.lik_param, lane, etab[w], a.quirks, o);
+  if (valid) lik_eval<LIK, CATD>(yv, yauxv, mu, vv, a.lik_param, lane, etab[w], a.quirks, o);
   if (G == 64) {  // wave-per-row likelihoods: p / c were only needed for q(f); re-read them instead of keeping 2 x MAXQ
                   // doubles alive across the node loop (register pressure = occupancy of the quadrature)
 #pragma unroll
