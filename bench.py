@@ -91,6 +91,10 @@ def main():
     ap.add_argument("--other-steps", type=int, default=5, help="timed steps per other configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-wakeup", action="store_true", help="skip the ~0.3 s synthetic device wake-up before the warm-up steps")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="--gpus 1 only: run the DISTRIBUTED code path (nccl process group, StatsReducer negotiation, native RCCL "
+                         "communicator, hmogp_elbo_grad_sharded, the alternative-exchange-mode loop, teardown order) with a world "
+                         "of ONE rank -- a dry run of everything a multi-GPU launch executes, on a 1-GPU box")
     ap.add_argument("--no-exact-zero-pass", action="store_true", help="skip the extra (untimed-for-value) opt-in mode pass")
     args = ap.parse_args()
 
@@ -114,8 +118,13 @@ def main():
     guard = _StdoutToStderr()
     guard.__enter__()
     rccl_ranks = 1
-    if world > 1:
+    if args.force_dist and world != 1:
+        raise SystemExit("bench.py: --force-dist is the one-rank dry run of the distributed path (use it with --gpus 1)")
+    distm = world > 1 or args.force_dist       # the distributed code path (a world of one rank with --force-dist)
+    if distm:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(_free_port())
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         ones = torch.ones(1, dtype=torch.float64, device="cuda")
         dist.all_reduce(ones)                                   # proof that RCCL connected every rank
@@ -139,12 +148,14 @@ def main():
         a = pinned_empty(np.shape(prm[k]))
         a[...] = prm[k]
         prm[k] = a
-    reducer = hdist.StatsReducer(eng, device=local_rank) if world > 1 else None
+    if args.force_dist:
+        hdist.force_collectives(True)      # the negotiation's flag reductions are issued for real, also with one rank
+    reducer = hdist.StatsReducer(eng, device=local_rank, single_rank_exchange=args.force_dist) if distm else None
 
     def step(red=reducer):
         # world > 1, default: the engine holds its own RCCL communicator ("native") and hmogp_elbo_grad_sharded IS the step
         # (row pass -> pack / ncclAllReduce / unpack on the engine's stream -> replicated finish, one host sync at the end)
-        if world == 1:
+        if not distm:
             return eng.elbo_grad(**prm)
         if red.mode == "native":
             return eng.elbo_grad(sharded=True, **prm)
@@ -153,7 +164,7 @@ def main():
         return eng.step_finish()
 
     def fence():
-        if world > 1:
+        if distm:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -191,7 +202,7 @@ def main():
     closing_fence_ms = 1e3 * (time.perf_counter() - tf)
     # (the collector stays off for the other timed loops of this process; they collect explicitly between workloads)
     rows_all = [rows_rank]
-    if world > 1:
+    if distm:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -203,7 +214,7 @@ def main():
 
     # ---- N > 1: the same steps with the other exchange modes (reported, not `value`) ------------------------------------
     exchange_modes, repl_all = {}, None
-    if world > 1:
+    if distm:
         def timed_mode(red):
             for _ in range(max(1, args.warmup)):
                 step(red)
@@ -226,7 +237,7 @@ def main():
             if alt in exchange_modes:
                 continue
             try:
-                red_alt = hdist.StatsReducer(eng, device=local_rank, mode=alt)
+                red_alt = hdist.StatsReducer(eng, device=local_rank, mode=alt, single_rank_exchange=args.force_dist)
             except RuntimeError:            # not available on every rank (agreed collectively): nothing to time
                 continue
             exchange_modes[alt] = timed_mode(red_alt)
@@ -300,18 +311,20 @@ def main():
             line["reducer_mode"] = reducer.mode
             line["exchange_modes_ms_per_step"] = exchange_modes
             line["replicated_ms_per_rank"] = repl_all
-        if world == 1 and not args.no_exact_zero_pass:
+        if args.force_dist:
+            line["force_dist"] = True       # one-rank dry run of the distributed path: no other configurations, no CPU legs
+        if world == 1 and not distm and not args.no_exact_zero_pass:
             line["exact_zero_windows"] = exact_zero_pass(args, prm, X, Y, N, M, Q, P, out)
         # GPU legs first, CPU legs last: after the full-size CPU baseline (64 worker threads x BLAS threads, ~20 s of all host
         # cores) the launch-latency-bound chains of the small configurations measured 0.3 ms slower (host-side launch jitter)
-        if world == 1 and not args.no_other_configs:
+        if world == 1 and not distm and not args.no_other_configs:
             line["other_configs"] = other_configs(args)   # (the headline engine keeps its 40 GB of row workspaces: 288 GB of HBM)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not distm and not args.no_cpu_baseline:
             line.update(cpu_baselines(args, eng, prm, X, Y, N, M, Q, P))
             eng.close()
         print(json.dumps(line))
         sys.stdout.flush()
-    if world > 1:
+    if distm:
         if reducer is not None:
             reducer.close()                 # ncclCommDestroy of the library's own communicator, on every rank, before torch's
         dist.barrier()
@@ -653,6 +666,14 @@ def other_configs(args):
           "Df=14, 125000 of N_t=1M rows per task, M=1024, Q=4", 8 * 125000, 4, 1024, ms, cat, out,
           note="single-GPU measurement of a rank's share; the 8-GPU step adds one 16.9 MB all-reduce")
     eng.close()
+    # C4 at its FULL size on ONE GPU: 8 tasks x 1M rows streamed in eight pools of 2^20 rows (the K^ / P~ workspaces of a pool are
+    # 2 x 34 GB) -- the single-GPU denominator of the 8-GPU claim
+    eng, prm, X, Y, ms, cat, out = run("C4F", c4, 1000000, 1024, 4, 1, 20260933, steps=min(K, 3), warmup=1)
+    entry("C4 FULL SIZE on one GPU: T=8 [HetGaussian,Categorical(5),Beta,Exponential,Gaussian,Bernoulli,Poisson,Gamma] Df=14, "
+          "N_t=1M rows per task (8M rows, 8 pools), M=1024, Q=4", 8 * 1000000, 4, 1024, ms, cat, out,
+          note="denominator of the 8-GPU strong-scaling claim for config 4", steps_timed=min(K, 3))
+    eng.close()
+    del X, Y
     # C5 -- 2-D spatial, M = 2048, + predict_f on a 256 x 256 grid
     c5 = [("Categorical", {"K": 4}), ("Gaussian", {"sigma": 0.5})]
     eng, prm, X, Y, ms, cat, out = run("C5", c5, 50000, 2048, 2, 2, 20260934)

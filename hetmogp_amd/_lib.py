@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMOGP_LIB_PATH") or os.path.join(_HERE, "libhetmogp_hip.so")   # (override: A/B experiments)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 # likelihood ids (class names of the reference's likelihoods/<name>.py)
 LIK_GAUSSIAN, LIK_BERNOULLI, LIK_HETGAUSSIAN, LIK_CATEGORICAL, LIK_POISSON, LIK_EXPONENTIAL, LIK_GAMMA, LIK_BETA = range(8)
 LIK_IDS_BY_NAME = dict(Gaussian=0, Bernoulli=1, HetGaussian=2, Categorical=3, Poisson=4, Exponential=5, Gamma=6, Beta=7)
@@ -22,6 +22,7 @@ GROUP_QU, GROUP_HYPER, GROUP_Z, GROUP_ALL = 1, 2, 4, 7
 CFG_EXACT_ZERO_WINDOWS = 1
 CFG_CACHE_KUU = 2
 CFG_NO_SMALL_PATH = 4
+CFG_STRICT_QF = 8
 QUIRK_GAMMA_BETA_PI, QUIRK_CATEGORICAL_DM, QUIRK_STALE_W, QUIRK_W_DIAG, QUIRK_KAPPA_DIAG = 1, 2, 4, 8, 16
 QUIRKS_REFERENCE, QUIRKS_EXACT = 31, 0
 
@@ -106,6 +107,7 @@ EXPORTS = {
     "hmogp_jitchol_inv": (C.c_int, [C.c_int32, c_double_p, C.c_int32, C.c_int32, c_int32_p, c_double_p, c_double_p,
                                     c_int32_p]),
     "hmogp_potri": (C.c_int, [C.c_int32, c_double_p, C.c_int32, C.c_int32, c_double_p]),
+    "hmogp_potrs_rows": (C.c_int, [C.c_int32, c_double_p, C.c_int32, c_double_p, C.c_int64, c_double_p]),
     "hmogp_gemm_f64": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, c_double_p,
                                  C.c_int32, c_double_p, C.c_int32, C.c_double, c_double_p, C.c_int32]),
     "hmogp_predictive": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int64, c_double_p, c_double_p, c_double_p,

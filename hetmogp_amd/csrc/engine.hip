@@ -223,6 +223,33 @@ void jitchol_batched(const double* Kuu, double* Luu, int Q, int M, const double*
   jitchol_resolve(Kuu, Luu, Q, M, diag_mean, rung_io, d_info, d_jit, dscr, st, js);
 }
 
+// V <- V Luu^-T Luu^-1 = dpotrs(Luu, V^T)^T for the n rows of V (n x M row-major, in place; batched over Q with strides sV / sL):
+// two BLOCKED TRIANGULAR SOLVES, 32-column diagonal blocks by true substitution (trsm_diag_kernel), the updates between them as
+// GEMMs (alpha = -1, beta = 1) -- backward stable like LAPACK's dtrsm.  Used by the strict q(f) mode and hmogp_potrs_rows.
+void potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL, int M, long long n, int Q, hipStream_t st) {
+  // C[:, c0:c0+nc] -= V[:, a0:a0+k] op(B)   (op(B) = Luu[c0.., a0..]^T for the forward solve, Luu[a0.., c0..] for the backward one)
+  auto update = [&](int c0, int nc, int a0, int k, const double* B_, int b_kmajor) {
+    GemmArgs g;
+    g.A = V + a0, g.lda = M, g.a_kmajor = 0, g.sA = sV;
+    g.B = B_, g.ldb = M, g.b_kmajor = b_kmajor, g.sB = sL;
+    g.C = V + c0, g.ldc = M, g.sC = sV;
+    g.M = (int)n, g.N = nc, g.K = k;
+    g.alpha = -1.0, g.beta = 1.0;
+    g.nbatch = Q;
+    launch_gemm_f64(g, st);
+  };
+  for (int j0 = 0; j0 < M; j0 += 32) {                        // X Luu^T = V
+    const int nb = std::min(32, M - j0);
+    if (j0 > 0) update(j0, nb, 0, j0, Luu + (long long)j0 * M, 0);
+    launch_trsm_diag(0, V, sV, Luu, sL, M, j0, nb, n, Q, st);
+  }
+  for (int j0 = ((M - 1) / 32) * 32; j0 >= 0; j0 -= 32) {     // A Luu = X
+    const int nb = std::min(32, M - j0), j1 = j0 + nb;
+    if (j1 < M) update(j0, nb, j1, M - j1, Luu + (long long)j1 * M + j0, 1);
+    launch_trsm_diag(1, V, sV, Luu, sL, M, j0, nb, n, Q, st);
+  }
+}
+
 // ------------------------------------------------------------------------------------ RCCL, resolved at run time
 // The exchange step of a row-sharded run is ONE ncclAllReduce on the engine's own stream.  librccl is not a
 // link-time dependency: a single-GPU user never needs it, and in a process that has already loaded a librccl.so.1 (PyTorch
@@ -279,6 +306,13 @@ struct hmogp_engine {
   int T = 0, Q = 0, M = 0, P = 0, Df = 0, device = 0;
   long long chunk = 1048576;  // rows per pool (hmogp_config.chunk_rows); workspaces are sized by the rows actually streamed
   bool use_windows = false, cache_kuu = false, kuu_key_valid = false, no_small = false;
+  // [r5] STRICT q(f) (HMOGP_CFG_STRICT_QF): q(f)'s mean and variance and the row-side gradient statistics are formed the way the
+  // reference forms them -- A = K^ Kuu^-1 through two triangular factors of Luu (its dpotrs, svmogp_inf.py:214), v = ||L_q^T A^T||^2 -
+  // A . K^ (:217-218), dVE_dmu = A^T alpha (:144), dVE_dS = A^T diag(beta) A (:145-148), dL_dKmn through A (S Kuu^-1 - I) (:157-161)
+  // -- instead of through the explicit C_q = Kuu^-1 S Kuu^-1 - Kuu^-1, which differs from them by ~cond(Kuu) eps (1e-4 relative in
+  // g_W / g_kappa / g_Z once GPy's jitter ladder is taken, cond ~ 1e7).  ~3.5x the forward work; for parity in that regime.
+  bool strict = false;
+  DevBuf Dm, Ah, vpg, vcg;
   unsigned quirks = HMOGP_QUIRKS_REFERENCE;
   std::vector<double> h_Z, kuu_key;
   std::vector<int> rung_request, kuu_rung;
@@ -622,6 +656,11 @@ struct hmogp_engine {
     use_windows = (c->flags & HMOGP_CFG_EXACT_ZERO_WINDOWS) != 0;
     cache_kuu = (c->flags & HMOGP_CFG_CACHE_KUU) != 0;
     no_small = (c->flags & HMOGP_CFG_NO_SMALL_PATH) != 0;
+    strict = (c->flags & HMOGP_CFG_STRICT_QF) != 0;
+    if (strict) no_small = true;     // (the fused small-model kernels carry the explicit-inverse algebra only)
+    if (strict && use_windows) throw EngineError{HMOGP_E_INVALID, "HMOGP_CFG_STRICT_QF and HMOGP_CFG_EXACT_ZERO_WINDOWS exclude each other"};
+    if (c->flags & ~(HMOGP_CFG_EXACT_ZERO_WINDOWS | HMOGP_CFG_CACHE_KUU | HMOGP_CFG_NO_SMALL_PATH | HMOGP_CFG_STRICT_QF))
+      throw EngineError{HMOGP_E_INVALID, "unknown bits in hmogp_config.flags"};
     quirks = c->quirks;
     if (quirks & ~HMOGP_QUIRKS_REFERENCE) throw EngineError{HMOGP_E_INVALID, "unknown bits in hmogp_config.quirks"};
     if (use_windows && M > 8192) throw EngineError{HMOGP_E_INVALID, "exact-zero windows support M <= 8192"};
@@ -715,6 +754,7 @@ struct hmogp_engine {
     // parameter + M x M buffers
     const size_t mmq = sizeof(double) * MM * Q;
     for (DevBuf* b : {&Kuu, &Luu, &Kuui, &L, &S, &KiS, &KSK, &C, &Ctri, &Sqi, &tmpA, &tmpB, &HK, &G, &GSK, &dKmm, &dLdS}) b->ensure(mmq, true);
+    if (strict) Dm.ensure(mmq, true);
     // ALL parameters live in ONE device block [ hypers + jitter | Z | m_u | L_flat ] (segments 16-byte aligned): large models fill
     // the segments by separate copies straight from the caller's arrays, small-problem mode by ONE copy from a page-locked image
     // (a host-bound small-model step pays ~4-8 us of API time and ~4 us of device time per hipMemcpyAsync)
@@ -766,6 +806,7 @@ struct hmogp_engine {
     staged_key.clear();
     drop_graphs(true);   // (the evaluation that grows the workspaces runs normally to its end: its key stays warm)
     for (DevBuf* b : {&vp, &vc, &vpt, &vct, &valpha, &vbeta, &valpha0, &vbeta0}) b->ensure(nv, true);
+    if (strict) Ah.ensure(nm), vpg.ensure(nv, true), vcg.ensure(nv, true);
     colpart.ensure(sizeof(double) * std::max((rows + 255) / 256, (std::min<long long>(rows, 16384) + 31) / 32) * M * (1 + P) * Q);
     quadpart.ensure(sizeof(double) * (rows * 64 / 256 + 1 + HMOGP_QUAD_MULTI) * HMOGP_MAXSCAL);
     fwdpart.ensure(sizeof(double) * 4 * FWD_PARTS * ((M + 127) / 128) * rows * Q);  // 4 statistics x FWD_PARTS wave columns per tile
@@ -971,7 +1012,15 @@ struct hmogp_engine {
     // behind ~0.6 ms of queued work -- no host round trip in the latency-bound chain.  If a latent did fail (GPy's jitter
     // ladder is needed: rare), the ladder runs synchronously as before and the same launches are simply issued again.
     auto tail = [&](bool first) {
-      if (!kuu_hit) {
+      if (!kuu_hit && strict) {
+        // strict mode: K_uu^-1 = dpotrs(Luu, I) by the blocked substitution, lower triangle mirrored like GPy's dpotri wrapper
+        // (util.py:199).  The merge-based triangular inverse below is ~100x further from LAPACK's dpotri where it matters here
+        // (|K_uu^-1 K_uu - I| 8.6e-8 against 3e-10 at cond 1e7) -- invisible at cond <= 1e5, 2e-8 of g_W / g_Z at 1e7.
+        if (first) HIP_TRY(hipStreamWaitEvent(st, ev_zero, 0));
+        launch_identity(Kuui.d(), Q, M, st);
+        potrs_rows_inplace(Kuui.d(), MM, Luu.d(), MM, M, M, Q, st);
+        launch_mirror_lower(Kuui.d(), Q, M, MM, st);
+      } else if (!kuu_hit) {
         if (first) HIP_TRY(hipStreamWaitEvent(st, ev_zero, 0));     // (tmpA zeroed on the third stream, above)
         launch_trtri_batched(Luu.d(), tmpA.d(), tmpB.d(), Q, M, st, first);
         launch_ltl_batched(tmpA.d(), Kuui.d(), Q, M, st);           // K_uu^-1          (util.py:199)
@@ -979,6 +1028,7 @@ struct hmogp_engine {
       launch_gemv_batched(Kuui.d(), dmu.d(), a.d(), Q, M, 1, Q, st);  // a = K_uu^-1 m
       HIP_TRY(hipStreamWaitEvent(st, ev_S, 0));
       mm(Kuui.d(), false, S.d(), true, KiS.d());
+      if (strict) launch_strict_d(KiS.d(), Dm.d(), Q, M, st);        // S K_uu^-1 - I   (svmogp_inf.py:157-158)
       mm(KiS.d(), false, Kuui.d(), true, KSK.d());
       launch_sub(KSK.d(), Kuui.d(), C.d(), MM * Q, st);             // C = K^-1 S K^-1 - K^-1
       launch_tri_fold(C.d(), Ctri.d(), Q, M, st);                   // x^T Ctri x == x^T C x with a triangular matrix
@@ -1051,7 +1101,7 @@ struct hmogp_engine {
       RbfBatch rbt;
       rbt.nq = Q, rbt.var = dvar.d(), rbt.ell = dell.d(), rbt.sZ = P, rbt.sK = sK, rbt.sWin = 2 * wtiles;
       const long long n = pl.back().off + pl.back().n;
-      launch_rbf(Xws.d(), P, n, P, dZ.d(), ldz, M, 0.0, 1.0, Kh.d(), false, stream, nullptr, false, &rbt);
+      launch_rbf(Xws.d(), P, n, P, dZ.d(), ldz, M, 0.0, 1.0, Kh.d(), false, stream, nullptr, strict, &rbt);
       return;
     }
     Scope sc(this, CAT_RBF, (int)(seg_end - seg_begin) + (use_windows ? 3 * Q : 0), stream);
@@ -1074,7 +1124,7 @@ struct hmogp_engine {
       const long long step = (stream != st && !use_windows) ? (chunk_env > 0 ? chunk_env : (st2_masked ? 100000LL : KUF_CHUNK_ROWS)) : sg.n;
       for (long long r = 0; r < sg.n; r += step)
         launch_rbf(Xs + r * P, P, std::min(step, sg.n - r), P, dZ.d(), ldz, M, 0.0, 1.0, Kh.d() + (sg.off + r) * M, false, stream,
-                   rw, false, &rbt);
+                   rw, strict, &rbt);   // (strict q(f): GPy's rounding order, sqrt and divide included)
     }
   }
 
@@ -1091,6 +1141,40 @@ struct hmogp_engine {
     for (auto& sg : pl)
       HIP_TRY(hipMemcpyAsync(Xws.d() + sg.off * P, tasks[sg.t].X.d() + sg.r0 * P, sizeof(double) * sg.n * P,
                              hipMemcpyDeviceToDevice, stream));
+  }
+
+  // strict q(f): the solve-based forms of svmogp_inf.py:212-218 for the n pool rows whose K^ sits in Kh (all latents batched).
+  // A = K^ Kuu^-1 = dpotrs(Luu, K^T)^T by two BLOCKED TRIANGULAR SOLVES against Luu: 32-column diagonal blocks by true substitution
+  // (trsm_diag_kernel), the updates between them as GEMMs -- backward stable like LAPACK's dtrsm.  (Round 5 first used two
+  // products with the explicit Luu^-1: m_fd was then 9e-8 of its scale away from the reference at cond(K_uu) = 1e7, 1.4e-2 at
+  // cond 1e12; with the substitution 3e-10 / the reference's own rounding sensitivity.)
+  void strict_forward(long long n, const double* X, bool grads, bool hyper) {
+    const long long MM = (long long)M * M, ldn = ws_rows, sK = ldn * M;
+    Scope sc(this, CAT_FWD, 4 * ((M + 31) / 32) + (grads ? 4 : 2));
+    auto rows_gemm = [&](const double* A_, const double* B_, int b_kmajor, int b_tri, double* C_) {
+      GemmArgs g;
+      g.A = A_, g.lda = M, g.a_kmajor = 0, g.sA = sK;
+      g.B = B_, g.ldb = M, g.b_kmajor = b_kmajor, g.sB = MM, g.b_tri = b_tri;
+      g.C = C_, g.ldc = M, g.sC = sK;
+      g.M = (int)n, g.N = M, g.K = M;
+      g.nbatch = Q;
+      launch_gemm_f64(g, st);
+    };
+    for (int q = 0; q < Q; ++q)
+      HIP_TRY(hipMemcpyAsync(Ah.d() + q * sK, Kh.d() + q * sK, sizeof(double) * n * M, hipMemcpyDeviceToDevice, st));
+    potrs_rows_inplace(Ah.d(), sK, Luu.d(), MM, M, n, Q, st);   // A = dpotrs(Luu, K^T)^T        (svmogp_inf.py:214-215)
+    rows_gemm(Ah.d(), L.d(), 1, +1, Pt.d());        // T = A L_q    = dtrmm(L_q^T, R)^T          (:217)
+    StrictRows sr;
+    sr.M = M, sr.Q = Q, sr.P = P, sr.ldz = Q * P, sr.n = n, sr.ldn = ldn, sr.sK = sK, sr.sZ = P;
+    sr.Kh = Kh.d(), sr.Ah = Ah.d(), sr.Tt = Pt.d(), sr.Pt = Pt.d(), sr.mu = dmu.d(), sr.a = a.d();
+    sr.X = X, sr.Z = dZ.d(), sr.ell = dell.d();
+    sr.p = vp.d(), sr.c = vc.d(), sr.pg = vpg.d(), sr.cg = vcg.d(), sr.pt = hyper ? vpt.d() : nullptr, sr.ct = hyper ? vct.d() : nullptr;
+    sr.phase = 0;
+    launch_strict_rowstats(sr, st);                 // p = A m, c = rowsum(T^2) - rowsum(A .* K^)   (:216, :218)
+    if (!grads) return;
+    rows_gemm(Ah.d(), Dm.d(), 1, 0, Pt.d());        // P~ = A (S Kuu^-1 - I)                      (:157-161)
+    sr.phase = 1;
+    launch_strict_rowstats(sr, st);                 // K^ a, rowsum(P~ .* K^) and their r2-weighted twins
   }
 
   // ------------------------------------------------------------------------------------------ row pass
@@ -1150,6 +1234,7 @@ struct hmogp_engine {
           qa.Df = Df, qa.d0 = k.d0;
         }
         qa.quirks = quirks;
+        if (strict && want_hyper) qa.pg = vpg.d() + sg.off, qa.cg = vcg.d() + sg.off;
         qa.alpha = valpha.d() + sg.off, qa.beta = vbeta.d() + sg.off;
         qa.alpha0 = valpha0.d() + sg.off, qa.beta0 = vbeta0.d() + sg.off;
         qa.partials = quadpart.d();
@@ -1177,7 +1262,8 @@ struct hmogp_engine {
         // (P > 1: more arithmetic per byte -- a block streams 4.8 instead of 6.3 GB/s at P = 2 -- so proportionally more of them)
         const int cap = cap_env >= 0 ? cap_env : (use_windows ? 0 : std::max(48, (int)(196608.0 * (1.0 + 0.35 * (P - 1)) / std::max(1, M))));
         launch_colstats(Kh.d() + off * M, Pt.d() + off * M, a.d(), valpha.d() + off, valpha0.d() + off, vbeta0.d() + off,
-                        X + off * P, P, dZ.d(), ldz, rows, M, (int)csplit, want_z, colpart.d() + slab_first * clen, st2, cw, &cb, cap);
+                        X + off * P, P, dZ.d(), ldz, rows, M, (int)csplit, want_z, colpart.d() + slab_first * clen, st2, cw, &cb, cap,
+                        strict ? Ah.d() + off * M : nullptr);
       };
 
       SmallRows sr;
@@ -1191,6 +1277,9 @@ struct hmogp_engine {
         sr.slab = smallslab.d(), sr.stats = stats.d(), sr.NG = NG, sr.per_q = per_q, sr.oR = oR, sr.oDZ = oDZ;
         Scope sc(this, CAT_FWD, 1);
         launch_small_fwd(sr, st);      // K^ + P~ = K^ C_q + row statistics, one launch for all tasks and latents of the pool
+      } else if (strict) {
+        if (prefetched) HIP_TRY(hipStreamWaitEvent(st, ev_kuf, 0));
+        strict_forward(n, X, want_hyper || want_z, want_hyper);
       } else
       {
         const long long off = 0, rows = n;
@@ -1267,8 +1356,9 @@ struct hmogp_engine {
         const int ksplit = use_windows ? std::min(8, gram_ksplit(n, M)) : gram_ksplit(n, M);
         slabs.ensure(sizeof(double) * MM * ksplit * Q, true);
         GemmArgs g;
-        g.A = Kh.d(), g.lda = M, g.a_kmajor = 1, g.sA = sK;
-        g.B = Kh.d(), g.ldb = M, g.b_kmajor = 1, g.sB = sK;
+        // (strict q(f): the Gram of A = K^ Kuu^-1 IS dVE_dS, svmogp_inf.py:145-148)
+        g.A = strict ? Ah.d() : Kh.d(), g.lda = M, g.a_kmajor = 1, g.sA = sK;
+        g.B = g.A, g.ldb = M, g.b_kmajor = 1, g.sB = sK;
         g.kscale = vbeta.d(), g.sS = ldn;
         g.C = slabs.d(), g.ldc = M, g.sC = MM * ksplit;
         g.M = g.N = M, g.K = (int)n;
@@ -1332,7 +1422,9 @@ struct hmogp_engine {
         const char* e = getenv("HMOGP_SMALL_PATH");
         return e ? atoi(e) : 1;
       }();
-      small_path = small_mode && M <= HMOGP_SMALL_M && path_env != 0 && !small_veto;
+      // (with a communicator attached the path must not depend on this rank's row count: every rank takes the regular kernels,
+      //  so that the replicated M x M algebra -- and with it the never re-synchronised resident q(u) replicas -- rounds alike)
+      small_path = small_mode && M <= HMOGP_SMALL_M && path_env != 0 && !small_veto && !comm;
       small_info_pending = false;
       static const int rows_env = [] {   // HMOGP_SMALL_ROWS=0: the regular row-pass kernels behind the fused M x M kernels (A/B runs)
         const char* e = getenv("HMOGP_SMALL_ROWS");
@@ -1447,10 +1539,15 @@ struct hmogp_engine {
     {
       Scope sc(this, CAT_MM, 0);
       launch_mirror_lower(Hq(0), Q, M, per_q, st);                   // the row pass / the exchange fill the lower triangle
-      mm(Hq(0), false, Kuui.d(), true, HK.d(), 1.0, per_q);          // H K^-1
-      mm(Kuui.d(), false, HK.d(), true, G.d(), 1.0, -1, -1, nullptr, 0, 0, true);  // G = K^-1 H K^-1 (dVE_dS, svmogp_inf.py:148):
-      launch_mirror_lower(G.d(), Q, M, MM, st);                      // symmetric -> lower tiles only, then mirrored
-      launch_gemv_batched(Kuui.d(), Hq(0) + oR, Kr.d(), Q, M, per_q, 1, st);  // K^-1 r  (dVE_dmu, :144)
+      if (strict) {   // the bundle already holds dVE_dS = A^T diag(beta) A and dVE_dmu = A^T alpha (svmogp_inf.py:144-148)
+        HIP_TRY(hipMemcpy2DAsync(G.p, sizeof(double) * MM, Hq(0), sizeof(double) * per_q, sizeof(double) * MM, Q, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpy2DAsync(Kr.p, sizeof(double) * M, Hq(0) + oR, sizeof(double) * per_q, sizeof(double) * M, Q, hipMemcpyDeviceToDevice, st));
+      } else {
+        mm(Hq(0), false, Kuui.d(), true, HK.d(), 1.0, per_q);          // H K^-1
+        mm(Kuui.d(), false, HK.d(), true, G.d(), 1.0, -1, -1, nullptr, 0, 0, true);  // G = K^-1 H K^-1 (dVE_dS, svmogp_inf.py:148):
+        launch_mirror_lower(G.d(), Q, M, MM, st);                      // symmetric -> lower tiles only, then mirrored
+        launch_gemv_batched(Kuui.d(), Hq(0) + oR, Kr.d(), Q, M, per_q, 1, st);  // K^-1 r  (dVE_dmu, :144)
+      }
       // two independent tails: the K_uu-side gradients stay on the main stream, the q(u) gradients and the KL terms
       // go to the second one
       HIP_TRY(hipEventRecord(ev_fork, st));
@@ -1679,6 +1776,7 @@ struct hmogp_engine {
       }
       qa.scale = h_bs[sg.t];
       qa.quirks = quirks;
+      if (strict) qa.pg = vpg.d() + sg.off, qa.cg = vcg.d() + sg.off;
       qa.alpha = valpha.d() + sg.off, qa.beta = vbeta.d() + sg.off;      // rewritten with identical values
       qa.alpha0 = valpha0.d() + sg.off, qa.beta0 = vbeta0.d() + sg.off;
       qa.partials = quadpart.d();
@@ -1788,7 +1886,13 @@ struct hmogp_engine {
     for (long long r0 = 0; r0 < Nnew; r0 += ldn) {
       const long long n = std::min(ldn, Nnew - r0);
       HIP_TRY(hipMemcpyAsync(dX.p, Xnew + r0 * P, sizeof(double) * n * P, hipMemcpyHostToDevice, st));
-      for (int q = 0; q < Q; ++q) {
+      if (strict) {
+        RbfBatch rbt;
+        rbt.nq = Q, rbt.var = dvar.d(), rbt.ell = dell.d(), rbt.sZ = P, rbt.sK = ldn * M;
+        launch_rbf(dX.d(), P, n, P, dZ.d(), ldz, M, 0.0, 1.0, Kh.d(), false, st, nullptr, true, &rbt);
+        strict_forward(n, dX.d(), false, false);
+      }
+      for (int q = 0; q < Q && !strict; ++q) {
         double* kh = Kh.d() + (long long)q * ldn * M;
         double* pt = Pt.d() + (long long)q * ldn * M;
         launch_rbf(dX.d(), P, n, P, dZ.d() + q * P, ldz, M, h_var[q], h_ell[q], kh, false, st, nullptr, false);
@@ -2153,6 +2257,21 @@ int hmogp_potri(int32_t device, const double* L, int32_t Q, int32_t M, double* S
     launch_ltl_batched(dLi.d(), dO.d(), Q, M, nullptr);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(Sinv, dO.p, sizeof(double) * MM * Q, hipMemcpyDeviceToHost));
+  });
+}
+
+int hmogp_potrs_rows(int32_t device, const double* L, int32_t M, const double* B, int64_t n, double* out) {
+  return guarded(nullptr, [&] {
+    if (!L || !B || !out || M < 1 || n < 0) throw EngineError{HMOGP_E_INVALID, "bad potrs arguments"};
+    need_device(device);
+    HIP_TRY(hipSetDevice(device));
+    DevBuf dL, dV;
+    dL.ensure(sizeof(double) * M * M), dV.ensure(sizeof(double) * std::max<long long>(1, n) * M);
+    HIP_TRY(hipMemcpy(dL.p, L, sizeof(double) * M * M, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dV.p, B, sizeof(double) * n * M, hipMemcpyHostToDevice));
+    potrs_rows_inplace(dV.d(), n * M, dL.d(), (long long)M * M, M, n, 1, nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dV.p, sizeof(double) * n * M, hipMemcpyDeviceToHost));
   });
 }
 

@@ -5,6 +5,8 @@
 void launch_add_diag_copy(const double* src, double* dst, int Q, int M, const double* d_jit, hipStream_t s);
 void launch_sub(const double* A, const double* B, double* C, long long n, hipStream_t s);
 void launch_tri_fold(const double* C, double* T, int Q, int M, hipStream_t s);  // T = tril(C) + tril(C^T, -1)
+void launch_identity(double* A, int Q, int M, hipStream_t s);   // A[q] = I
+void launch_strict_d(const double* KiS, double* D, int Q, int M, hipStream_t s);  // D = KiS^T - I  (strict q(f))
 #define KL_BLOCKS 64
 // out[(q*KL_BLOCKS + b)*5 + {0..4}] = block partials of sum(Kuui.*S), m^T a, sum log|diag Luu|, sum log|diag L|,
 // #inf(Sqi) (Sqi may be nullptr); the host adds the KL_BLOCKS partials in order

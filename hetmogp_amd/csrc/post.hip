@@ -23,6 +23,20 @@ __global__ void sub_kernel(const double* __restrict__ A, const double* __restric
   for (; i < n; i += stride) C[i] = A[i] - B[i];
 }
 
+__global__ void identity_kernel(double* __restrict__ A, int M) {
+  const long long o = (long long)blockIdx.z * M * M;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c < M) A[o + (long long)r * M + c] = (r == c) ? 1.0 : 0.0;
+}
+
+// strict q(f): D = (Kuu^-1 S)^T - I = S Kuu^-1 - I, the right factor of P~ = A D (svmogp_inf.py:157-159: tmp = 2 (S Kuui - I))
+__global__ void strict_d_kernel(const double* __restrict__ KiS, double* __restrict__ D, int M) {
+  const long long o = (long long)blockIdx.z * M * M;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c >= M) return;
+  D[o + (long long)r * M + c] = KiS[o + (long long)c * M + r] - (r == c ? 1.0 : 0.0);
+}
+
 // T = tril(C) + tril(C^T, -1): the lower-triangular matrix with x^T T x == x^T C x (C need not be exactly symmetric).
 // With it the quadratic forms k^T C k of the forward contraction cost half the products (GemmArgs::b_tri).
 __global__ void tri_fold_kernel(const double* __restrict__ C, double* __restrict__ T, int M) {
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(256) void kzz_rows_kernel(const double* __restrict_
     s1 += ek;
     s2 += ek * r2;
 #pragma unroll
-    for (int p = 0; p < P; ++p) gz[p] += (ek + ekt) * (zj[p] - zm[p]);
+    for (int p = 0; p < P; ++p) gz[p] += (r2 != 0.0) ? (ek + ekt) * (zj[p] - zm[p]) : 0.0;   // (quirk Q10: GPy gradients_X drops r == 0)
   }
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
@@ -294,6 +308,12 @@ void launch_add_diag_copy(const double* src, double* dst, int Q, int M, const do
 void launch_sub(const double* A, const double* B, double* C, long long n, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(sub_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, s, A, B, C, n);
+}
+void launch_identity(double* A, int Q, int M, hipStream_t s) {
+  hipLaunchKernelGGL(identity_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, A, M);
+}
+void launch_strict_d(const double* KiS, double* D, int Q, int M, hipStream_t s) {
+  hipLaunchKernelGGL(strict_d_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, KiS, D, M);
 }
 void launch_tri_fold(const double* C, double* T, int Q, int M, hipStream_t s) {
   hipLaunchKernelGGL(tri_fold_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, C, T, M);

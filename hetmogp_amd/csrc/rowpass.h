@@ -39,7 +39,26 @@ struct QuadArgs {
   double* out_v = nullptr;
   double* out_gm = nullptr;            // optional [N][dimf]: scaled d ve / d m, d ve / d v (inner-protocol debug export)
   double* out_gv = nullptr;
+  // strict q(f) (HMOGP_CFG_STRICT_QF): p / c above are the solve-based forms (q(f) of svmogp_inf.py:212-218); the block scalars
+  // sa / swk take these explicit-inverse forms instead (K^ a, rowsum(P~ .* K^): the reference's gradient code, :157-161)
+  const double* pg = nullptr;          // [Q][ldn] or nullptr (= p)
+  const double* cg = nullptr;          // [Q][ldn] or nullptr (= c)
 };
+
+// strict q(f): the row statistics of the solve-based forms (rowpass.hip: strict_rowstats_kernel)
+struct StrictRows {
+  int phase = 0, M = 0, Q = 1, P = 1, ldz = 0;
+  long long n = 0, ldn = 0, sK = 0, sZ = 0;
+  const double *Kh = nullptr, *Ah = nullptr, *Tt = nullptr, *Pt = nullptr;   // [Q][sK] row-major n x M
+  const double* mu = nullptr;     // [M][Q] q_u_means
+  const double* a = nullptr;      // [Q][M] Kuu^-1 m
+  const double *X = nullptr, *Z = nullptr, *ell = nullptr;
+  double *p = nullptr, *c = nullptr, *pg = nullptr, *cg = nullptr, *pt = nullptr, *ct = nullptr;   // [Q][ldn]
+};
+void launch_strict_rowstats(const StrictRows& a, hipStream_t s);
+// one <= 32-column diagonal block of the blocked triangular solves V L^T = B (dir 0) / A L = V (dir 1), in place, batched over Q
+void launch_trsm_diag(int dir, double* V, long long sV, const double* L, long long sL, int M, int j0, int nb, long long n, int Q,
+                      hipStream_t s);
 
 // [r4] every segment (task x row range) of a pool in one launch -- small models only: the weights are read from device memory
 #define HMOGP_QUAD_MULTI 8
@@ -102,7 +121,7 @@ void launch_windows(const double* X, long long N, int P, const double* Z, int ld
 void launch_colstats(const double* Kh, const double* Pt, const double* a, const double* alpha, const double* alpha0,
                      const double* beta0, const double* X, int P, const double* Z, int ldz, long long N, int M, int rows,
                      bool want_z, double* partials, hipStream_t s, const int* colwin = nullptr, const ColBatch* batch = nullptr,
-                     int max_blocks = 0);
+                     int max_blocks = 0, const double* Ar = nullptr);
 void launch_reduce_rows(const double* partials, long long nrows, int len, const long long* off, double* dst, bool accumulate,
                         hipStream_t s);
 void launch_reduce_slabs(const double* slabs, int nslabs, long long stride, long long len, double* dst, bool accumulate,

@@ -296,12 +296,16 @@ __device__ __forceinline__ void quad_body(const QuadArgs& a, unsigned blk, QuadS
 #pragma unroll
   for (int j = 0; j < HMOGP_MAXJ; ++j) o.gm[j] = o.gv[j] = 0.0;
   if (valid) lik_eval<LIK, CATD>(yv, yauxv, mu, vv, a.lik_param, lane, etab[w], a.quirks, o);
-  if (G == 64) {  // wave-per-row likelihoods: p / c were only needed for q(f); re-read them instead of keeping 2 x MAXQ
-                  // doubles alive across the node loop (register pressure = occupancy of the quadrature)
+  if (G == 64 || a.pg) {  // wave-per-row likelihoods: p / c were only needed for q(f); re-read them instead of keeping 2 x MAXQ
+                          // doubles alive across the node loop (register pressure = occupancy of the quadrature).
+                          // Strict q(f) (a.pg != nullptr): the block scalars sa / swk take the explicit-inverse forms K^ a and
+                          // rowsum(P~ .* K^) the reference's gradient code uses (svmogp_inf.py:157-161), q(f) took the solve-based ones
+    const double* pp = a.pg ? a.pg : a.p;
+    const double* cc = a.pg ? a.cg : a.c;
 #pragma unroll
     for (int q = 0; q < HMOGP_MAXQ; ++q) {
-      pq[q] = (valid && q < Q) ? a.p[q * a.ldn + n] : 0.0;
-      cq[q] = (valid && q < Q) ? a.c[q * a.ldn + n] : 0.0;
+      pq[q] = (valid && q < Q) ? pp[q * a.ldn + n] : 0.0;
+      cq[q] = (valid && q < Q) ? cc[q * a.ldn + n] : 0.0;
     }
   }
   if (a.out_mu && lead) {
@@ -378,6 +382,7 @@ __global__ __launch_bounds__(256) void quad_multi_kernel(QuadMulti m) {
   a.ldn = m.ldn;
   a.Wd = m.Wd, a.W0d = m.W0d, a.kapd = m.kapd, a.vard = m.vard, a.scaled = m.scale_base + g.t;
   a.Df = m.Df, a.d0 = g.d0;
+  a.pg = a.cg = nullptr;
   a.quirks = m.quirks;
   a.alpha = m.alpha + g.off, a.beta = m.beta + g.off, a.alpha0 = m.alpha0 + g.off, a.beta0 = m.beta0 + g.off;
   a.partials = m.partials + g.part0;
@@ -418,9 +423,10 @@ __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restri
                                                        const double* __restrict__ X, const double* __restrict__ Z, int ldz,
                                                        long long N, int M, int rows, int want_z,
                                                        double* __restrict__ partials, const int* __restrict__ colwin,
-                                                       ColBatch bt) {
+                                                       ColBatch bt, const double* __restrict__ Ar) {
   {  // batched over the latents (grid.z)
     const long long q = blockIdx.z;
+    if (Ar) Ar += q * bt.sK;
     Kh += q * bt.sK, Pt += q * bt.sK, a += q * bt.sA, alpha += q * bt.sV, alpha0 += q * bt.sV, beta0 += q * bt.sV;
     Z += q * bt.sZ, partials += q * bt.sPart;
     if (colwin) colwin += q * bt.sWin;
@@ -436,6 +442,7 @@ __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restri
     z1[p] = two ? Z[(long long)(c + 1) * ldz + p] : 0.0;
   }
   const double a0 = a[c], a1 = two ? a[c + 1] : 0.0;
+  const double zs0 = sumsq<P>(z0), zs1 = sumsq<P>(z1);
   // A block takes the row splits blockIdx.y, blockIdx.y + gridDim.y, ...: the grid may be CAPPED (launch_colstats) so that
   // this HBM-bound pass occupies only a few CU slots at a time beside the FP64-MFMA Gram it runs next to -- a block that
   // holds half a CU while it waits for HBM keeps a Gram block (whose registers fill the other half) from being scheduled.
@@ -467,11 +474,25 @@ __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restri
         }
       }
       const double al = alpha[n];
-      r0 += k0 * al;
-      r1 += k1 * al;
+      if (Ar) {   // strict q(f): r = A^T alpha with A = K^ Kuu^-1 (dVE_dmu of svmogp_inf.py:144 as the reference forms it)
+        r0 += Ar[n * M + c] * al;
+        r1 += (two ? Ar[n * M + c + 1] : 0.0) * al;
+      } else {
+        r0 += k0 * al;
+        r1 += k1 * al;
+      }
       if (want_z) {
         const double al0 = alpha0[n], be0 = 2.0 * beta0[n];
-        const double e0 = (al0 * a0 + be0 * q0) * k0, e1 = (al0 * a1 + be0 * q1) * k1;
+        double e0 = (al0 * a0 + be0 * q0) * k0, e1 = (al0 * a1 + be0 * q1) * k1;
+        if (Ar) {   // strict mode also restates quirk Q10: GPy's gradients_X drops the entries whose COMPUTED (expanded-form)
+                    // distance is exactly 0 -- visible for un-centred inputs only, where that form clips small distances to 0
+          double xv[P];
+#pragma unroll
+          for (int p = 0; p < P; ++p) xv[p] = X[n * P + p];
+          const double xsq = sumsq<P>(xv);
+          if (rbf_r2_fast<P>(xv, xsq, z0, zs0, 1.0) == 0.0) e0 = 0.0;
+          if (rbf_r2_fast<P>(xv, xsq, z1, zs1, 1.0) == 0.0) e1 = 0.0;
+        }
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           const double x = X[n * P + p];
@@ -904,7 +925,8 @@ void launch_log_predictive(int lik, int J, double param, long long N, int S, uns
 
 void launch_colstats(const double* Kh, const double* Pt, const double* a, const double* alpha, const double* alpha0,
                      const double* beta0, const double* X, int P, const double* Z, int ldz, long long N, int M, int rows,
-                     bool want_z, double* partials, hipStream_t s, const int* colwin, const ColBatch* batch, int max_blocks) {
+                     bool want_z, double* partials, hipStream_t s, const int* colwin, const ColBatch* batch, int max_blocks,
+                     const double* Ar) {
   if (N <= 0) return;
   ColBatch bt = batch ? *batch : ColBatch{};
   dim3 grid((M + 511) / 512, (unsigned)((N + rows - 1) / rows), batch ? batch->nq : 1);
@@ -913,7 +935,109 @@ void launch_colstats(const double* Kh, const double* Pt, const double* a, const 
     grid.y = (unsigned)std::max<long long>(1, std::min<long long>(grid.y, max_blocks / per_y));
   }
   DISPATCH_P(P, hipLaunchKernelGGL((colstats_kernel<PP>), grid, dim3(256), 0, s, Kh, Pt, a, alpha, alpha0, beta0, X, Z, ldz,
-                                   N, M, rows, want_z ? 1 : 0, partials, colwin, bt));
+                                   N, M, rows, want_z ? 1 : 0, partials, colwin, bt, Ar));
+}
+
+// ---- strict q(f) (HMOGP_CFG_STRICT_QF): row statistics of the solve-based forms of svmogp_inf.py:212-218 ------------------------
+// One wave per row.  phase 0:  p = A m_q,  c = rowsum(T .* T) - rowsum(A .* K^)    with A = K^ Kuu^-1 (two triangular products
+// against Luu^-1), T = A L_q  ==  the reference's  sum(square(dtrmm(L_q^T, R)), 0) - sum(R * Kfu^T, 0)  with R = dpotrs(Luu, Kfu^T).
+// phase 1:  pg = K^ a,  cg = rowsum(P~ .* K^)  and their r2-weighted twins pt, ct, with P~ = A (S Kuu^-1 - I): what the reference's
+// dL_dKmn (svmogp_inf.py:157-161) reduces to against K^ in svmogp.py:116-156.
+template <int P>
+__global__ __launch_bounds__(256) void strict_rowstats_kernel(StrictRows a) {
+  const int q = blockIdx.y, lane = threadIdx.x & 63;
+  const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= a.n) return;
+  const int M = a.M;
+  const double* kh = a.Kh + q * a.sK + n * M;
+  if (a.phase == 0) {
+    const double* ah = a.Ah + q * a.sK + n * M;
+    const double* tt = a.Tt + q * a.sK + n * M;
+    double sp = 0.0, st = 0.0, sk = 0.0;
+    for (int m = lane; m < M; m += 64) {
+      const double av = ah[m], tv = tt[m];
+      sp += av * a.mu[(long long)m * a.Q + q];
+      st += tv * tv;
+      sk += av * kh[m];
+    }
+    sp = wave_sum(sp), st = wave_sum(st), sk = wave_sum(sk);
+    if (lane == 0) a.p[q * a.ldn + n] = sp, a.c[q * a.ldn + n] = st - sk;
+    return;
+  }
+  const double* pt = a.Pt + q * a.sK + n * M;
+  const double* av = a.a + (long long)q * M;
+  const double* Z = a.Z + (long long)q * a.sZ;
+  const double ell = a.ell[q];
+  double xv[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) xv[p] = a.X[n * P + p];
+  const double xsq = sumsq<P>(xv);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  for (int m = lane; m < M; m += 64) {
+    double zv[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) zv[p] = Z[(long long)m * a.ldz + p];
+    const double r2 = rbf_r2<P>(xv, xsq, zv, sumsq<P>(zv), ell);
+    const double k = kh[m], ka = k * av[m], pk = pt[m] * k;
+    s0 += ka, s1 += pk, s2 += ka * r2, s3 += pk * r2;
+  }
+  s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2), s3 = wave_sum(s3);
+  if (lane == 0) {
+    a.pg[q * a.ldn + n] = s0, a.cg[q * a.ldn + n] = s1;
+    if (a.pt) a.pt[q * a.ldn + n] = s2, a.ct[q * a.ldn + n] = s3;
+  }
+}
+// strict q(f): the diagonal-block step of the blocked triangular solves  V Luu^T = K^  (DIR 0, forward over the block's columns)
+// and  A Luu = V  (DIR 1, backward) that make up the reference's dpotrs (svmogp_inf.py:214).  One thread = one row of the n x M
+// right-hand side with its <= 32 unknowns in registers, the 32 x 32 diagonal block of Luu in LDS (broadcast reads); TRUE
+// substitution, every unknown divided by its pivot as in LAPACK's dtrsm.  (A product with an explicit inverse of the block -- of
+// any width down to 8 -- loses cond(block) more digits: 5e-8 instead of 3e-10 in m_fd at cond(K_uu) = 1e7, measured.)  The
+// off-diagonal updates between two such steps are plain GEMMs (launch_gemm_f64, alpha = -1, beta = 1).
+template <int DIR>
+__global__ __launch_bounds__(256) void trsm_diag_kernel(double* __restrict__ V, long long sV, const double* __restrict__ L,
+                                                        long long sL, int M, int j0, int nb, long long n) {
+  // (the unknowns live in LDS, one column of 256 lanes per unknown -- conflict-free -- and the loops run at run time: with
+  //  x[32] in registers and both loops unrolled the compiler hoists all 528 broadcast reads and spills ~1 KB per lane)
+  __shared__ double Ls[32][33];
+  __shared__ double xs[32][256];
+  V += (long long)blockIdx.y * sV, L += (long long)blockIdx.y * sL;
+  const int t = threadIdx.x;
+  for (int e = t; e < 32 * 32; e += 256) {
+    const int r = e >> 5, c = e & 31;
+    Ls[r][c] = (r < nb && c < nb) ? L[(long long)(j0 + r) * M + j0 + c] : (r == c ? 1.0 : 0.0);
+  }
+  const long long row = (long long)blockIdx.x * 256 + t;
+  const bool valid = row < n;
+  double* v = V + (valid ? row : 0) * M + j0;
+  for (int c = 0; c < nb; ++c) xs[c][t] = valid ? v[c] : 0.0;
+  __syncthreads();
+  if (DIR == 0) {
+    for (int j = 0; j < nb; ++j) {
+      double acc = xs[j][t];
+      for (int i = 0; i < j; ++i) acc -= xs[i][t] * Ls[j][i];
+      xs[j][t] = acc / Ls[j][j];
+    }
+  } else {
+    for (int j = nb - 1; j >= 0; --j) {
+      double acc = xs[j][t];
+      for (int i = nb - 1; i > j; --i) acc -= xs[i][t] * Ls[i][j];
+      xs[j][t] = acc / Ls[j][j];
+    }
+  }
+  if (valid)
+    for (int c = 0; c < nb; ++c) v[c] = xs[c][t];
+}
+void launch_trsm_diag(int dir, double* V, long long sV, const double* L, long long sL, int M, int j0, int nb, long long n, int Q,
+                      hipStream_t s) {
+  if (n <= 0 || nb <= 0) return;
+  dim3 grid((unsigned)((n + 255) / 256), Q);
+  if (dir == 0) hipLaunchKernelGGL((trsm_diag_kernel<0>), grid, dim3(256), 0, s, V, sV, L, sL, M, j0, nb, n);
+  else hipLaunchKernelGGL((trsm_diag_kernel<1>), grid, dim3(256), 0, s, V, sV, L, sL, M, j0, nb, n);
+}
+void launch_strict_rowstats(const StrictRows& a, hipStream_t s) {
+  if (a.n <= 0) return;
+  dim3 grid((unsigned)((a.n + 3) / 4), a.Q);
+  DISPATCH_P(a.P, hipLaunchKernelGGL((strict_rowstats_kernel<PP>), grid, dim3(256), 0, s, a));
 }
 
 void launch_reduce_rows(const double* partials, long long nrows, int len, const long long* off, double* dst, bool accumulate,

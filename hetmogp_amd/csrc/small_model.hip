@@ -588,7 +588,7 @@ __device__ __forceinline__ void sm_kzz_rows(const SmallF& f, const double* __res
       s1 += ek;
       s2 += ek * r2;
 #pragma unroll
-      for (int p = 0; p < P; ++p) gz[p] += (ek + ekt) * (zj[p] - zm[p]);
+      for (int p = 0; p < P; ++p) gz[p] += (r2 != 0.0) ? (ek + ekt) * (zj[p] - zm[p]) : 0.0;   // (quirk Q10: GPy gradients_X drops r == 0)
     }
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);

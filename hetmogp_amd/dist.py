@@ -47,12 +47,22 @@ def _flag_device(group, device):
     return torch.device("cuda", int(device)) if dist.get_backend(group) == "nccl" else torch.device("cpu")
 
 
+_FORCE_COLLECTIVES = False
+
+
+def force_collectives(on=True):
+    """Dry runs of the distributed path with ONE rank (bench.py --force-dist): issue the flag reductions of the negotiation
+    also when the group has a single rank, so that the very calls a multi-GPU launch makes are executed."""
+    global _FORCE_COLLECTIVES
+    _FORCE_COLLECTIVES = bool(on)
+
+
 def all_agree(ok, group=None, device=0):
     """True on every rank iff `ok` is true on every rank (a MIN all-reduce of one flag).  Every mode decision of the
     exchange step goes through this, so ranks can never end up in different modes."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _FORCE_COLLECTIVES):
         return bool(ok)
     t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_flag_device(group, device))
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
@@ -63,7 +73,7 @@ def agree_min_max(value, group=None, device=0):
     """(min, max) of an integer over the ranks of `group`: two all-reduces issued unconditionally by every rank."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _FORCE_COLLECTIVES):
         return int(value), int(value)
     lo = torch.tensor([int(value)], dtype=torch.int32, device=_flag_device(group, device))
     hi = lo.clone()
@@ -126,7 +136,7 @@ class StatsReducer(object):
     the step.  `last_ms` = host wall milliseconds of the last exchange (for "native": the DEVICE time of pack + all-reduce + unpack,
     category "exchange" of Engine.timings(), also when the step went through `sharded_elbo_grad`'s fused call), `n_calls` = exchanges so far."""
 
-    def __init__(self, engine, device=0, mode=None, group=None, native_api=None):
+    def __init__(self, engine, device=0, mode=None, group=None, native_api=None, single_rank_exchange=False):
         import torch
         import torch.distributed as dist
         self.engine, self.group = engine, group
@@ -135,13 +145,17 @@ class StatsReducer(object):
         self.tensor = None
         self.last_ms, self.total_ms, self.n_calls = 0.0, 0.0, 0
         self.owns_comm = False
+        # single_rank_exchange=True: a world of ONE rank still negotiates like a larger one ("native" first) and runs every
+        # exchange for real (pack -> all-reduce over one rank -> unpack) -- the dry run of the distributed path on a 1-GPU box
+        # (bench.py --force-dist); the default skips the exchange of a single rank, which has nothing to exchange
+        self.single_rank_exchange = bool(single_rank_exchange)
         nccl = dist.is_initialized() and dist.get_backend(group) == "nccl"
         if mode is not None:
             candidates = [mode]
         elif not nccl:
             candidates = ["host"]
         else:       # (a single rank has nothing to exchange: no communicator is set up for it unless asked for)
-            candidates = ["native", "device", "staged"] if self.world > 1 else ["device", "staged"]
+            candidates = ["native", "device", "staged"] if (self.world > 1 or self.single_rank_exchange) else ["device", "staged"]
         self.mode = None
         for cand in candidates:
             if cand == "native":
@@ -202,8 +216,8 @@ class StatsReducer(object):
             self.owns_comm = False
 
     def __call__(self):
-        if self.world == 1 and self.mode != "native":     # (a one-rank communicator still runs its three launches: tests)
-            return
+        if self.world == 1 and self.mode != "native" and not self.single_rank_exchange:
+            return                                        # (a one-rank communicator still runs its three launches: tests)
         import time
         import torch
         import torch.distributed as dist

@@ -74,7 +74,10 @@ class Engine(object):
     """specs: list of (likelihood class name, kwargs) per task, e.g. [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {})]."""
 
     def __init__(self, specs, Q, M, P, device=0, chunk_rows=0, exact_zero_windows=False, cache_kuu=False, small_path=True,
-                 reuse_outputs=False, quirks="reference"):
+                 reuse_outputs=False, quirks="reference", strict_qf=False):
+        # strict_qf=True (HMOGP_CFG_STRICT_QF): q(f) and the row side of the gradients through the reference's solve-based forms
+        # (svmogp_inf.py:214-218, :144-161) instead of the explicit C_q -- parity within 1e-5 also where GPy's jitter ladder is taken
+        self.strict_qf = bool(strict_qf)
         self.specs = [(n, dict(k)) for n, k in specs]
         self.T, self.Q, self.M, self.P = len(specs), int(Q), int(M), int(P)
         f_index, d_index = [], []
@@ -93,7 +96,7 @@ class Engine(object):
                           self.f_index.ctypes.data_as(_lib.c_int32_p), self.d_index.ctypes.data_as(_lib.c_int32_p),
                           int(device), int(chunk_rows),
                           (_lib.CFG_EXACT_ZERO_WINDOWS if exact_zero_windows else 0) | (_lib.CFG_CACHE_KUU if cache_kuu else 0) |
-                          (0 if small_path else _lib.CFG_NO_SMALL_PATH),
+                          (0 if small_path else _lib.CFG_NO_SMALL_PATH) | (_lib.CFG_STRICT_QF if strict_qf else 0),
                           _lib.quirk_mask(quirks))
         self.quirks = _lib.quirk_mask(quirks)
         self._h = C.c_void_p()
@@ -214,7 +217,10 @@ class Engine(object):
         """One ``parameters_changed()``: returns dict(elbo, KL, kl [Q], g_m_u, g_L_u, g_variance, g_lengthscale, g_W,
         g_kappa, g_Z, rungs, v_negative[, dL_dS]).  `sharded=True` = hmogp_elbo_grad_sharded: the row-sharded step of a
         multi-GPU run (begin on this rank's rows -> in-library all-reduce -> finish), COLLECTIVE over the ranks of the
-        communicator attached with `comm_init`; the default never communicates."""
+        communicator attached with `comm_init`; the default never communicates.
+        With `Engine(reuse_outputs=True)` EVERY returned array (the three large gradients AND the small ones: g_variance, g_W,
+        kl, rung, flags ...) is owned by the engine and overwritten in place by the next evaluation -- `engine.last` and any
+        retained result dict change with it; copy what must persist."""
         p, keep = self._params(**params)
         c, o = self._outputs(want_dL_dS, skip_qu=params.get("m_u") is None)
         fn = lib.hmogp_elbo_grad_sharded if sharded else lib.hmogp_elbo_grad
@@ -426,6 +432,15 @@ def potri(L, device=None):
     L = _f64(L)
     out = np.zeros_like(L)
     check(lib.hmogp_potri(device, _p(L), L.shape[0], L.shape[1], _p(out)))
+    return out
+
+
+def potrs_rows(L, B, device=None):
+    """B (L L^T)^-1 for the rows of B [n, M]: GPy's dpotrs(L, B^T)^T (svmogp_inf.py:214) by blocked substitution on the device."""
+    device = _resolve_device(device)
+    L, B = _f64(L), _f64(B)
+    out = np.zeros_like(B)
+    check(lib.hmogp_potrs_rows(device, _p(L), L.shape[0], _p(B), B.shape[0], _p(out)))
     return out
 
 

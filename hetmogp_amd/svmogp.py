@@ -138,7 +138,9 @@ class DeviceNatGrad(DeviceAdadelta):
         DeviceAdadelta.__init__(self, model, step_rate=step_rate, decay=decay, momentum=momentum, offset=offset)
         self.gamma = float(gamma)
         self.gamma_used = float(gamma)
-        self.rejected = 0
+        self.rejected = 0            # step sizes refused by hmogp_qu_natgrad (halved and retried)
+        self.skipped = 0             # E-steps in which all eight retries were refused: q(u) unchanged, info["gamma"] == 0.0
+        self.step_taken = True
         # Step-size schedule: log-linear from gamma_start to gamma over the first `warmup` E-steps.  With N >> M the data term
         # dominates the prior in the new precision, and then m_new = S_new theta_new is nearly the FULL Newton step of the mean
         # whatever gamma is (it cancels) -- from a poor start that overshoots for exp-link likelihoods (Poisson: measured ELBO
@@ -183,18 +185,26 @@ class DeviceNatGrad(DeviceAdadelta):
                     frac = min(1.0, self.e_steps / float(self.warmup)) if self.warmup > 0 else 1.0
                     gam = float(np.exp(np.log(self.gamma_start) + frac * (np.log(self.gamma) - np.log(self.gamma_start))))
                     self.e_steps += 1
+                    self.step_taken = False
                     for _ in range(8):
                         try:
                             eng.qu_natgrad(gam)
-                            self.gamma_used = gam
+                            self.gamma_used, self.step_taken = gam, True
                             break
                         except np.linalg.LinAlgError:
                             self.rejected += 1
                             gam *= 0.5
+                    if not self.step_taken:      # eight halvings left the positive-definite cone every time: q(u) did NOT move
+                        self.gamma_used = 0.0
+                        self.skipped += 1
+                        import warnings
+                        warnings.warn("natural-gradient E-step %d skipped: every step size down to %.3g left the positive-definite "
+                                      "cone (q(u) unchanged)" % (self.e_steps, gam * 2.0), RuntimeWarning)
                     m._qu_host_stale = True
                     m._dirty = True
                 self.n_iter += 1
-                yield dict(n_iter=self.n_iter, gradient=g, step=self.step, gamma=self.gamma_used)
+                yield dict(n_iter=self.n_iter, gradient=g, step=self.step, gamma=self.gamma_used,
+                           step_taken=bool(self.step_taken) if e_step else None)
         finally:
             try:
                 self.finish()
@@ -205,7 +215,7 @@ class DeviceNatGrad(DeviceAdadelta):
 class SVMOGP(object):
     def __init__(self, X, Y, Z, kern_list, likelihood, Y_metadata, name="SVMOGP", batch_size=None, W_list=None,
                  device=None, chunk_rows=0, exact_zero_windows=False, distributed=False, quirks="reference",
-                 gradients_of_fixed=False):
+                 gradients_of_fixed=False, strict_qf=False):
         """The reference's constructor (svmogp.py:17) plus engine options (no reference equivalent):
         device            HIP device ordinal; default: LOCAL_RANK when `distributed`, else 0
         distributed       one process per GPU inside an initialised torch.distributed group: rows are sharded over ranks
@@ -217,6 +227,10 @@ class SVMOGP(object):
                           (nothing to skip at that size, and the small-model kernels need the dense layout)
         quirks            "reference" (default: reproduce the reference's results including its known deviations from the
                           exact gradient) | "exact" (true ELBO gradients) | an int mask of _lib.QUIRK_*
+        strict_qf         HMOGP_CFG_STRICT_QF: q(f) and the row side of the gradients through the reference's solve-based forms
+                          (svmogp_inf.py:214-218, :144-161) -- element-wise 1e-5 parity with the reference also where GPy's jitter
+                          ladder is taken (K_uu with l >> inducing spacing, e.g. the notebook's own lengthscale 0.05 on
+                          linspace(0, 1, M >= 24)); ~3.5x the forward work
         gradients_of_fixed  batch mode only: also evaluate the gradient groups whose parameters are all fixed (the
                           reference always computes them and the optimiser never reads them); default off, which makes
                           the VE steps of `vem_algorithm` skip the hyper-parameter / Z path."""
@@ -251,10 +265,15 @@ class SVMOGP(object):
             exact_zero_windows = bool(self.Xdim == 1 and 128 <= self.num_inducing <= 8192 and
                                       all(x.shape[0] < 2 or bool(np.all(np.diff(x[:, 0]) >= 0.0)) for x in self.Xmulti_all))
         self.exact_zero_windows = bool(exact_zero_windows)
+        self.strict_qf = bool(strict_qf)
         self._engine = Engine(likelihood.specs(), self.num_latent_funcs, self.num_inducing, self.Xdim, device=device,
                               chunk_rows=chunk_rows, exact_zero_windows=exact_zero_windows, cache_kuu=True,
-                              reuse_outputs=True, quirks=quirks)   # gradients arrive in engine-owned page-locked arrays, copied into
+                              reuse_outputs=True, quirks=quirks, strict_qf=strict_qf,
+                              small_path=not distributed)   # gradients arrive in engine-owned page-locked arrays, copied into
                                                     # the parameters' .gradient fields by parameters_changed()
+        # (distributed: the fused small-model kernels are chosen from THIS rank's row count; ranks whose shares straddle the
+        #  threshold would round the replicated M x M algebra differently and the device-resident q(u) replicas, which are never
+        #  re-synchronised, would drift apart -- every rank therefore keeps the regular kernels.  ADVICE r4)
         self._engine.set_data(self.Xmulti_all, self.Ymulti_all)
         self._engine_has_full = True      # False while foreign data (set_data of arrays that are not row ranges) is resident
         # distributed=True (inside an initialised torch.distributed group, one process per GPU): the rows of every
@@ -441,13 +460,22 @@ class SVMOGP(object):
     def shuffle_rows(self, seed=0):
         """Permute the rows of every task ONCE (data resident in HBM are re-uploaded in the new order), so that the contiguous
         minibatch slices of `new_batch` (the reference's protocol, util.py:52-72: slices are visited in order and never shuffled)
-        become uniform random subsets.  Not in the reference.  Needed by natural-gradient SVI: a contiguous slice of sorted
+        become uniform random subsets.  Not in the reference.  `model.Xmulti_all` / `Ymulti_all` ARE reordered (user code that indexes
+        them afterwards sees the new order); `model.row_permutation[t]` maps the new rows to the original ones.  Needed by natural-gradient SVI: a contiguous slice of sorted
         inputs informs a small part of the input space only, its batch_scale pretends the whole data set looks like it, and a
         natural-gradient step towards that local, over-confident posterior diverges where Adadelta's tiny Euclidean steps do
         not (measured at N_all = 1e6, batch 8192: ELBO -3e7 -> -1e17 within two steps at gamma = 0.1)."""
+        if self.exact_zero_windows:
+            import warnings
+            warnings.warn("shuffle_rows() with exact_zero_windows on: the windows mode skips exact zeros of K_uf for SORTED rows; "
+                          "after the shuffle every minibatch is unbanded and the device falls back to full ranges (results "
+                          "unchanged, the mode only adds overhead)", RuntimeWarning)
         rng = np.random.RandomState(seed)
+        prev = getattr(self, "row_permutation", None)
+        self.row_permutation = []    # row_permutation[t][i] = index in the ORIGINAL Xmulti_all[t] of what is now row i (composes)
         for t in range(len(self.Ymulti_all)):
             perm = rng.permutation(self.Xmulti_all[t].shape[0])
+            self.row_permutation.append(perm if prev is None else prev[t][perm])
             self.Xmulti_all[t] = np.ascontiguousarray(self.Xmulti_all[t][perm])
             self.Ymulti_all[t] = np.ascontiguousarray(self.Ymulti_all[t][perm])
         self._engine.set_data(self.Xmulti_all, self.Ymulti_all)
@@ -547,23 +575,30 @@ class SVMOGP(object):
         return self._opt_buf
 
     def _free_plan(self):
-        """(params, positive mask over the optimiser vector) of the free parameters, rebuilt when a fix() / unfix() changes the
-        set: the transforms below then run ONCE over the whole vector instead of once per parameter (an objective evaluation
-        of a notebook-sized model takes 0.2 ms on the device: per-parameter NumPy calls were a third of the wall time)."""
+        """(params, indices of the positive entries of the optimiser vector) of the free parameters, rebuilt when a fix() /
+        unfix() changes the set: the transforms below then touch ONLY the few positive entries (variance, lengthscale, kappa), once,
+        by index -- not once per parameter (an objective evaluation of a notebook-sized model takes 0.2 ms on the device: per-
+        parameter NumPy calls were a third of the wall time) and not over the whole vector either (1.6 M entries, almost all
+        q(u), at M = 1024: expm1 / log1p over all of them cost ~90 ms per L-BFGS evaluation and overflowed on very negative
+        unconstrained entries)."""
         params = [p for _, p in self._named_params()]
         sig = tuple((id(p), p.is_fixed, p.size) for p in params)
         plan = getattr(self, "_plan", None)
         if plan is None or plan[0] != sig:
             free = [p for p in params if not p.is_fixed]
             mask = np.concatenate([np.full(p.size, bool(p.positive)) for p in free]) if free else np.zeros(0, bool)
-            plan = self._plan = (sig, free, mask, bool(mask.any()))
+            idx = np.flatnonzero(mask)
+            plan = self._plan = (sig, free, idx, bool(idx.size))
         return plan
 
     @optimizer_array.setter
     def optimizer_array(self, x):
         x = np.asarray(x, dtype=float)
-        _, free, mask, any_pos = self._free_plan()
-        vals = np.where(mask, logexp_f(x), x) if any_pos else x
+        _, free, idx, any_pos = self._free_plan()
+        vals = x
+        if any_pos:
+            vals = x.copy()
+            vals[idx] = logexp_f(x[idx])
         i = 0
         for p in free:
             n = p.size
@@ -572,13 +607,13 @@ class SVMOGP(object):
         self.parameters_changed()                                                  # ... one evaluation for the whole vector)
 
     def _transformed_gradient(self):
-        _, free, mask, any_pos = self._free_plan()
+        _, free, idx, any_pos = self._free_plan()
         if not free:
             return np.zeros(0)
         g = np.concatenate([np.asarray(p.gradient, dtype=float).ravel() for p in free])
         if any_pos:
-            theta = np.concatenate([p.values.ravel() for p in free])
-            g = np.where(mask, g * logexp_gradfactor(theta), g)
+            theta = np.concatenate([p.values.ravel() for p in free if p.positive])
+            g[idx] *= logexp_gradfactor(theta)
         return g
 
     def _grads(self, x):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMOGP_ABI_VERSION 5
+#define HMOGP_ABI_VERSION 6
 
 /* likelihood ids (class names of /root/reference/likelihoods/<name>.py) */
 enum {
@@ -109,6 +109,13 @@ typedef struct {
  * exact-zero windows: M <= 8192.  T, M, Df and the row counts are bounded by device memory only.                 */
 
 /* hmogp_config.flags */
+#define HMOGP_CFG_STRICT_QF 8u /* ABI v6, opt-in: STRICT q(f).  The reference forms q(f_d) and the row side of its gradients through
+   A = K_fu K_uu^-1 obtained by triangular solves against Luu (dpotrs, svmogp_inf.py:214-218; A^T alpha, A^T diag(beta) A and
+   A (S K_uu^-1 - I) at :144-161); the default path uses the algebraically equal explicit C_q = K_uu^-1 S K_uu^-1 - K_uu^-1, which
+   differs from that by ~cond(K_uu) * 2^-53.  Once GPy's jitter ladder is taken (cond ~ 1e7) the default path's g_W / g_kappa / g_Z
+   are 1e-4 .. 1e-3 away from the reference's; with this flag the engine follows the reference's forms (two triangular products
+   with Luu^-1, the Gram of A, ...) and stays within 1e-5 element-wise there (tests/test_gpu_ladder.py).  ~3.5x the forward
+   work, regular kernels only (no fused small-model path), excludes HMOGP_CFG_EXACT_ZERO_WINDOWS.  bench.py never sets it.   */
 #define HMOGP_CFG_NO_SMALL_PATH 4u /* ABI v5: keep the regular kernels and three streams also for small models (M <= 64 would
                                     * otherwise take the fused small-model kernels, M <= 128 with <= 65536 rows one stream): A/B
                                     * comparisons of the two paths inside one process (tests)                                */
@@ -308,6 +315,10 @@ int hmogp_jitchol_inv(int32_t device, const double* A, int32_t Q, int32_t M, con
                       double* L, double* Ainv, int32_t* rung);
 /* (L L^T)^-1 from lower factors (GPy dpotri): L [Q,M,M] -> Sinv [Q,M,M].                                 */
 int hmogp_potri(int32_t device, const double* L, int32_t Q, int32_t M, double* Sinv);
+/* out [n, M] = dpotrs(L, B^T)^T = B (L L^T)^-1 for the n rows of B [n, M], L [M, M] lower (GPy util.linalg.dpotrs as
+ * svmogp_inf.py:214 calls it): two blocked triangular solves, true substitution inside 32-column diagonal blocks -- the
+ * building block of HMOGP_CFG_STRICT_QF.  ABI v6.                                                                      */
+int hmogp_potrs_rows(int32_t device, const double* L, int32_t M, const double* B, int64_t n, double* out);
 /* C = alpha * op(A) op(B) + beta * C on the FP64-MFMA GEMM; transA/transB in {0,1}; row-major.           */
 int hmogp_gemm_f64(int32_t device, int32_t transA, int32_t transB, int32_t M, int32_t N, int32_t K,
                    double alpha, const double* A, int32_t lda, const double* B, int32_t ldb, double beta,

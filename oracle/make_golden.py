@@ -17,6 +17,10 @@ Fixture families:
   ref_<case>.npz    N1  REAL-SIZE runs of the reference's own SVMOGP.parameters_changed + SVMOGPInf.inference (C1 exactly:
                         N_t = 1000, M = 50, Q = 2; multi-tile M = 128 / 144 / 160): ELBO, KL, q(f_d), dL_dmu_u, dL_dL_u, dL_dKmm
                         and the assembled parameter gradients; the Q*Df dense M x N `dL_dKmn` blocks are NOT stored (size).
+  lad_<case>.npz    J1  the reference's own SVMOGP.parameters_changed in the regime where GPy's jitchol decides the numbers
+                        (notebook hyper-parameters at C1's shape: cond 1e12, rung -1; M = 128 at 4 spacings: rung 0; un-centred
+                        inputs: rung 1), each run twice (inputs, inputs moved by one ulp): `sens_*` = the reference's own
+                        rounding-level sensitivity.
   mpred_<case>.npz  f2  model-level prediction through the reference's own SVMOGP methods (svmogp.py:219-351):
                         predictive_new, _raw_predict_f, _raw_predict_stochastic, _raw_predict, predictive, at tiny N
                         (the _raw_predict_f route factorises the N x N K_ff of the TRAINING inputs).  Relies on the
@@ -501,11 +505,152 @@ def gen_reference_real_sizes(stand, inf, util, hl, svmogp, liks):
               "cond(Kuu)", ["%.1e" % np.linalg.cond(Kuu[q]) for q in range(Q)])
 
 
+# ----------------------------------------------------------------- J1: the reference itself where GPy's jitter ladder lives
+C1_MIX = [("HetGaussian", {}), ("Bernoulli", {}), ("Categorical", {"K": 3})]
+LADDER_CASES = [
+    # tag, likelihood specs, N_t, M, Q, lengthscale / inducing spacing (None: absolute lengthscale below), variances, input offset
+    # (i) BASELINE config 1's shape with the notebook's OWN hyper-parameters (notebooks/demo.ipynb cell 7: ls = 0.05, var = 0.5,
+    #     Z = linspace(0, 1, M)): l / h = 2.45, cond(K_uu) = 1.1e12 -- LAPACK's dpotrf still succeeds (rung -1)
+    ("c1_notebook_ell", C1_MIX, [1000, 1000, 1000], 50, 2, None, (0.5, 0.5), 0.0),
+    # (ii) headline likelihood mix, M = 128, l = 4 h: plain dpotrf fails, rung 0 (jitter 1e-6 mean diag) holds; cond 1e7
+    ("h_mix_M128_ladder", H_MIX, [400, 383, 417, 350], 128, 3, 4.0, (0.5, 0.7, 0.9), 0.0),
+    # (iii) un-centred inputs (x in [1e4, 1e4 + 1]): GPy's expanded distance |x|^2 + |z|^2 - 2 x.z loses 8 digits, K_uu is
+    #     indefinite by 2e-6 -- rung 0 (5e-7) fails as well, rung 1 holds
+    ("c1_offset_rung1", C1_MIX, [300, 280, 310], 50, 2, 4.0, (0.5, 0.5), 1.0e4),
+]
+
+
+def _textbook_cholesky(A):
+    """Cholesky-Banachiewicz, one row at a time, every entry one dot product: a valid factorisation whose sums run in a
+    different order than LAPACK's blocked dpotrf."""
+    n = A.shape[0]
+    L = np.zeros_like(A)
+    for i in range(n):
+        for j in range(i):
+            L[i, j] = (A[i, j] - np.dot(L[i, :j], L[j, :j])) / L[j, j]
+        d = A[i, i] - np.dot(L[i, :i], L[i, :i])
+        if not d > 0.0:
+            raise np.linalg.LinAlgError("textbook Cholesky: non-positive pivot %d" % i)
+        L[i, i] = np.sqrt(d)
+    return L
+
+
+def gen_reference_ladder(stand, inf, util, hl, svmogp, liks):
+    """Row J1 of VERDICT r4: the reference's own `SVMOGP.parameters_changed` (svmogp.py:85-166) where `jitchol` (util.py:197-199)
+    decides the numbers.  Each case is run TWICE: as it is, and with every covariance entry the kernel returns (`RBF.K`, reached
+    from util.py:161,197) moved by one unit in the last place (K (1 +- 2^-52), seeded) -- what a second implementation's exp()
+    is entitled to differ by -- and a THIRD time with LAPACK's dpotrf inside `jitchol` replaced by a textbook row-by-row Cholesky
+    (same matrix, same rung, same jitter: only the order of the factorisation's sums changes -- what a GPU factorisation
+    differs in).  `sens_<key>` = the larger |difference| of the two: the reference's own sensitivity to rounding-level changes,
+    the only yardstick another implementation can be held to where it exceeds 1e-5."""
+
+    import random
+    import time
+    import GPy.util.linalg as gl
+    for k, (tag, specs, Ns, M, Q, c_ell, var, offset) in enumerate(LADDER_CASES):
+        rng = np.random.RandomState(900 + k)
+        c = build_case(rng, specs, Ns, M, Q, 1, (1.0,) * Q, False, False)
+        h = spacing(M, 1)
+        c["Z"] = np.tile(np.linspace(0, 1, M)[:, None], (1, Q)) + offset
+        c["X"] = [x + offset for x in c["X"]]
+        c["lengthscale"] = np.array([0.05] * Q if c_ell is None else [c_ell * h] * Q)
+        c["variance"] = np.array(var, float)
+        T = len(specs)
+
+        def run(Z, ulp_rng=None, alt_rungs=None):
+            likelihood = hl.HetLikelihood([make_lik(liks, s) for s in specs])
+            Y_metadata = likelihood.generate_metadata()
+            Df = likelihood.num_output_functions(Y_metadata)
+            kern_list = util.latent_functions_prior(Q, lenghtscale=c["lengthscale"], variance=c["variance"], input_dim=1)
+            W_list = [c["W"][q][:, None].copy() for q in range(Q)]
+            np.random.seed(97531 + k)
+            random.seed(864 + k)
+            model = svmogp.SVMOGP(X=c["X"], Y=c["Y"], Z=Z[:, :1].copy(), kern_list=kern_list, likelihood=likelihood,
+                                  Y_metadata=Y_metadata, batch_size=None, W_list=W_list)
+            model.q_u_means[...] = c["m_u"]
+            model.q_u_chols[...] = c["L_flat"]
+            model.Z[...] = Z
+            rungs = []
+            orig = stand.jitchol
+            rec = lambda A, maxtries=5: orig(A, maxtries, _record=rungs)
+            if alt_rungs is not None:       # the SAME rung as the plain run, factorised by the textbook algorithm
+                def rec(A, maxtries=5):
+                    r = alt_rungs[len(rungs) % Q]
+                    rungs.append(r)
+                    jit = 0.0 if r < 0 else np.diag(A).mean() * 1e-6 * 10.0 ** r
+                    return _textbook_cholesky(A + np.eye(A.shape[0]) * jit)
+            gl.jitchol = rec
+            util.linalg.jitchol = rec
+            plain_K = stand.RBF.K
+            if ulp_rng is not None:
+                stand.RBF.K = lambda self, X, X2=None: (lambda K: K * (1.0 + ulp_rng.choice([-1.0, 1.0], size=K.shape) * 2.0 ** -52))(
+                    plain_K(self, X, X2))
+            try:
+                t0 = time.time()
+                model.parameters_changed()
+                dt = time.time() - t0
+                Kuu, Luu, Kuui = util.latent_funs_cov(Z, kern_list)
+            finally:
+                gl.jitchol = orig
+                util.linalg.jitchol = orig
+                stand.RBF.K = plain_K
+            rungs = rungs[:Q]                          # (latent_funs_cov factorises the Q prior covariances first, util.py:196-199)
+            p_U = inf.pu(Kuu=Kuu, Luu=Luu, Kuui=Kuui)
+            q_U = inf.qu(mu_u=c["m_u"], chols_u=c["L_flat"])
+            f_index = Y_metadata["function_index"].flatten()
+            out = {}
+            for d in range(Df):
+                Xt = model.Xmulti[f_index[d]]
+                qf = model.inference_method.calculate_q_f(X=Xt, Z=Z, q_U=q_U, p_U=p_U, kern_list=kern_list, B=model.B_list,
+                                                          M=M, N=Xt.shape[0], Q=Q, D=Df, d=d)
+                out["m_fd_%d" % d] = qf.m_fd
+                out["v_fd_%d" % d] = qf.v_fd
+            out["KL"] = np.asarray(model.inference_method.calculate_KL(q_U=q_U, p_U=p_U, M=M, Q=Q)).reshape(1, 1)
+            out["elbo"] = np.asarray(model.log_likelihood()).reshape(1, 1)
+            out["g_m_u"] = np.asarray(model.q_u_means.gradient).copy()
+            out["g_L_u"] = np.asarray(model.q_u_chols.gradient).copy()
+            out["g_Z"] = np.asarray(model.Z.gradient).copy()
+            out["g_variance"] = np.array([float(np.ravel(kq.variance.gradient)[0]) for kq in kern_list])
+            out["g_lengthscale"] = np.array([float(np.ravel(kq.lengthscale.gradient)[0]) for kq in kern_list])
+            out["g_W"] = np.stack([np.ravel(B.W.gradient) for B in model.B_list])
+            out["g_kappa"] = np.stack([np.ravel(B.kappa.gradient) for B in model.B_list])
+            cond = [float(np.linalg.cond(Luu[q] @ Luu[q].T)) for q in range(Q)]
+            return out, rungs, dt, f_index, Y_metadata["d_index"].flatten(), Df, cond
+
+        out, rungs, dt, f_index, d_index, Df, cond = run(c["Z"])
+        out2, rungs2, _, _, _, _, _ = run(c["Z"], np.random.RandomState(950 + k))
+        assert rungs2 == rungs, (tag, rungs, rungs2)        # a case whose rung flips with the last bit pins nothing
+        out3, _, _, _, _, _, _ = run(c["Z"], None, rungs)
+        sens = {"sens_" + key: np.maximum(np.abs(np.asarray(out[key]) - np.asarray(out2[key])),
+                                          np.abs(np.asarray(out[key]) - np.asarray(out3[key]))).astype(np.float32) for key in out}
+        print("   one-ulp K / textbook-Cholesky sensitivities:",
+              {key: "%.1e / %.1e" % (float(np.max(np.abs(out[key] - out2[key]))) / (float(np.max(np.abs(out[key]))) + 1e-300),
+                                     float(np.max(np.abs(out[key] - out3[key]))) / (float(np.max(np.abs(out[key]))) + 1e-300))
+               for key in ("elbo", "g_m_u", "g_L_u", "g_Z", "g_variance", "g_lengthscale", "g_W", "g_kappa", "m_fd_0", "v_fd_0")})
+        for t in range(T):
+            out["Xall_%d" % t], out["Yall_%d" % t] = c["X"][t], c["Y"][t]
+            out["Xbatch_%d" % t], out["Ybatch_%d" % t] = c["X"][t], c["Y"][t]
+        np.savez_compressed(
+            os.path.join(OUT, "lad_%s.npz" % tag), spec=json.dumps(specs), T=T, M=M, Q=Q, P=1, Df=Df,
+            Z=c["Z"], variance=c["variance"], lengthscale=c["lengthscale"], W=c["W"], W0=c["W"],
+            kappa=np.zeros((Q, Df)), m_u=c["m_u"], L_flat=c["L_flat"], stochastic=0, batch_size=-1, vem_step=1,
+            batch_scale=np.ones(T), f_index=f_index, d_index=d_index, rungs=np.array(rungs, dtype=np.int64),
+            cond_jittered=np.array(cond), reference_seconds=dt, **out, **sens)
+        print("lad", tag, "rungs", rungs, "ELBO", float(out["elbo"]), "cond(Kuu + jitter) %s" % ["%.1e" % x for x in cond],
+              "reference parameters_changed: %.2f s" % dt,
+              "| 1-ulp sensitivity (max |d| / max |ref|):",
+              {key: "%.1e" % (float(np.max(sens["sens_" + key])) / (float(np.max(np.abs(out[key]))) + 1e-300))
+               for key in ("elbo", "g_m_u", "g_L_u", "g_Z", "g_variance", "g_lengthscale", "g_W", "g_kappa")})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     stand, inf, util, hl, svmogp, liks = _import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "ref":          # only the real-size family (the others are unchanged)
         gen_reference_real_sizes(stand, inf, util, hl, svmogp, liks)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "ladder":       # only the jitter-ladder family
+        gen_reference_ladder(stand, inf, util, hl, svmogp, liks)
         return
     gen_likelihoods(liks)
     gen_predictive(liks)
@@ -514,6 +659,7 @@ def main():
     gen_model(stand, util, hl, svmogp, liks)
     gen_model_predict(stand, util, hl, svmogp, liks)
     gen_reference_real_sizes(stand, inf, util, hl, svmogp, liks)
+    gen_reference_ladder(stand, inf, util, hl, svmogp, liks)
 
 
 if __name__ == "__main__":

@@ -263,8 +263,12 @@ def assemble_literal(prm, prob, X, grads, stochastic=False, vem_step=True, z_fix
         gkap = np.zeros(Df)
         gZ = np.zeros((M, P))
         T2 = dKmm + dKmm.T
+        # quirk Q10 (GPy 1.9.5 Stationary.gradients_X: `invdist = 1 / where(r != 0, r, inf)`): entries whose COMPUTED distance is
+        # exactly 0 are dropped.  In exact arithmetic r = 0 means x = z and the term vanishes anyway; with un-centred inputs the
+        # expanded form |x|^2 + |z|^2 - 2 x.z clips small positive distances to 0 and the dropped terms are visible (2e-5 of g_Z
+        # for x in [1e4, 1e4 + 1], tests/golden/lad_c1_offset_rung1.npz)
         for p in range(P):
-            gZ[:, p] += np.sum(-T2 * Kzz * (Zq[:, p][:, None] - Zq[:, p][None, :]), 1) / ell ** 2
+            gZ[:, p] += np.sum(-T2 * Kzz * (r2 != 0.0) * (Zq[:, p][:, None] - Zq[:, p][None, :]), 1) / ell ** 2
         for d in range(Df):
             Xt = X[f_index[d]]
             r2x = rbf_r2_scaled(Zq, Xt, ell)
@@ -276,7 +280,7 @@ def assemble_literal(prm, prob, X, grads, stochastic=False, vem_step=True, z_fix
             gvar += W0[q, d] * np.sum(Kzx * dK) / var + (W0[q, d] ** 2 + kappa0[q, d]) * sgv
             gell += W0[q, d] * np.sum(dK * Kzx * r2x) / ell
             for p in range(P):
-                gZ[:, p] += W0[q, d] * np.sum(-dK * Kzx * (Zq[:, p][:, None] - Xt[:, p][None, :]), 1) / ell ** 2
+                gZ[:, p] += W0[q, d] * np.sum(-dK * Kzx * (r2x != 0.0) * (Zq[:, p][:, None] - Xt[:, p][None, :]), 1) / ell ** 2
         out["g_variance"][q] = m_gate * gvar
         out["g_lengthscale"][q] = m_gate * gell
         out["g_W"][q] = m_gate * gW
@@ -302,18 +306,24 @@ def u_algebra(prm, prob, forced_rungs=None):
     """Replicated M x M quantities needed before the row pass: per q  Kuu, Luu, Kuui, L, S, a, C."""
     Q, M = prob["Q"], prob["M"]
     Kuu, Luu, Kuui, rungs = latent_covariances(prm, prob, forced_rungs)
-    u = dict(Kuu=Kuu, Luu=Luu, Kuui=Kuui, rungs=rungs, L=[], S=[], a=[], C=[])
+    u = dict(Kuu=Kuu, Luu=Luu, Kuui=Kuui, rungs=rungs, L=[], S=[], a=[], C=[], D=[])
     for q in range(Q):
         L_q = flat_to_tril(prm["L_flat"][:, q], M)
         S_q = L_q @ L_q.T
         u["L"].append(L_q), u["S"].append(S_q)
         u["a"].append(Kuui[q] @ prm["m_u"][:, q])
         u["C"].append(Kuui[q] @ S_q @ Kuui[q] - Kuui[q])
+        if prob.get("strict_qf"):      # the engine's HMOGP_CFG_STRICT_QF algebra (see local_stats)
+            u["D"].append(S_q @ Kuui[q] - np.eye(M))                   # svmogp_inf.py:157-158 (tmp / 2)
     return u
 
 
 def local_stats(prm, prob, u, X, Y, batch_scale=None):
-    """Row pass over this shard's rows (additive over shards).  Returns the flat statistic bundle."""
+    """Row pass over this shard's rows (additive over shards).  Returns the flat statistic bundle.
+
+    prob["strict_qf"] = True restates the engine's HMOGP_CFG_STRICT_QF mode: q(f) and the row side of the gradients through
+    A = K^ Kuu^-1 formed by two triangular solves against Luu (the reference's dpotrs, svmogp_inf.py:214-218), the bundle's H / r
+    slots then hold dVE_dS = A^T diag(beta) A and dVE_dmu = A^T alpha (:144-148) and P~ = A (S Kuu^-1 - I) (:157-161)."""
     Q, M, P, T, Df = prob["Q"], prob["M"], prob["P"], prob["T"], prob["Df"]
     lay = stats_layout(prob)
     batch_scale = [1.0] * T if batch_scale is None else list(batch_scale)
@@ -327,16 +337,28 @@ def local_stats(prm, prob, u, X, Y, batch_scale=None):
         N = Xt.shape[0]
         if N == 0:
             continue
-        Khat, R2, Pt, p, c, pt, ct = [], [], [], [], [], [], []
+        strict = bool(prob.get("strict_qf"))
+        Khat, R2, Pt, p, c, pt, ct, Am, pg, cg = [], [], [], [], [], [], [], [], [], []
         for q in range(Q):
             Zq = prm["Z"][:, q * P:(q + 1) * P]
             ell = prm["lengthscale"][q]
             r2 = rbf_r2_scaled(Xt, Zq, ell)
             K = prm["variance"][q] * np.exp(-0.5 * r2)
-            PP = K @ u["C"][q]
+            if strict:
+                V = scipy.linalg.solve_triangular(u["Luu"][q], K.T, lower=True)                  # two triangular SOLVES
+                A = scipy.linalg.solve_triangular(u["Luu"][q], V, lower=True, trans="T").T       # (= dpotrs, :214)
+                PP = A @ u["D"][q]
+                Tm = A @ u["L"][q]
+                Am.append(A)
+                p.append(A @ prm["m_u"][:, q]), c.append(np.sum(Tm * Tm, 1) - np.sum(A * K, 1))
+                pg.append(K @ u["a"][q]), cg.append(np.sum(PP * K, 1))
+            else:
+                PP = K @ u["C"][q]
+                p.append(K @ u["a"][q]), c.append(np.sum(PP * K, 1))
             Khat.append(K), R2.append(r2), Pt.append(PP)
-            p.append(K @ u["a"][q]), c.append(np.sum(PP * K, 1))
             pt.append((K * r2) @ u["a"][q]), ct.append(np.sum(PP * K * r2, 1))
+        if not strict:
+            pg, cg = p, c
         mu = np.zeros((N, len(ds)))
         vv = np.zeros((N, len(ds)))
         for j, d in enumerate(ds):
@@ -358,17 +380,18 @@ def local_stats(prm, prob, u, X, Y, batch_scale=None):
             alpha, beta = gm @ w, gv @ (w * w)
             alpha0, beta0 = gm @ W0[q, ds], gv @ (W0[q, ds] * w)
             K = Khat[q]
-            stats[o + lay["H"]:o + lay["H"] + M * M] += ((K * beta[:, None]).T @ K).reshape(-1)
-            stats[o + lay["r"]:o + lay["r"] + M] += K.T @ alpha
+            Kg = Am[q] if strict else K
+            stats[o + lay["H"]:o + lay["H"] + M * M] += ((Kg * beta[:, None]).T @ Kg).reshape(-1)
+            stats[o + lay["r"]:o + lay["r"] + M] += Kg.T @ alpha
             E = (alpha0[:, None] * u["a"][q][None, :] + 2.0 * beta0[:, None] * Pt[q]) * K       # N x M
             Zq = prm["Z"][:, q * P:(q + 1) * P]
             for pp in range(P):
                 stats[o + lay["dZ"] + pp:o + lay["dZ"] + M * P:P] += np.sum(
-                    E * (Xt[:, pp][:, None] - Zq[:, pp][None, :]), 0)
-            stats[o + lay["sa"]] += alpha0 @ p[q] + 2.0 * beta0 @ c[q]
+                    E * (R2[q] != 0.0) * (Xt[:, pp][:, None] - Zq[:, pp][None, :]), 0)     # (quirk Q10, see assemble_literal)
+            stats[o + lay["sa"]] += alpha0 @ pg[q] + 2.0 * beta0 @ cg[q]
             stats[o + lay["sl"]] += alpha0 @ pt[q] + 2.0 * beta0 @ ct[q]
             for j, d in enumerate(ds):
-                stats[o + lay["swk"] + d] += gm[:, j] @ p[q] + 2.0 * prm["W"][q, d] * (gv[:, j] @ c[q])
+                stats[o + lay["swk"] + d] += gm[:, j] @ pg[q] + 2.0 * prm["W"][q, d] * (gv[:, j] @ cg[q])
     return stats, v_neg
 
 
@@ -404,8 +427,11 @@ def finish(prm, prob, u, stats, stochastic=False, vem_step=True, z_fixed=False):
         S_qi, _ = potri_sym(L_q)
         if np.any(np.isinf(S_qi)):
             raise ValueError("Sqi: Cholesky representation unstable")
-        G = Ki @ H @ Ki
-        Kr = Ki @ r
+        if prob.get("strict_qf"):      # the bundle already holds dVE_dS and dVE_dmu
+            G, Kr = H, r
+        else:
+            G = Ki @ H @ Ki
+            Kr = Ki @ r
         KiS = Ki @ S
         GSK = G @ KiS.T
         dVE_dK = G - GSK - GSK.T - np.outer(Kr, a)
@@ -425,7 +451,7 @@ def finish(prm, prob, u, stats, stochastic=False, vem_step=True, z_fixed=False):
         gZ = dZs / ell ** 2
         T2 = EK + EK.T
         for pp in range(P):
-            gZ[:, pp] += np.sum(T2 * (Zq[:, pp][None, :] - Zq[:, pp][:, None]), 1) / ell ** 2
+            gZ[:, pp] += np.sum(T2 * (r2 != 0.0) * (Zq[:, pp][None, :] - Zq[:, pp][:, None]), 1) / ell ** 2   # (quirk Q10)
         out["g_variance"][q] = m_gate * gvar
         out["g_lengthscale"][q] = m_gate * gell
         if exact:

@@ -101,6 +101,45 @@ def test_C4_rank_share_full_size():
     check_config(C4_SPECS, 125000, 1024, 4, window=1000, seed=20260933, pools=2, exact_zero=False)
 
 
+@pytest.mark.timeout(1200)
+def test_C4_full_size_pools():
+    """BASELINE config 4 at its FULL size on ONE GPU: 8 tasks x 1 000 000 rows, M = 1024, Q = 4, Df = 14, streamed through pools
+    of 2^20 rows that cross task boundaries.  The evaluation equals the sum of the eight rank-share bundles (what the 8-GPU
+    exchange would all-reduce: `dist.shard_ranges` row ranges, stats_read / stats_write), is bit-repeatable, and matches the
+    oracle on a window of rows at the END of every task."""
+    from hetmogp_amd.engine import Engine
+    from hetmogp_amd.synthetic import make_case
+    from hetmogp_amd.dist import shard_ranges
+    from oracle import svmogp_oracle as so
+    N, M, Q, P, T, world = 1000000, 1024, 4, 1, len(C4_SPECS), 8
+    prm, X, Y = make_case(C4_SPECS, [N] * T, M=M, Q=Q, P=P, seed=20260933)
+    e = Engine(C4_SPECS, Q, M, P)
+    e.set_data(X, Y)
+    full = e.elbo_grad(**prm)
+    assert np.isfinite(full["elbo"]) and not full["v_negative"] and full["rungs"] == [-1] * Q
+    again = e.elbo_grad(**prm)
+    for k in KEYS:
+        assert np.array_equal(np.asarray(full[k]), np.asarray(again[k])), k
+    total = None
+    for rank in range(world):
+        rb, re = shard_ranges([0] * T, [N] * T, rank, world)
+        e.step_begin(row_begin=rb, row_end=re, **prm)
+        s = e.stats_read()
+        total = s if total is None else total + s
+    e.stats_write(total)
+    summed = e.step_finish()
+    for k in KEYS:
+        assert rel(summed[k], full[k]) < 1e-9, ("sum of 8 rank shares", k, rel(summed[k], full[k]))
+    window = 500
+    prob = so.make_problem(C4_SPECS, Q, M, P)
+    want = so.elbo_grad_fused(prm, prob, [x[N - window:] for x in X], [y[N - window:] for y in Y])
+    got = e.elbo_grad(row_begin=[N - window] * T, row_end=[N] * T, **prm)
+    for k in KEYS:
+        assert rel(got[k], want[k]) < 1e-8, ("oracle window", k, rel(got[k], want[k]))
+        assert elementwise_excess(got[k], want[k]) <= 1.0, ("oracle window, element-wise 1e-5", k)
+    e.close()
+
+
 @pytest.mark.timeout(900)
 def test_C5_full_size():
     """C5: T=2 [Categorical(4), Gaussian], 2-D inputs, N_t = 50 000, M = 2048 (46 x 46 grid cut to 2048), Q = 2 -- 16 x 16 GEMM

@@ -1,0 +1,128 @@
+"""GPU: the engine against runs of the REFERENCE ITSELF where GPy's jitter ladder decides the numbers (row J1 of VERDICT r4;
+fixtures tests/golden/lad_*.npz from oracle/make_golden.py:gen_reference_ladder -- the reference's own SVMOGP.parameters_changed,
+svmogp.py:85-166, over util.py:181-200's jitchol):
+
+  lad_c1_notebook_ell     BASELINE config 1's shape (N_t=1000, M=50, Q=2) with the notebook's own hyper-parameters (demo.ipynb cell 7:
+                          lengthscale 0.05, variance 0.5, Z = linspace): l/h = 2.45, cond(K_uu) = 1.1e12, LAPACK still succeeds (rung -1)
+  lad_h_mix_M128_ladder   headline mix, M=128, l = 4 h: plain dpotrf fails, rung 0 holds (cond 1e7)
+  lad_c1_offset_rung1     un-centred inputs (x in [1e4, 1e4+1]): K_uu indefinite by 2e-6, rung 0 fails too, rung 1 holds
+
+What is asserted:
+  * the FREE ladder (forced_rung = None) lands on the rung LAPACK took in the reference, in both modes;
+  * STRICT q(f) mode (HMOGP_CFG_STRICT_QF): ELBO, KL, m_fd / v_fd and all seven gradient arrays against the reference's numbers
+    under the element-wise criterion |a-b| <= 1e-5 |b| + 1e-9 max|b| (nothing loosened) AND an array norm of 1e-7 (1e-8 elsewhere
+    in this suite: two valid K_uu^-1 of a cond-1e7 matrix differ by 1e-9, and g_W / g_Z reach 1.4e-8 of their scale through
+    K_uu^-1 m) wherever the reference's own sensitivity to rounding-level changes (`sens_*` of the fixture: every covariance entry
+    moved by one ulp, dpotrf replaced by a textbook Cholesky) is below 1e-7 of the array; where it is not (cond 1e12: the
+    reference's own numbers move by 1e-4 when exp() rounds differently) within 50 x that sensitivity;
+  * the DEFAULT mode (explicit C_q) is measured and printed beside it -- it is 1e-4..1e-3 off in g_W / g_kappa / g_Z there,
+    which is why the strict mode exists."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, elementwise_excess, rel_norm
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ["elbo", "KL", "g_m_u", "g_L_u", "g_variance", "g_lengthscale", "g_W", "g_kappa", "g_Z"]
+LAD = sorted(glob.glob(os.path.join(GOLDEN, "lad_*.npz")))
+
+
+def _run(g, strict, forced=None, small_path=True):
+    from hetmogp_amd.engine import Engine
+    from oracle import svmogp_oracle as so
+    prm, prob, X, Y, bs = so.load_case(g)
+    e = Engine(prob["specs"], prob["Q"], prob["M"], prob["P"], strict_qf=strict, small_path=small_path)
+    e.set_data(X, Y)
+    out = e.elbo_grad(Z=prm["Z"], m_u=prm["m_u"], L_flat=prm["L_flat"], variance=prm["variance"], lengthscale=prm["lengthscale"],
+                      W=prm["W"], kappa=prm["kappa"], W0=prm.get("W0"), batch_scale=bs, forced_rung=forced)
+    qf = {}
+    for t in range(prob["T"]):
+        m, v = e.predict_f(X[t])
+        for d in range(prob["Df"]):
+            if prob["f_index"][d] == t:
+                qf["m_fd_%d" % d], qf["v_fd_%d" % d] = m[:, d], v[:, d]
+    e.close()
+    return out, qf, prob
+
+
+def _errors(out, qf, g):
+    rows = {}
+    for k in KEYS:
+        rows[k] = (rel_norm(out[k], g[k]), elementwise_excess(out[k], g[k]), _sens_ratio(g, k))
+    for k in sorted(qf):
+        rows[k] = (rel_norm(qf[k], g[k][:, 0]), elementwise_excess(qf[k], g[k][:, 0]), _sens_ratio(g, k))
+    return rows
+
+
+def _sens_ratio(g, k):
+    return float(np.max(g["sens_" + k])) / (float(np.max(np.abs(g[k]))) + 1e-300)
+
+
+def test_fixture_family_is_complete():
+    names = {os.path.basename(p) for p in LAD}
+    assert {"lad_c1_notebook_ell.npz", "lad_h_mix_M128_ladder.npz", "lad_c1_offset_rung1.npz"} <= names
+    rungs = {os.path.basename(p): list(np.load(p)["rungs"]) for p in LAD}
+    assert rungs["lad_c1_notebook_ell.npz"] == [-1, -1]
+    assert rungs["lad_h_mix_M128_ladder.npz"] == [0, 0, 0]
+    assert min(rungs["lad_c1_offset_rung1.npz"]) >= 1       # a case where rung 0 fails as well
+
+
+@pytest.mark.parametrize("path", LAD, ids=os.path.basename)
+@pytest.mark.parametrize("strict", [False, True], ids=["default", "strict"])
+def test_free_ladder_lands_on_the_reference_rung(path, strict):
+    g = np.load(path)
+    out, _, _ = _run(g, strict)
+    assert out["rungs"] == [int(r) for r in g["rungs"]]
+
+
+@pytest.mark.parametrize("path", LAD, ids=os.path.basename)
+def test_strict_mode_vs_reference_run_in_the_ladder_regime(path, capsys):
+    g = np.load(path)
+    out, qf, prob = _run(g, True)
+    assert out["rungs"] == [int(r) for r in g["rungs"]]
+    rows = _errors(out, qf, g)
+    dout, dqf, _ = _run(g, False)
+    drows = _errors(dout, dqf, g)
+    with capsys.disabled():
+        print("\n[ladder] %s  rungs %s  cond(K_uu + jitter) %s" % (os.path.basename(path), out["rungs"],
+                                                                    ["%.1e" % c for c in g["cond_jittered"]]))
+        print("[ladder]   %-12s %-24s %-24s %s" % ("array", "strict: norm / elem-excess", "default: norm / elem-excess", "reference 1-ulp sens"))
+        for k, (rn, ex, sr) in rows.items():
+            print("[ladder]   %-12s %9.2e / %-12.3g %9.2e / %-12.3g %9.2e" % (k, rn, ex, drows[k][0], drows[k][1], sr))
+    for k, (rn, ex, sr) in rows.items():
+        a = out[k] if k in out else qf[k]
+        b = g[k] if k in out else g[k][:, 0]
+        if sr < 1e-7:      # the reference's own numbers are stable to 1e-7 here: the element-wise criterion, nothing loosened
+            assert rn < 1e-7, (k, "norm", rn)
+            assert ex <= 1.0, (k, "element-wise excess", ex)
+        else:              # conditioning-limited (the reference moves by `sr` when exp() rounds differently): 50 x its own sensitivity
+            a, b = np.asarray(a, float).ravel(), np.asarray(b, float).ravel()
+            bound = 1e-5 * np.abs(b) + 1e-9 * np.max(np.abs(b)) + 50.0 * float(np.max(g["sens_" + k]))
+            assert np.all(np.abs(a - b) <= bound), (k, "beyond 50 x the reference's own one-ulp sensitivity", rn, sr)
+
+
+def test_default_mode_is_off_by_more_than_1e5_where_the_ladder_is_taken():
+    """Documents WHY the strict mode exists: at rung 0 (cond 1e7) the explicit-inverse path is inside 1e-5 for the ELBO and the q(u)
+    gradients and outside it for g_W / g_kappa / g_Z; if this ever stops failing the strict mode is no longer needed there."""
+    g = np.load(os.path.join(GOLDEN, "lad_h_mix_M128_ladder.npz"))
+    out, qf, _ = _run(g, False)
+    rows = _errors(out, qf, g)
+    assert rows["elbo"][1] <= 1.0 and rows["g_m_u"][1] <= 1.0
+    assert max(rows[k][1] for k in ("g_W", "g_kappa", "g_Z")) > 1.0
+    assert max(rows[k][0] for k in KEYS) < 1e-2          # ... and nowhere grossly wrong
+
+
+def test_strict_equals_default_where_K_uu_is_well_conditioned():
+    """Away from the ladder the two modes are the same numbers (1e-9): BASELINE config 1 at its exact size."""
+    g = np.load(os.path.join(GOLDEN, "ref_c1_exact.npz"))
+    a, qa, _ = _run(g, True)
+    b, qb, _ = _run(g, False)
+    for k in KEYS:
+        assert rel_norm(a[k], b[k]) < 1e-9, k
+        assert rel_norm(a[k], g[k]) < 1e-8, k
+    for k in qa:
+        assert rel_norm(qa[k], qb[k]) < 1e-9, k
