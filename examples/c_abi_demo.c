@@ -33,7 +33,10 @@ int main(void) {
   cfg.abi_version = HMOGP_ABI_VERSION;
   cfg.T = T, cfg.Q = Q, cfg.M = M, cfg.P = P, cfg.Df = Df;
   cfg.lik_id = lik_id, cfg.lik_param = lik_param, cfg.f_index = f_index, cfg.d_index = d_index;
-  cfg.device = 0, cfg.chunk_rows = 0, cfg.flags = 0, cfg.quirks = HMOGP_QUIRKS_REFERENCE;
+  cfg.device = 0, cfg.chunk_rows = 0, cfg.quirks = HMOGP_QUIRKS_REFERENCE;
+  /* regular kernels also for this small model: a sharded step (hmogp_elbo_grad_sharded) never takes the fused small-model
+   * kernels, and the demo shows that its one-rank exchange is BIT-identical to the plain call */
+  cfg.flags = HMOGP_CFG_NO_SMALL_PATH;
   hmogp_handle h = NULL;
   CHECK(hmogp_create(&cfg, &h));
 

@@ -339,6 +339,7 @@ struct hmogp_engine {
   // N x M workspaces and row vectors
   long long ws_rows = 0;
   DevBuf Kh, Pt, vp, vc, vpt, vct, valpha, vbeta, valpha0, vbeta0;
+  DevBuf colred;               // [Q][M] per-column sums of E .* r2 (column statistics) before they are added into sl_q
   DevBuf stats, wire, slabs, colpart, quadpart, fwdpart, winrow, wincol, winhit, Xws, dstage;
   long long nwire = 0;  // float64 words of the wire format (lower triangles of H_q only; rowpass.hip: wire_tri_kernel)
   int* h_info = nullptr;     // page-locked landing buffer of the factorisation's info flags
@@ -807,7 +808,8 @@ struct hmogp_engine {
     drop_graphs(true);   // (the evaluation that grows the workspaces runs normally to its end: its key stays warm)
     for (DevBuf* b : {&vp, &vc, &vpt, &vct, &valpha, &vbeta, &valpha0, &vbeta0}) b->ensure(nv, true);
     if (strict) Ah.ensure(nm), vpg.ensure(nv, true), vcg.ensure(nv, true);
-    colpart.ensure(sizeof(double) * std::max((rows + 255) / 256, (std::min<long long>(rows, 16384) + 31) / 32) * M * (1 + P) * Q);
+    colpart.ensure(sizeof(double) * std::max((rows + 255) / 256, (std::min<long long>(rows, 16384) + 31) / 32) * M * (2 + P) * Q);
+    colred.ensure(sizeof(double) * M * Q);
     quadpart.ensure(sizeof(double) * (rows * 64 / 256 + 1 + HMOGP_QUAD_MULTI) * HMOGP_MAXSCAL);
     fwdpart.ensure(sizeof(double) * 4 * FWD_PARTS * ((M + 127) / 128) * rows * Q);  // 4 statistics x FWD_PARTS wave columns per tile
     if (use_windows) {
@@ -1204,7 +1206,10 @@ struct hmogp_engine {
       // Forward contraction for all latents (batched), row statistics fused into its epilogue; P~ itself is only stored
       // when the Z gradient (its one remaining consumer, colstats) is requested.  One launch per pool.
       const long long sPart = 4LL * FWD_PARTS * tiles * ldn;
-      const long long clen = (long long)M * (1 + P);          // one column-statistics slab: [ r (M) | dZ (M*P) ]
+      const long long clen = (long long)M * (2 + P);          // one column-statistics slab: [ r (M) | dZ (M*P) | s2 (M) ]
+      // [r5] the r2-weighted statistic of the lengthscale gradient comes from the column statistics (E and x - z are in hand there),
+      // not from two more row statistics of the forward epilogue; strict q(f) keeps its own (strict_rowstats_kernel, GPy's r2 form)
+      const bool col_sl = want_hyper && !strict && !small_rows;
       // slabs of the column statistics: 256-row splits
       const long long csplit = col_split(n);
       const long long nsp = (n + csplit - 1) / csplit;        // slabs of the column statistics
@@ -1216,7 +1221,8 @@ struct hmogp_engine {
         qa.y = k.Y.d() + sg.r0;
         qa.yaux = k.Yaux.p ? k.Yaux.d() + sg.r0 : nullptr;
         qa.p = vp.d() + sg.off, qa.c = vc.d() + sg.off;
-        qa.pt = want_hyper ? vpt.d() + sg.off : nullptr, qa.ct = want_hyper ? vct.d() + sg.off : nullptr;
+        const bool row_sl = want_hyper && !col_sl;    // (small-model / strict paths: sl from the row statistics p~, c~)
+        qa.pt = row_sl ? vpt.d() + sg.off : nullptr, qa.ct = row_sl ? vct.d() + sg.off : nullptr;
         qa.ldn = ldn;
         std::memset(qa.w, 0, sizeof(qa.w)), std::memset(qa.w0, 0, sizeof(qa.w0)), std::memset(qa.kap, 0, sizeof(qa.kap));
         std::memset(qa.var, 0, sizeof(qa.var));
@@ -1254,16 +1260,18 @@ struct hmogp_engine {
         // streams K^ and P~ at 4.5 TB/s for 8.7 ms, evicts the Gram's operand panels from the L2s and stretches it from
         // 39.3 to 45.4 ms; 192 blocks take 32 ms of the Gram's 40 at 1.2 TB/s and stretch it to 39.9 (profiles/
         // r03_colstats_cap.txt: step 126.8 -> 120.7 ms).  Bytes per Gram flop scale with 1 / M, so the cap does too.
+        // [r5] the blocks also accumulate the r2-weighted statistic now (a third more arithmetic per element): 192 blocks took 42.7 ms,
+        // longer than the Gram's 39.6; 256 take 37.5 and leave the Gram at 39.4 (gpurun_out/cap_sweep.log -> profiles/r05_colstats_cap.txt).
         static const int cap_env = [] {   // HMOGP_COLSTATS_CAP=<blocks in flight> (0 = one block per row split)
           const char* e = getenv("HMOGP_COLSTATS_CAP");
           return e ? atoi(e) : -1;
         }();
         // (exact-zero windows: the banded Gram is short; the cap was sized for the dense one)
         // (P > 1: more arithmetic per byte -- a block streams 4.8 instead of 6.3 GB/s at P = 2 -- so proportionally more of them)
-        const int cap = cap_env >= 0 ? cap_env : (use_windows ? 0 : std::max(48, (int)(196608.0 * (1.0 + 0.35 * (P - 1)) / std::max(1, M))));
+        const int cap = cap_env >= 0 ? cap_env : (use_windows ? 0 : std::max(48, (int)(262144.0 * (1.0 + 0.35 * (P - 1)) / std::max(1, M))));
         launch_colstats(Kh.d() + off * M, Pt.d() + off * M, a.d(), valpha.d() + off, valpha0.d() + off, vbeta0.d() + off,
                         X + off * P, P, dZ.d(), ldz, rows, M, (int)csplit, want_z, colpart.d() + slab_first * clen, st2, cw, &cb, cap,
-                        strict ? Ah.d() + off * M : nullptr);
+                        strict ? Ah.d() + off * M : nullptr, col_sl ? dell.d() : nullptr);
       };
 
       SmallRows sr;
@@ -1300,15 +1308,15 @@ struct hmogp_engine {
           g.nbatch = Q;
           g.role = 1;
           g.fs_part = fwdpart.d() + 4LL * FWD_PARTS * tiles * off, g.fs_sPart = sPart, g.fs_a = a.d(), g.fs_sA = M, g.fs_x = X + off * P;
-          g.fs_z = dZ.d(), g.fs_sZ = P, g.fs_ldz = ldz, g.fs_P = P, g.fs_hyper = want_hyper ? 1 : 0, g.fs_ell = dell.d();
-          g.store_c = want_z ? 1 : 0;
+          g.fs_z = dZ.d(), g.fs_sZ = P, g.fs_ldz = ldz, g.fs_P = P, g.fs_hyper = 0, g.fs_ell = dell.d();
+          g.store_c = (want_z || want_hyper) ? 1 : 0;     // P~ is consumed by the column statistics (dZ and, [r5], sl)
           g.win = rw, g.win_stride = 2 * wtiles;
           nparts = launch_gemm_rowpass_or_general(g, st);
         }
         {
           Scope sc2(this, CAT_ROWSTATS, 1);  // sum of the per-column-tile partials of the fused row statistics
           launch_combine_parts(fwdpart.d() + 4LL * FWD_PARTS * tiles * off, nparts * tiles, rows, vp.d() + off, vc.d() + off,
-                               want_hyper ? vpt.d() + off : nullptr, want_hyper ? vct.d() + off : nullptr, st, Q, sPart, ldn);
+                               nullptr, nullptr, st, Q, sPart, ldn);
         }
       }
       // small models: every segment of the pool in ONE quadrature launch, its block partials summed by small_red_kernel
@@ -1378,7 +1386,11 @@ struct hmogp_engine {
         }
         {
           Scope sc(this, CAT_COLSTATS, 1, st2);   // all 256-row slabs of the pool -> bundle
-          launch_reduce_slabs(colpart.d(), (int)nsp, clen, clen, Hq(0) + oR, true, st2, Q, nsp * clen, per_q);
+          launch_reduce_slabs(colpart.d(), (int)nsp, clen, (long long)M * (1 + P), Hq(0) + oR, true, st2, Q, nsp * clen, per_q);
+          if (col_sl) {   // per-column s2 -> [Q][M] -> added into sl_q in a fixed order
+            launch_reduce_slabs(colpart.d() + (long long)M * (1 + P), (int)nsp, clen, M, colred.d(), false, st2, Q, nsp * clen, M);
+            launch_sum_cols(colred.d(), Q, M, Hq(0) + oSL, per_q, st2);
+          }
         }
         HIP_TRY(hipEventRecord(ev_col, st2));
         Scope sc2(this, CAT_COLSTATS, 1);  // row-range slabs -> bundle (accounted with the column statistics)
@@ -1422,9 +1434,10 @@ struct hmogp_engine {
         const char* e = getenv("HMOGP_SMALL_PATH");
         return e ? atoi(e) : 1;
       }();
-      // (with a communicator attached the path must not depend on this rank's row count: every rank takes the regular kernels,
-      //  so that the replicated M x M algebra -- and with it the never re-synchronised resident q(u) replicas -- rounds alike)
-      small_path = small_mode && M <= HMOGP_SMALL_M && path_env != 0 && !small_veto && !comm;
+      // (a SHARDED step -- hmogp_elbo_grad_sharded, or hmogp_step_begin with a communicator attached -- must not choose its path
+      //  from this rank's row count: every rank takes the regular kernels, so that the replicated M x M algebra, and with it the
+      //  never re-synchronised resident q(u) replicas, round alike on all ranks.  ADVICE r4.  Plain hmogp_elbo_grad is unaffected.)
+      small_path = small_mode && M <= HMOGP_SMALL_M && path_env != 0 && !small_veto && !(comm && sharded_call);
       small_info_pending = false;
       static const int rows_env = [] {   // HMOGP_SMALL_ROWS=0: the regular row-pass kernels behind the fused M x M kernels (A/B runs)
         const char* e = getenv("HMOGP_SMALL_ROWS");
@@ -1433,8 +1446,10 @@ struct hmogp_engine {
       small_rows = small_path && rows_env != 0;
     }
 
+  bool sharded_call = false;
   void begin(const hmogp_params* p, bool sync = true, bool will_exchange = false) {
     HIP_TRY(hipSetDevice(device));
+    sharded_call = will_exchange || sync;      // (hmogp_step_begin is the first half of a split, i.e. exchanged, step)
     began = false, exchanged = false;
     spans.clear();  // a failed evaluation may have left unmatched timing spans behind
     pool_used = 0;

@@ -254,14 +254,13 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
     // slice a has been consumed (into the buffer it frees): every slice but the first has two consumption periods to land
     // in.  The waits count on loads returning in order: s_waitcnt vmcnt(4) with [slice a | stores | slice a + 1] outstanding
     // can only be satisfied once slice a has landed (were one of its 4 loads outstanding, so were all 4 of slice a + 1).
-    const int P = g.fs_P;
-    const bool hyper = g.fs_hyper != 0;
+    // [r5] TWO statistics (p = K^ a, c = rowsum(P~ .* K^)).  Their r2-weighted twins (only ever consumed as the scalar sl of the
+    // lengthscale gradient) moved to colstats_kernel, which forms E_nm and x_n - z_m anyway: no per-element distances, no
+    // `hyper` branch and no inputs staged here any more.
     constexpr int NCH = 2 * NB, WSTAGE = 2 * NCH * 128;
     double* flat = &lds.a[0][0];                  // Tile = 4 * TILE_DOUBLES contiguous doubles
     double* stg = flat + w * WSTAGE;              // [2 buffers][NCH chunks][64 lanes][2]
-    double* xs = flat + W * WSTAGE;               // [4][128] inputs of the block's rows / lengthscale (dimension-major)
-    double* zs = xs + 4 * 128;                    // [4][128] inducing inputs of the block's columns / lengthscale
-    static_assert(W * WSTAGE + 2 * 4 * 128 <= 4 * TILE_DOUBLES, "epilogue scratch fits the tile buffers");
+    static_assert(W * WSTAGE <= 4 * TILE_DOUBLES, "epilogue scratch fits the tile buffers");
     const int colq = j0 + wn * WN + 4 * lk;       // + b*16 (+ 2h)
     auto issue = [&](int a) {
       const int grow = min(i0 + wm * 64 + a * 16 + lr, M - 1);
@@ -274,22 +273,14 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
     };
     issue(0);
     issue(1);
-    {
-      const double inv_l = 1.0 / g.fs_ell[batch];
-      for (int e = t; e < 4 * 128; e += NT) {
-        const int p = e >> 7, rr = e & 127;
-        xs[e] = (hyper && i0 + rr < M && p < P) ? g.fs_x[(long long)(i0 + rr) * P + p] * inv_l : 0.0;
-        zs[e] = (hyper && p < P) ? g.fs_z[(long long)batch * g.fs_sZ + (long long)(j0 + rr) * g.fs_ldz + p] * inv_l : 0.0;
-      }
-      if (t < 128) epi_a[t] = g.fs_a[(long long)batch * g.fs_sA + j0 + t];
-    }
+    if (t < 128) epi_a[t] = g.fs_a[(long long)batch * g.fs_sA + j0 + t];
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       if (a < 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // slice a has landed; slice a + 1 may still be in flight
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int rl = wm * 64 + a * 16 + lr;
-      double sp = 0.0, sc = 0.0, spt = 0.0, sct = 0.0;
+      double sp = 0.0, sc = 0.0;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const int cl = wn * WN + b * 16 + 4 * lk;  // this lane's 4 adjacent columns of sub-tile b (within the tile)
@@ -298,46 +289,21 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
         const double kv[4] = {k01.x, k01.y, k23.x, k23.y};
         const f64x2 a01 = *reinterpret_cast<const f64x2*>(epi_a + cl), a23 = *reinterpret_cast<const f64x2*>(epi_a + cl + 2);
         const double av[4] = {a01.x, a01.y, a23.x, a23.y};
-        double r2[4] = {0.0, 0.0, 0.0, 0.0};
-        if (hyper) {
-#pragma unroll 1
-          for (int p = 0; p < P; ++p) {              // uniform trip count (P <= 4); rolled: bounded register pressure
-            const f64x2 z01 = *reinterpret_cast<const f64x2*>(zs + p * 128 + cl), z23 = *reinterpret_cast<const f64x2*>(zs + p * 128 + cl + 2);
-            const double zz[4] = {z01.x, z01.y, z23.x, z23.y};
-            const double xp = xs[p * 128 + rl];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const double d = xp - zz[r];
-              r2[r] += d * d;
-            }
-          }
-        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const double pv = acc[a][b][r];
           sp += kv[r] * av[r];
-          sc += pv * kv[r];
-          if (hyper) {
-            const double wv = kv[r] * r2[r];
-            spt += wv * av[r];
-            sct += pv * wv;
-          }
+          sc += acc[a][b][r] * kv[r];
         }
       }
 #pragma unroll
       for (int o = 16; o <= 32; o <<= 1) {           // the four lanes (lk) that share this row
         sp += __shfl_xor(sp, o, 64);
         sc += __shfl_xor(sc, o, 64);
-        if (hyper) {
-          spt += __shfl_xor(spt, o, 64);
-          sct += __shfl_xor(sct, o, 64);
-        }
       }
       if (lk == 0 && i0 + rl < M) {                  // partial of (column tile, wave column): [stat][4 * tiles_n][M]
         double* o = fs_part + ((long long)(NWN * tj + wn)) * M + (i0 + rl);
         const long long ss = (long long)NWN * tiles_n * M;
         o[0] = sp, o[ss] = sc;
-        if (hyper) o[2 * ss] = spt, o[3 * ss] = sct;
       }
       if (a < 2) {                                   // slice a is consumed: its buffer takes slice a + 2
         asm volatile("" ::: "memory");

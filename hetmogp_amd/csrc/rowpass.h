@@ -121,7 +121,9 @@ void launch_windows(const double* X, long long N, int P, const double* Z, int ld
 void launch_colstats(const double* Kh, const double* Pt, const double* a, const double* alpha, const double* alpha0,
                      const double* beta0, const double* X, int P, const double* Z, int ldz, long long N, int M, int rows,
                      bool want_z, double* partials, hipStream_t s, const int* colwin = nullptr, const ColBatch* batch = nullptr,
-                     int max_blocks = 0, const double* Ar = nullptr);
+                     int max_blocks = 0, const double* Ar = nullptr, const double* ell = nullptr);
+// partial slab per row split: [ r (M) | dZ (M*P) | s2 (M) ], s2[m] = sum_n E_nm |x_n - z_m|^2 / l^2 when `ell` ([nq], device) is given
+void launch_sum_cols(const double* v, int Q, int M, double* dst, long long sDst, hipStream_t s);   // dst[q * sDst] += sum_m v[q][m]
 void launch_reduce_rows(const double* partials, long long nrows, int len, const long long* off, double* dst, bool accumulate,
                         hipStream_t s);
 void launch_reduce_slabs(const double* slabs, int nslabs, long long stride, long long len, double* dst, bool accumulate,

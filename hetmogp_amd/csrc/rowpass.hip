@@ -416,17 +416,19 @@ __global__ __launch_bounds__(256) void quad_multi_kernel(QuadMulti m) {
 
 
 // ---- colstats: thread = 2 columns, block = 512 columns x `rows` rows ----------------------------------------
-template <int P>
+// STRICT (HMOGP_CFG_STRICT_QF only): r = A^T alpha from a second matrix and quirk Q10's r == 0 gating -- kept out of the hot-path
+// instantiation, which has to fit 64 registers to run beside the Gram.
+template <int P, bool STRICT>
 __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restrict__ Kh, const double* __restrict__ Pt,
                                                        const double* __restrict__ a, const double* __restrict__ alpha,
                                                        const double* __restrict__ alpha0, const double* __restrict__ beta0,
                                                        const double* __restrict__ X, const double* __restrict__ Z, int ldz,
                                                        long long N, int M, int rows, int want_z,
                                                        double* __restrict__ partials, const int* __restrict__ colwin,
-                                                       ColBatch bt, const double* __restrict__ Ar) {
+                                                       ColBatch bt, const double* __restrict__ Ar, const double* __restrict__ ell) {
   {  // batched over the latents (grid.z)
     const long long q = blockIdx.z;
-    if (Ar) Ar += q * bt.sK;
+    if (STRICT) Ar += q * bt.sK;
     Kh += q * bt.sK, Pt += q * bt.sK, a += q * bt.sA, alpha += q * bt.sV, alpha0 += q * bt.sV, beta0 += q * bt.sV;
     Z += q * bt.sZ, partials += q * bt.sPart;
     if (colwin) colwin += q * bt.sWin;
@@ -442,7 +444,11 @@ __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restri
     z1[p] = two ? Z[(long long)(c + 1) * ldz + p] : 0.0;
   }
   const double a0 = a[c], a1 = two ? a[c + 1] : 0.0;
-  const double zs0 = sumsq<P>(z0), zs1 = sumsq<P>(z1);
+  const double zs0 = STRICT ? sumsq<P>(z0) : 0.0, zs1 = STRICT ? sumsq<P>(z1) : 0.0;
+  // [r5] ell != nullptr: also  s2[m] = sum_n E_nm |x_n - z_m|^2 / l^2  -- the r2-weighted statistic behind the lengthscale gradient
+  // (sl = sum_m s2[m]; svmogp.py:140 -> GPy update_gradients_full).  It used to be carried by the forward contraction's epilogue
+  // as two more row statistics (p~, c~) with the distances recomputed per element there; E_nm and x_n - z_m are in hand here.
+  const bool want_e = want_z || ell;
   // A block takes the row splits blockIdx.y, blockIdx.y + gridDim.y, ...: the grid may be CAPPED (launch_colstats) so that
   // this HBM-bound pass occupies only a few CU slots at a time beside the FP64-MFMA Gram it runs next to -- a block that
   // holds half a CU while it waits for HBM keeps a Gram block (whose registers fill the other half) from being scheduled.
@@ -453,7 +459,7 @@ __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restri
       n0 = max(n0, (long long)colwin[2 * (c >> 7)]);
       n1 = min(n1, (long long)colwin[2 * (c >> 7) + 1]);
     }
-    double r0 = 0.0, r1 = 0.0, d0[P], d1[P];
+    double r0 = 0.0, r1 = 0.0, d0[P], d1[P], s20 = 0.0, s21 = 0.0;
 #pragma unroll
     for (int p = 0; p < P; ++p) d0[p] = d1[p] = 0.0;
     for (long long n = n0; n < n1; ++n) {
@@ -461,30 +467,30 @@ __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restri
       if (vec) {
         const f64x2 kv = *reinterpret_cast<const f64x2*>(Kh + n * M + c);
         k0 = kv.x, k1 = kv.y;
-        if (want_z) {
+        if (want_e) {
           const f64x2 qv = *reinterpret_cast<const f64x2*>(Pt + n * M + c);
           q0 = qv.x, q1 = qv.y;
         }
       } else {
         k0 = Kh[n * M + c];
         k1 = two ? Kh[n * M + c + 1] : 0.0;
-        if (want_z) {
+        if (want_e) {
           q0 = Pt[n * M + c];
           q1 = two ? Pt[n * M + c + 1] : 0.0;
         }
       }
       const double al = alpha[n];
-      if (Ar) {   // strict q(f): r = A^T alpha with A = K^ Kuu^-1 (dVE_dmu of svmogp_inf.py:144 as the reference forms it)
+      if (STRICT) {   // strict q(f): r = A^T alpha with A = K^ Kuu^-1 (dVE_dmu of svmogp_inf.py:144 as the reference forms it)
         r0 += Ar[n * M + c] * al;
         r1 += (two ? Ar[n * M + c + 1] : 0.0) * al;
       } else {
         r0 += k0 * al;
         r1 += k1 * al;
       }
-      if (want_z) {
+      if (want_e) {
         const double al0 = alpha0[n], be0 = 2.0 * beta0[n];
         double e0 = (al0 * a0 + be0 * q0) * k0, e1 = (al0 * a1 + be0 * q1) * k1;
-        if (Ar) {   // strict mode also restates quirk Q10: GPy's gradients_X drops the entries whose COMPUTED (expanded-form)
+        if (STRICT) {   // strict mode also restates quirk Q10: GPy's gradients_X drops the entries whose COMPUTED (expanded-form)
                     // distance is exactly 0 -- visible for un-centred inputs only, where that form clips small distances to 0
           double xv[P];
 #pragma unroll
@@ -493,16 +499,24 @@ __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restri
           if (rbf_r2_fast<P>(xv, xsq, z0, zs0, 1.0) == 0.0) e0 = 0.0;
           if (rbf_r2_fast<P>(xv, xsq, z1, zs1, 1.0) == 0.0) e1 = 0.0;
         }
+        double q20 = 0.0, q21 = 0.0;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           const double x = X[n * P + p];
-          d0[p] += e0 * (x - z0[p]);
-          d1[p] += e1 * (x - z1[p]);
+          const double dx0 = x - z0[p], dx1 = x - z1[p];
+          d0[p] += e0 * dx0;
+          d1[p] += e1 * dx1;
+          q20 += dx0 * dx0, q21 += dx1 * dx1;
         }
+        s20 += e0 * q20;
+        s21 += e1 * q21;
       }
     }
-    // partial layout per row-split: [ r (M) | dZ (M*P) ]
-    double* out = partials + sp * ((long long)M * (1 + P));
+    // partial layout per row-split: [ r (M) | dZ (M*P) | s2 (M) ]
+    double* out = partials + sp * ((long long)M * (2 + P));
+    const double il2 = ell ? 1.0 / (ell[blockIdx.z] * ell[blockIdx.z]) : 0.0;   // (scaled once per split, not per element)
+    out[(long long)M * (1 + P) + c] = s20 * il2;
+    if (two) out[(long long)M * (1 + P) + c + 1] = s21 * il2;
     out[c] = r0;
     if (two) out[c + 1] = r1;
 #pragma unroll
@@ -926,7 +940,7 @@ void launch_log_predictive(int lik, int J, double param, long long N, int S, uns
 void launch_colstats(const double* Kh, const double* Pt, const double* a, const double* alpha, const double* alpha0,
                      const double* beta0, const double* X, int P, const double* Z, int ldz, long long N, int M, int rows,
                      bool want_z, double* partials, hipStream_t s, const int* colwin, const ColBatch* batch, int max_blocks,
-                     const double* Ar) {
+                     const double* Ar, const double* ell) {
   if (N <= 0) return;
   ColBatch bt = batch ? *batch : ColBatch{};
   dim3 grid((M + 511) / 512, (unsigned)((N + rows - 1) / rows), batch ? batch->nq : 1);
@@ -934,8 +948,26 @@ void launch_colstats(const double* Kh, const double* Pt, const double* a, const 
     const long long per_y = (long long)grid.x * grid.z;
     grid.y = (unsigned)std::max<long long>(1, std::min<long long>(grid.y, max_blocks / per_y));
   }
-  DISPATCH_P(P, hipLaunchKernelGGL((colstats_kernel<PP>), grid, dim3(256), 0, s, Kh, Pt, a, alpha, alpha0, beta0, X, Z, ldz,
-                                   N, M, rows, want_z ? 1 : 0, partials, colwin, bt, Ar));
+  if (Ar) {
+    DISPATCH_P(P, hipLaunchKernelGGL((colstats_kernel<PP, true>), grid, dim3(256), 0, s, Kh, Pt, a, alpha, alpha0, beta0, X, Z, ldz,
+                                     N, M, rows, want_z ? 1 : 0, partials, colwin, bt, Ar, ell));
+  } else {
+    DISPATCH_P(P, hipLaunchKernelGGL((colstats_kernel<PP, false>), grid, dim3(256), 0, s, Kh, Pt, a, alpha, alpha0, beta0, X, Z, ldz,
+                                     N, M, rows, want_z ? 1 : 0, partials, colwin, bt, Ar, ell));
+  }
+}
+
+// dst[q * sDst] += sum_m v[q][m]   (the per-column s2 of the column statistics -> the bundle's sl_q; fixed order)
+__global__ __launch_bounds__(256) void sum_cols_kernel(const double* __restrict__ v, int M, double* __restrict__ dst, long long sDst) {
+  __shared__ double scratch[16];
+  const double* x = v + (long long)blockIdx.x * M;
+  double s = 0.0;
+  for (int m = threadIdx.x; m < M; m += 256) s += x[m];
+  s = block_sum(s, scratch);
+  if (threadIdx.x == 0) dst[(long long)blockIdx.x * sDst] += s;
+}
+void launch_sum_cols(const double* v, int Q, int M, double* dst, long long sDst, hipStream_t s) {
+  hipLaunchKernelGGL(sum_cols_kernel, dim3(Q), dim3(256), 0, s, v, M, dst, sDst);
 }
 
 // ---- strict q(f) (HMOGP_CFG_STRICT_QF): row statistics of the solve-based forms of svmogp_inf.py:212-218 ------------------------

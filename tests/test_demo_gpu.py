@@ -54,7 +54,7 @@ def test_plain_c_program_through_the_abi_matches_the_ctypes_binding(tmp_path):
     m_u = 0.5 * np.sin(1.0 + 3.0 * m + q)
     rr, cc = np.tril_indices(M)
     L_flat = np.where((rr == cc)[:, None], 1.0, 0.02 * np.cos(1.0 + rr[:, None] + 2.0 * cc[:, None] + q))
-    e = Engine([("Gaussian", {"sigma": 0.5}), ("Bernoulli", {})], Q, M, 1)
+    e = Engine([("Gaussian", {"sigma": 0.5}), ("Bernoulli", {})], Q, M, 1, small_path=False)   # (the demo sets HMOGP_CFG_NO_SMALL_PATH)
     e.set_data([X0[:, None], X1[:, None]], [Y0, Y1])
     out = e.elbo_grad(Z=Z, m_u=m_u, L_flat=L_flat, variance=[0.5, 0.7], lengthscale=[0.08, 0.11],
                       W=[[0.9, -0.4], [0.3, 0.8]], kappa=np.zeros((2, 2)))

@@ -67,7 +67,10 @@ def test_native_exchange_one_rank_communicator():
     from hetmogp_amd._lib import HetMOGPError
     assert comm_available()
     specs, prm, X, Y = _case()
-    e = Engine(specs, 3, 64, 1)
+    # (small_path=False: a SHARDED step never takes the fused small-model kernels -- its path must not depend on one rank's row
+    #  count, ADVICE r4 -- so bit-identity with the plain call is asserted on the regular kernels; the small path's plain call
+    #  agrees with them to rounding, checked at the end)
+    e = Engine(specs, 3, 64, 1, small_path=False)
     e.set_data(X, Y)
     full = e.elbo_grad(**prm)
     assert e.timings()[0]["exchange"] == 0.0 and e.comm_info() == (0, -1)
@@ -93,6 +96,16 @@ def test_native_exchange_one_rank_communicator():
     with pytest.raises(ValueError):
         e.elbo_grad(sharded=True, **dict(prm, row_begin=[0] * len(X), row_end=[x.shape[0] + 1 for x in X]))
     assert e.comm_info() == (0, -1)
+    es = Engine(specs, 3, 64, 1)                                          # default: fused small-model kernels for the plain call ...
+    es.set_data(X, Y)
+    small = es.elbo_grad(**prm)
+    es.comm_init(1, 0, comm_unique_id())
+    shard = es.elbo_grad(sharded=True, **prm)                            # ... regular kernels for the sharded one
+    for k in ("elbo", "g_m_u", "g_L_u", "g_Z", "g_W", "g_variance", "g_lengthscale"):
+        a, b = np.asarray(shard[k], float), np.asarray(small[k], float)
+        assert np.max(np.abs(a - b)) <= 1e-9 * np.max(np.abs(b)), k
+        assert np.array_equal(np.asarray(shard[k]), np.asarray(full[k])), k
+    es.close()
     with pytest.raises(HetMOGPError):
         e.elbo_grad(sharded=True, **prm)                                 # no communicator any more: E_STATE, not a hang
     e.comm_init(1, 0, comm_unique_id())
@@ -290,6 +303,38 @@ def test_bench_self_launches_two_ranks():
     assert line["allreduce_ms_per_step"] > 0.0 and line["reducer_mode"] == "native"
     assert "native" in line["exchange_modes_ms_per_step"]          # ("device" is timed too wherever torch can alias the buffer)
     assert len(line["replicated_ms_per_rank"]) == 2
+
+
+@pytest.mark.timeout(900)
+def test_bench_force_dist_one_rank_dry_run():
+    """`python bench.py --gpus 1 --force-dist`: the whole distributed branch of bench.py (nccl process group, proof all-reduce,
+    StatsReducer negotiation with its flag reductions, the library's own RCCL communicator, hmogp_elbo_grad_sharded as the step,
+    the alternative-exchange-mode loop, gathers, teardown order) with a world of ONE rank -- so that the first real multi-GPU
+    launch cannot die on Python.  Its line must agree with the plain single-GPU line of the same workload."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    common = ["--gpus", "1", "--steps", "4", "--warmup", "2", "--rows", "50000", "--inducing", "512"]
+
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + extra, env=env, capture_output=True,
+                           text=True, timeout=800)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]                      # the contract: ONE JSON line on stdout
+        return json.loads(lines[0])
+
+    forced = run(["--force-dist"])
+    plain = run(["--no-other-configs", "--no-cpu-baseline", "--no-exact-zero-pass"])
+    assert forced["force_dist"] is True and forced["n_gpus"] == 1 and forced["rccl_ranks"] == 1
+    assert forced["reducer_mode"] == "native" and forced["allreduce_ms_per_step"] > 0.0
+    assert set(forced["exchange_modes_ms_per_step"]) >= {"native"}
+    assert forced["rows_per_rank"] == [4 * 50000] and len(forced["replicated_ms_per_rank"]) == 1
+    assert forced["allreduce_bytes"] > 0
+    assert abs(forced["elbo"] - plain["elbo"]) <= 1e-12 * abs(plain["elbo"])      # same numbers ...
+    assert forced["ms_per_step"] < 1.25 * plain["ms_per_step"] + 0.5               # ... in the same time (+ one-rank exchange)
+    print("force-dist %.3f ms/step (exchange %.3f) vs plain %.3f ms/step; modes %s" % (
+        forced["ms_per_step"], forced["allreduce_ms_per_step"], plain["ms_per_step"], forced["exchange_modes_ms_per_step"]))
 
 
 def _facade_nccl_worker(rank, world, port, q):
