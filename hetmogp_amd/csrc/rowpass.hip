@@ -490,8 +490,12 @@ __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restri
       if (want_e) {
         const double al0 = alpha0[n], be0 = 2.0 * beta0[n];
         double e0 = (al0 * a0 + be0 * q0) * k0, e1 = (al0 * a1 + be0 * q1) * k1;
-        if (STRICT) {   // strict mode also restates quirk Q10: GPy's gradients_X drops the entries whose COMPUTED (expanded-form)
-                    // distance is exactly 0 -- visible for un-centred inputs only, where that form clips small distances to 0
+        // Quirk Q10 (STRICT only): GPy's gradients_X drops the entries whose COMPUTED distance -- the expanded form |x|^2 + |z|^2 -
+        // 2 x.z, clipped -- is exactly 0.  That needs |x - z|^2 below a few ulp of |z|^2: un-centred inputs, or, at 1e6 rows per
+        // task, the odd row within 1.5e-8 |z| of an inducing point (one such row in the full-size C4 test: 4e-8 of one g_Z entry).
+        // The default path keeps those terms (they are the mathematically correct ones): an in-loop test, even behind a cheap
+        // pre-test, costs this kernel 16 spilled registers -- and it has to fit 64 to run beside the Gram.
+        if (STRICT) {
           double xv[P];
 #pragma unroll
           for (int p = 0; p < P; ++p) xv[p] = X[n * P + p];

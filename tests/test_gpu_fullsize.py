@@ -143,6 +143,9 @@ def test_C4_full_size_pools():
         #  differences of terms ~1e3 x larger; as in check_config(calibrate=True) the yardstick is the distance between the
         #  oracle's own literal (solve-based) and fused restatements, capped at 1e-7)
         tol = min(1e-7, max(1e-8, 10.0 * rel(want[k], lit[k])))
+        if k == "g_Z":     # quirk Q10 (GPy gradients_X drops entries whose computed distance is exactly 0): with 1e6 rows per task one
+            tol = 1e-7     # row lies within 1.5e-8 of the inducing point at 1.0; the oracle drops its term like the reference, the
+                           # engine's default mode keeps it (strict mode drops it): 4.3e-8 of that inducing point's entry
         print("C4 full, oracle window:", k, "engine-fused %.2e" % rel(got[k], want[k]), "fused-literal %.2e" % rel(want[k], lit[k]))
         assert rel(got[k], want[k]) < tol, ("oracle window", k, rel(got[k], want[k]), tol)
         assert elementwise_excess(got[k], want[k]) <= 1.0, ("oracle window, element-wise 1e-5", k)
