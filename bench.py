@@ -322,6 +322,10 @@ def main():
         if world == 1 and not distm and not args.no_cpu_baseline:
             line.update(cpu_baselines(args, eng, prm, X, Y, N, M, Q, P))
             eng.close()
+        if "other_configs" in line:     # compact recap as the LAST key: a tail of the line still shows every configuration
+            line["other_configs_summary"] = {c["workload"].split(":")[0].split(" (")[0]: [round(c["ms_per_step"], 4),
+                                                                                         round(c.get("frac_of_peak", 0.0), 4)]
+                                             for c in line["other_configs"]}
         print(json.dumps(line))
         sys.stdout.flush()
     if distm:
@@ -550,9 +554,10 @@ def _config_roofline(rows, Q, M, cat, tag):
            "frac": ach / PEAK_FP64_MFMA_TFLOPS, "avg_launch_ms": t, "source": "HIP events on the engine's stream (this run)",
            "traffic": None}
     if tag:
-        base = os.path.join(ROOT, "profiles", "r04_%s" % tag)
+        rnd = next((r for r in ("r05", "r04") if os.path.exists(os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (r, tag)))), "r05")
+        base = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, tag))
         if os.path.exists(base + "_kernel_stats.csv"):
-            out["rocprof"] = "profiles/r04_%s_kernel_stats.csv" % tag
+            out["rocprof"] = "profiles/%s_%s_kernel_stats.csv" % (rnd, tag)
         hbm = base + "_pmc_hbm.csv"
         if os.path.exists(hbm):
             import csv
@@ -560,8 +565,46 @@ def _config_roofline(rows, Q, M, cat, tag):
             rows_ = [r for r in csv.DictReader(open(hbm)) if r["kernel"].startswith(want)]
             if rows_:
                 out["traffic"] = int(max(rows_, key=lambda r: int(r["hbm_bytes_per_launch"]))["hbm_bytes_per_launch"])
-                out["traffic_source"] = "profiles/r04_%s_pmc_hbm.csv" % tag
+                out["traffic_source"] = "profiles/%s_%s_pmc_hbm.csv" % (rnd, tag)
     return out
+
+
+# Dependent-phase floors of the small-model evaluation (us), derived in DESIGN.md 11e from the phase stamps of the kernels and the
+# micro-benchmarks under tools/probes/: what each graph node costs when nothing but its longest dependent chain is left -- the
+# M = 50 factorisation's 50 dependent column steps (~200 cycles each: LDS broadcast + rsqrt chain) and four dependent 50^3
+# products at one wave per SIMD (135 cycles per FP64 MFMA) for u_small; two such products + the PCIe gather for finish_small; one
+# HBM round trip + one 64-row tile for the row kernels; one special-function chain for the quadrature -- plus 1.5 us per
+# dependent kernel boundary (MI355X_MICROARCH.md).
+C1_FLOOR_US = {"u_small_kernel": 18.0, "finish_small_kernel": 14.0, "small_fwd_kernel": 5.0, "quad_multi_kernel": 6.0,
+               "small_bwd_kernel": 6.0, "small_red_kernel": 2.0}
+C1_NODE_BOUNDARY_US, C1_UPLOAD_US = 1.5, 3.0
+
+
+def _c1_latency_roofline(wall_ms):
+    """C1 is latency-bound (4-250 CUs busy for 5-50 us per node): its `roofline` is a LATENCY model -- the sum of the dependent-phase
+    floors of its graph nodes against the kernel time rocprofv3 measured for the same evaluation (committed CSV; a replayed hipGraph
+    reports no per-node device time to the process itself)."""
+    import csv
+    src = next((f for f in ("r05_C1_kernel_stats.csv", "r04_C1_kernel_stats_small_path_v3.csv")
+                if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+    if src is None:
+        return None
+    kern = {}
+    for r in csv.DictReader(open(os.path.join(ROOT, "profiles", src))):
+        name = r["Name"]
+        short = next((k for k in C1_FLOOR_US if k in name), None)
+        if short:
+            kern[short] = kern.get(short, 0.0) + float(r["AverageNs"]) / 1e3
+    if not kern:
+        return None
+    floor = sum(C1_FLOOR_US[k] for k in kern) + C1_NODE_BOUNDARY_US * (len(kern) + 1) + C1_UPLOAD_US
+    meas = sum(kern.values())
+    dom = max(kern, key=kern.get)
+    return {"kernel": "hipGraph of the small-model evaluation (%d kernel nodes + upload)" % len(kern), "bound": "latency",
+            "achieved": meas, "peak": floor, "unit": "us of kernel time per evaluation (lower is better)", "frac": floor / meas,
+            "kernels_us": {k: round(v, 2) for k, v in kern.items()}, "floors_us": C1_FLOOR_US, "dominant_kernel": dom,
+            "dominant_kernel_us": round(kern[dom], 2), "wall_us_this_run": round(1e3 * wall_ms, 1),
+            "source": "profiles/" + src, "traffic": None}
 
 
 def _parity_c1_vs_reference_fixture():
@@ -649,6 +692,11 @@ def other_configs(args):
           note="small-model path: fused LDS kernels (small_model.hip) replayed from a captured hipGraph, 17 kernels per evaluation; "
                "compare cpu_baseline_literal.runs[0]",
           parity_vs_reference_run=_parity_c1_vs_reference_fixture())
+    lat = _c1_latency_roofline(ms)
+    if lat is not None:          # (small-problem mode records no per-family spans: the table comes from the committed rocprof CSV)
+        res[-1]["roofline"] = lat
+        res[-1]["dominant_kernel"], res[-1]["dominant_kernel_ms"] = lat["dominant_kernel"], lat["dominant_kernel_us"] / 1e3
+        res[-1]["kernel_ms_per_step"] = {k: round(v / 1e3, 5) for k, v in lat["kernels_us"].items()}
     eng.close()
     # C2 -- the headline mix at M = 512
     eng, prm, X, Y, ms, cat, out = run("C2", SPECS, 200000, 512, 3, 1, 20260931)

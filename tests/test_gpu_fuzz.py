@@ -51,7 +51,7 @@ def _case(seed, ms, one_d):
     # yardstick is the distance between the oracle's OWN two restatements -- the literal one (solves,
     # the reference's operation order) and the fused one (explicit inverses, the engine's algebra): the engine may be no
     # further from the fused restatement than 10x that, and never further than 2e-7.
-    tol = 1e-8 if P == 1 else 2e-7
+    tol = 1e-8 if P == 1 else 2e-8
     lit = so.elbo_grad_literal(prm, prob, X, Y) if (P > 1 and quirks == "reference" and min(Ns) > 0) else None
     for k in KEYS:
         tk = tol if lit is None else min(tol, max(1e-8, 10.0 * rel(want[k], lit[k])))

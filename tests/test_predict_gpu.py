@@ -37,22 +37,26 @@ def build(g):
     return model, [g["Xnew_%d" % t] for t in range(T)]
 
 
+@pytest.mark.parametrize("strict", [False, True], ids=["default", "strict"])
 @pytest.mark.parametrize("path", FILES, ids=os.path.basename)
-def test_predict_f_is_the_references_predictive_new(path):
-    """hmogp_predict_f (q(f_d) at new inputs from q(u)) == SVMOGP.predictive_new of the reference, for every function d."""
+def test_predict_f_is_the_references_predictive_new(path, strict):
+    """hmogp_predict_f (q(f_d) at new inputs from q(u)) == SVMOGP.predictive_new of the reference, for every function d.
+    [r5] The variance is a difference (explained - prior) that the default path forms through the explicit C_q: 1e-7 of its scale was
+    the tolerance of rounds 2-4.  Measured this round (tools/strict_tolerance_probe.py): it was the FORM, not the hardware -- the
+    strict mode (the reference's solve-based form, svmogp_inf.py:214-218) is held to 1e-9 here, the default to 1e-8."""
     from hetmogp_amd.engine import Engine
     g = np.load(path)
     specs = json.loads(str(g["spec"]))
     T, Q, M, P, Df = int(g["T"]), int(g["Q"]), int(g["M"]), int(g["P"]), int(g["Df"])
-    e = Engine(specs, Q, M, P)
+    e = Engine(specs, Q, M, P, strict_qf=strict)
     e.set_data([g["X_%d" % t] for t in range(T)], [g["Y_%d" % t] for t in range(T)])
     out = e.elbo_grad(Z=g["Z"], m_u=g["m_u"], L_flat=g["L_flat"], variance=g["variance"], lengthscale=g["lengthscale"],
                       W=g["W"], kappa=g["kappa"])
     assert abs(out["elbo"] - float(g["elbo"])) < 1e-8 * abs(float(g["elbo"]))
     for d in range(Df):
         m, v = e.predict_f(g["Xnew_%d" % int(g["f_index"][d])])
-        assert rel(m[:, d:d + 1], g["pn_m_%d" % d]) < 1e-8, d
-        assert rel(np.abs(v[:, d:d + 1]), g["pn_v_%d" % d]) < 1e-7, d
+        assert rel(m[:, d:d + 1], g["pn_m_%d" % d]) < (1e-9 if strict else 1e-8), d
+        assert rel(np.abs(v[:, d:d + 1]), g["pn_v_%d" % d]) < (1e-9 if strict else 1e-8), (d, rel(np.abs(v[:, d:d + 1]), g["pn_v_%d" % d]))
 
 
 @pytest.mark.parametrize("path", FILES, ids=os.path.basename)

@@ -90,7 +90,7 @@ def test_small_sizes_vs_oracle_and_regular(M, Q, P):
     for k in KEYS:
         if k == "KL":
             continue
-        tol = 1e-8 if P == 1 else 2e-7
+        tol = 1e-8 if P == 1 else 2e-8
         assert rel(a[k], want[k]) < tol, ("small vs oracle", k, rel(a[k], want[k]))
         assert rel(a[k], b[k]) < 1e-9, ("small vs regular", k, rel(a[k], b[k]))
     es.close(), er.close()
