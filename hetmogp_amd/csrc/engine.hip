@@ -1602,10 +1602,17 @@ struct hmogp_engine {
     // the small results (head of the bundle, KL partials, per-latent tails, K_uu-side rows) are gathered device-side and
     // leave in ONE copy into a page-locked buffer: ten separate pageable copies cost 0.3 ms of gaps
     if (!small_path) {
-      double* d = dstage.d();
+      // [r5] gathered STRAIGHT into the page-locked host block (its device-side address), like the small-model path: the separate
+      // D2H copy command behind the gather kernel started 240-390 us after it (rocprofv3 timelines of H and C3: the copy waited
+      // for the 12.6 MB g_L_u transfer of the other stream to drain) -- 5 % of a minibatch step for 10 KB of results.
+      static const bool direct = [] {   // HMOGP_GATHER_DIRECT=0: gather into HBM + hipMemcpyAsync as before (A/B runs)
+        const char* e = getenv("HMOGP_GATHER_DIRECT");
+        return !(e && e[0] == '0');
+      }();
+      double* d = direct ? hstage_dev : dstage.d();
       launch_gather_small(stats.d(), (long long)n_hg, klout.d(), (long long)n_kl, per_q, oDZ, per_q - oDZ, Q, rowout.d(),
                           (long long)n_row, d, st);
-      HIP_TRY(hipMemcpyAsync(hstage, d, sizeof(double) * n_stage, hipMemcpyDeviceToHost, st));
+      if (!direct) HIP_TRY(hipMemcpyAsync(hstage, d, sizeof(double) * n_stage, hipMemcpyDeviceToHost, st));
     }
     if (out->dL_dS) HIP_TRY(hipMemcpyAsync(out->dL_dS, dLdS.p, sizeof(double) * MM * Q, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(ev_fin1, st));
@@ -2116,12 +2123,27 @@ int hmogp_step_finish(hmogp_handle h, hmogp_outputs* out) {
 int hmogp_elbo_grad(hmogp_handle h, const hmogp_params* p, hmogp_outputs* out) {
   if (!h) return HMOGP_E_INVALID;
   return guarded(h, [&] {       // single device, NEVER a collective -- also with a communicator attached (debug / parity calls)
+    static const bool stamps = getenv("HMOGP_HOST_STAMPS") != nullptr;   // host-side timeline of the call (stderr; debugging)
+    static std::chrono::steady_clock::time_point last_ret;
+    const auto t_in = std::chrono::steady_clock::now();
     try {
       h->pending_warm.clear();
       if (h->graphs_broken || !h->graph_step(p, out)) {
         h->begin(p, false);
-        h->finish(out);
+        const auto t_b = std::chrono::steady_clock::now();
+        h->finish_enqueue(out);
+        const auto t_e = std::chrono::steady_clock::now();
+        if (stamps) HIP_TRY(hipStreamSynchronize(h->st));
+        const auto t_s = std::chrono::steady_clock::now();
+        h->finish_tail(out);
         h->mark_warm();
+        if (stamps) {
+          const auto t_r = std::chrono::steady_clock::now();
+          auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+          std::fprintf(stderr, "[hmogp host] outside %.0f us | begin (enqueue) %.0f | finish enqueue %.0f | wait %.0f | tail %.0f\n",
+                       us(last_ret, t_in), us(t_in, t_b), us(t_b, t_e), us(t_e, t_s), us(t_s, t_r));
+          last_ret = t_r;
+        }
       }
     } catch (const hmogp_engine::RetryRegular&) {   // small-model path: a latent needs the jitter ladder
       h->small_veto = true;
