@@ -1,0 +1,131 @@
+"""GPU: the strict q(f) mode (HMOGP_CFG_STRICT_QF) beyond the three jitter-ladder fixtures of tests/test_gpu_ladder.py --
+every dispatch branch the mode adds, against the reference-run fixtures and against the oracle's strict restatement:
+
+  * every reference-run fixture of the repository (inf_* / model_* / ref_*: 1-D and 2-D inputs, all eight likelihoods, ragged M = 5 ...
+    160, minibatch E- and M-steps with batch scales, stale-W quirk) must pass in strict mode under the same criterion as in default mode;
+  * seeded random configurations (ragged / 32-multiple / 128-multiple M, P = 1, 2, several pools, minibatch row ranges, gradient gates)
+    against `so.elbo_grad_fused(strict_qf=True)`;
+  * additivity of the strict bundle over row shards (its H / r slots hold A^T diag(beta) A and A^T alpha: still sums over rows),
+    the inner-protocol debug export, hmogp_potrs_rows against LAPACK, and the flag's exclusions."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_parity
+from test_gpu_engine import KEYS, rel, run, synth
+
+pytestmark = pytest.mark.gpu
+
+FIXTURES = sorted(glob.glob(os.path.join(GOLDEN, "model_*.npz")) + glob.glob(os.path.join(GOLDEN, "ref_*.npz")))
+
+
+def _engine(prob, X, Y, **kw):
+    from hetmogp_amd.engine import Engine
+    e = Engine(prob["specs"], prob["Q"], prob["M"], prob["P"], strict_qf=True, **kw)
+    e.set_data(X, Y)
+    return e
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=os.path.basename)
+def test_strict_mode_vs_every_reference_run_fixture(path):
+    from oracle import svmogp_oracle as so
+    from hetmogp_amd import _lib
+    g = np.load(path)
+    prm, prob, X, Y, bs = so.load_case(g)
+    mask = _lib.GROUP_ALL
+    if bool(g["stochastic"]):
+        mask = _lib.GROUP_QU if bool(g["vem_step"]) else (_lib.GROUP_HYPER | _lib.GROUP_Z)
+    e = _engine(prob, X, Y)
+    out = run(e, prm, bs, group_mask=mask)
+    assert out["rungs"] == [-1] * prob["Q"]
+    for k in KEYS:
+        assert_parity(out[k], g[k], k)
+    e.close()
+
+
+LIKS = [("Gaussian", {"sigma": 0.7}), ("Bernoulli", {}), ("Poisson", {}), ("Gamma", {}), ("Exponential", {}), ("HetGaussian", {}),
+        ("Beta", {}), ("Categorical", {"K": 3})]
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_strict_random_configuration_vs_strict_oracle(seed):
+    from oracle import svmogp_oracle as so
+    from hetmogp_amd import _lib
+    rng = np.random.RandomState(5000 + seed)
+    M = [16, 33, 50, 64, 96, 100, 128, 160, 256, 272, 384, 50, 144, 256][seed]
+    P = 2 if seed >= 11 else 1
+    Q = int(rng.randint(1, 4))
+    T = int(rng.randint(1, 4))
+    specs = [LIKS[i] for i in rng.choice(len(LIKS), T, replace=False)]
+    Ns = [int(rng.choice([1, 17, 130, 257, 700])) for _ in range(T)]
+    prm, prob, X, Y = synth(6000 + seed, specs, Ns, M, Q, P, tuple(0.9 + 0.4 * rng.rand(Q)))
+    sprob = dict(prob, strict_qf=True)
+    e = _engine(prob, X, Y, chunk_rows=int(rng.choice([1 << 20, 300])))
+    want = so.elbo_grad_fused(prm, sprob, X, Y)
+    out = run(e, prm)
+    for k in KEYS:
+        assert rel(out[k], want[k]) < 1e-8, (k, M, P, Q, specs, Ns, rel(out[k], want[k]))
+    # minibatch row ranges with batch scales; E-step gate (q(u) group only: the mode then skips P~ and the gradient statistics)
+    rb = [int(rng.randint(0, n // 2 + 1)) for n in Ns]
+    re = [int(min(n, b + max(1, n // 3))) for n, b in zip(Ns, rb)]
+    bs = [float(n) / max(e_ - b, 1) for n, b, e_ in zip(Ns, rb, re)]
+    Xs, Ys = [x[b:e_] for x, b, e_ in zip(X, rb, re)], [y[b:e_] for y, b, e_ in zip(Y, rb, re)]
+    wantb = so.elbo_grad_fused(prm, sprob, Xs, Ys, batch_scale=bs, stochastic=True, vem_step=True)
+    outb = run(e, prm, bs, row_begin=rb, row_end=re, group_mask=_lib.GROUP_QU)
+    for k in ("elbo", "g_m_u", "g_L_u"):
+        assert rel(outb[k], wantb[k]) < 1e-8, ("E-step", k, rel(outb[k], wantb[k]))
+    assert not np.any(outb["g_Z"]) and not np.any(outb["g_W"])
+    e.close()
+
+
+def test_strict_bundle_is_additive_over_row_shards_and_debug_export_matches():
+    from oracle import svmogp_oracle as so
+    g = np.load(os.path.join(GOLDEN, "ref_h_mix_M128.npz"))
+    prm, prob, X, Y, bs = so.load_case(g)
+    prm.pop("W0", None)
+    e = _engine(prob, X, Y)
+    full = e.elbo_grad(batch_scale=bs, **prm)
+    T = prob["T"]
+    cut = [x.shape[0] // 3 + 7 * t for t, x in enumerate(X)]
+    e.step_begin(row_begin=[0] * T, row_end=cut, batch_scale=bs, **prm)
+    s1 = e.stats_read()
+    e.step_begin(row_begin=cut, row_end=[x.shape[0] for x in X], batch_scale=bs, **prm)
+    s2 = e.stats_read()
+    e.stats_write(s1 + s2)
+    both = e.step_finish()
+    for k in KEYS:
+        assert rel(both[k], full[k]) < 1e-10, ("shards", k, rel(both[k], full[k]))
+    # inner protocol (svmogp_inf.py:107) in strict mode against the reference's own dict
+    e.elbo_grad(batch_scale=bs, **prm)
+    raw = e.debug_raw_grads([x.shape[0] for x in X])
+    for q in range(prob["Q"]):
+        assert_parity(raw["dL_dKmm"][q], g["dL_dKmm_%d" % q], ("dL_dKmm", q))
+        for d in range(prob["Df"]):
+            assert_parity(np.sum(raw["dL_dKmn"][q][d], axis=1), g["dL_dKmn_rowsum_%d_%d" % (q, d)], ("dL_dKmn", q, d))
+    e.close()
+
+
+@pytest.mark.parametrize("M", [8, 31, 32, 33, 64, 100, 128, 257])
+def test_potrs_rows_vs_lapack(M):
+    """hmogp_potrs_rows == dpotrs(L, B^T)^T (svmogp_inf.py:214): blocked substitution, ragged last block, well- and ill-conditioned."""
+    import scipy.linalg as sl
+    from hetmogp_amd.engine import potrs_rows
+    rng = np.random.RandomState(M)
+    A = rng.randn(M, M)
+    for jitter in (float(M), 1e-6):
+        K = A @ A.T / M + jitter * np.eye(M)
+        L = np.linalg.cholesky(K)
+        B = rng.randn(333, M)
+        ref = sl.cho_solve((L, True), B.T).T
+        out = potrs_rows(L, B)
+        bound = 50.0 * np.linalg.cond(K) * 2.2e-16
+        assert np.max(np.abs(out - ref)) <= max(1e-13, bound) * np.max(np.abs(ref)), (M, jitter)
+
+
+def test_strict_flag_exclusions():
+    from hetmogp_amd.engine import Engine
+    from hetmogp_amd._lib import InvalidArgument
+    with pytest.raises(InvalidArgument):
+        Engine([("Gaussian", {"sigma": 0.5})], 1, 128, 1, strict_qf=True, exact_zero_windows=True)
