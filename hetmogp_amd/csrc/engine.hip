@@ -238,15 +238,27 @@ void potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL
     g.nbatch = Q;
     launch_gemm_f64(g, st);
   };
-  for (int j0 = 0; j0 < M; j0 += 32) {                        // X Luu^T = V
-    const int nb = std::min(32, M - j0);
-    if (j0 > 0) update(j0, nb, 0, j0, Luu + (long long)j0 * M, 0);
-    launch_trsm_diag(0, V, sV, Luu, sL, M, j0, nb, n, Q, st);
+  // Two-level blocking: the bulk of the flops sits in updates of 128 columns at a time (full MFMA tiles: an update of a 32-column
+  // block alone uses a quarter of a 128 x 128 tile), the 32-column substitution steps and their short updates stay inside a
+  // 128-column block (strict forward at the headline size: 568 ms one-level, 337 ms two-level).
+  constexpr int NB = 128;
+  for (int J0 = 0; J0 < M; J0 += NB) {                        // X Luu^T = V   (forward over the columns)
+    const int J1 = std::min(M, J0 + NB);
+    if (J0 > 0) update(J0, J1 - J0, 0, J0, Luu + (long long)J0 * M, 0);
+    for (int j0 = J0; j0 < J1; j0 += 32) {
+      const int nb = std::min(32, J1 - j0);
+      if (j0 > J0) update(j0, nb, J0, j0 - J0, Luu + (long long)j0 * M + J0, 0);
+      launch_trsm_diag(0, V, sV, Luu, sL, M, j0, nb, n, Q, st);
+    }
   }
-  for (int j0 = ((M - 1) / 32) * 32; j0 >= 0; j0 -= 32) {     // A Luu = X
-    const int nb = std::min(32, M - j0), j1 = j0 + nb;
-    if (j1 < M) update(j0, nb, j1, M - j1, Luu + (long long)j1 * M + j0, 1);
-    launch_trsm_diag(1, V, sV, Luu, sL, M, j0, nb, n, Q, st);
+  for (int J0 = ((M - 1) / NB) * NB; J0 >= 0; J0 -= NB) {     // A Luu = X     (backward over the columns)
+    const int J1 = std::min(M, J0 + NB);
+    if (J1 < M) update(J0, J1 - J0, J1, M - J1, Luu + (long long)J1 * M + J0, 1);
+    for (int j0 = J0 + ((J1 - J0 - 1) / 32) * 32; j0 >= J0; j0 -= 32) {
+      const int nb = std::min(32, J1 - j0), j1 = j0 + nb;
+      if (j1 < J1) update(j0, nb, j1, J1 - j1, Luu + (long long)j1 * M + j0, 1);
+      launch_trsm_diag(1, V, sV, Luu, sL, M, j0, nb, n, Q, st);
+    }
   }
 }
 
@@ -310,7 +322,7 @@ struct hmogp_engine {
   // reference forms them -- A = K^ Kuu^-1 through two triangular factors of Luu (its dpotrs, svmogp_inf.py:214), v = ||L_q^T A^T||^2 -
   // A . K^ (:217-218), dVE_dmu = A^T alpha (:144), dVE_dS = A^T diag(beta) A (:145-148), dL_dKmn through A (S Kuu^-1 - I) (:157-161)
   // -- instead of through the explicit C_q = Kuu^-1 S Kuu^-1 - Kuu^-1, which differs from them by ~cond(Kuu) eps (1e-4 relative in
-  // g_W / g_kappa / g_Z once GPy's jitter ladder is taken, cond ~ 1e7).  ~3.5x the forward work; for parity in that regime.
+  // g_W / g_kappa / g_Z once GPy's jitter ladder is taken, cond ~ 1e7).  ~3.3x the step time at the headline size; for parity in that regime.
   bool strict = false;
   DevBuf Dm, Ah, vpg, vcg;
   unsigned quirks = HMOGP_QUIRKS_REFERENCE;
@@ -1160,7 +1172,8 @@ struct hmogp_engine {
       g.C = C_, g.ldc = M, g.sC = sK;
       g.M = (int)n, g.N = M, g.K = M;
       g.nbatch = Q;
-      launch_gemm_f64(g, st);
+      g.role = 1;                       // (no fused statistics: fs_part stays null) the specialised 8-wave forward kernel where the
+      launch_gemm_rowpass_or_general(g, st);   // shape allows it -- incl. its triangular-fold pairing for T = A L_q -- else the general one
     };
     for (int q = 0; q < Q; ++q)
       HIP_TRY(hipMemcpyAsync(Ah.d() + q * sK, Kh.d() + q * sK, sizeof(double) * n * M, hipMemcpyDeviceToDevice, st));

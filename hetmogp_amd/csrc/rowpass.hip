@@ -1045,19 +1045,51 @@ __global__ __launch_bounds__(256) void trsm_diag_kernel(double* __restrict__ V, 
   const long long row = (long long)blockIdx.x * 256 + t;
   const bool valid = row < n;
   double* v = V + (valid ? row : 0) * M + j0;
-  for (int c = 0; c < nb; ++c) xs[c][t] = valid ? v[c] : 0.0;
+  for (int c = 0; c < 32; ++c) xs[c][t] = (valid && c < nb) ? v[c] : 0.0;
   __syncthreads();
+  // Chunks of 8 unknowns: their right-hand sides sit in 8 registers while the contributions of the unknowns solved before are
+  // subtracted (one LDS read of the unknown + 8 broadcast reads of L feed 8 INDEPENDENT fused multiply-adds: the first version
+  // ran one dependent chain per unknown, 25 ms per step at 200 000 rows), then the 8 x 8 triangle is solved in registers.
+  // Padded rows / columns of the last block are identity: harmless.
   if (DIR == 0) {
-    for (int j = 0; j < nb; ++j) {
-      double acc = xs[j][t];
-      for (int i = 0; i < j; ++i) acc -= xs[i][t] * Ls[j][i];
-      xs[j][t] = acc / Ls[j][j];
+    for (int c0 = 0; c0 < 32; c0 += 8) {
+      if (c0 >= nb) break;
+      double acc[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] = xs[c0 + r][t];
+      for (int i = 0; i < c0; ++i) {
+        const double xi = xs[i][t];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] -= xi * Ls[c0 + r][i];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+#pragma unroll
+        for (int q = 0; q < r; ++q) acc[r] -= acc[q] * Ls[c0 + r][c0 + q];
+        acc[r] = acc[r] / Ls[c0 + r][c0 + r];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) xs[c0 + r][t] = acc[r];
     }
   } else {
-    for (int j = nb - 1; j >= 0; --j) {
-      double acc = xs[j][t];
-      for (int i = nb - 1; i > j; --i) acc -= xs[i][t] * Ls[i][j];
-      xs[j][t] = acc / Ls[j][j];
+    for (int c0 = 24; c0 >= 0; c0 -= 8) {
+      if (c0 >= nb) continue;
+      double acc[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc[r] = xs[c0 + r][t];
+      for (int i = 31; i >= c0 + 8; --i) {
+        const double xi = xs[i][t];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] -= xi * Ls[i][c0 + r];
+      }
+#pragma unroll
+      for (int r = 7; r >= 0; --r) {
+#pragma unroll
+        for (int q = 7; q > r; --q) acc[r] -= acc[q] * Ls[c0 + q][c0 + r];
+        acc[r] = acc[r] / Ls[c0 + r][c0 + r];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) xs[c0 + r][t] = acc[r];
     }
   }
   if (valid)

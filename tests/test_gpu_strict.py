@@ -80,6 +80,25 @@ def test_strict_random_configuration_vs_strict_oracle(seed):
     e.close()
 
 
+@pytest.mark.timeout(600)
+def test_strict_mode_at_the_headline_M_in_several_pools():
+    """M = 1024 (32 diagonal blocks per triangular solve, 128-column MFMA tiles for the Gram of A), Q = 3, the headline mix, rows
+    streamed in three pools that cross task boundaries: against the oracle's strict restatement, and equal to the single-pool run."""
+    from oracle import svmogp_oracle as so
+    from hetmogp_amd.synthetic import make_case
+    specs = [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {}), ("Poisson", {}), ("Gamma", {})]
+    M, Q = 1024, 3
+    prm, X, Y = make_case(specs, [2500, 2300, 2700, 2100], M=M, Q=Q, P=1, seed=20260936)
+    prob = so.make_problem(specs, Q, M, 1)
+    want = so.elbo_grad_fused(prm, dict(prob, strict_qf=True), X, Y)
+    e1, e3 = _engine(prob, X, Y), _engine(prob, X, Y, chunk_rows=3500)
+    a, b = e1.elbo_grad(**prm), e3.elbo_grad(**prm)
+    for k in KEYS:
+        assert rel(a[k], want[k]) < 1e-8, (k, rel(a[k], want[k]))
+        assert rel(b[k], a[k]) < 1e-10, ("pools", k, rel(b[k], a[k]))
+    e1.close(), e3.close()
+
+
 def test_strict_bundle_is_additive_over_row_shards_and_debug_export_matches():
     from oracle import svmogp_oracle as so
     g = np.load(os.path.join(GOLDEN, "ref_h_mix_M128.npz"))
