@@ -1447,10 +1447,11 @@ struct hmogp_engine {
         const char* e = getenv("HMOGP_SMALL_PATH");
         return e ? atoi(e) : 1;
       }();
-      // (a SHARDED step -- hmogp_elbo_grad_sharded, or hmogp_step_begin with a communicator attached -- must not choose its path
-      //  from this rank's row count: every rank takes the regular kernels, so that the replicated M x M algebra, and with it the
-      //  never re-synchronised resident q(u) replicas, round alike on all ranks.  ADVICE r4.  Plain hmogp_elbo_grad is unaffected.)
-      small_path = small_mode && M <= HMOGP_SMALL_M && path_env != 0 && !small_veto && !(comm && sharded_call);
+      // (a SHARDED step -- hmogp_elbo_grad_sharded, or the split form hmogp_step_begin ... hmogp_step_finish whose bundle the caller
+      //  exchanges with whatever it has: the library's communicator, torch.distributed, MPI -- must not choose its path from this
+      //  rank's row count: every rank takes the regular kernels, so that the replicated M x M algebra, and with it the never
+      //  re-synchronised resident q(u) replicas, round alike on all ranks.  ADVICE r4.  Plain hmogp_elbo_grad is unaffected.)
+      small_path = small_mode && M <= HMOGP_SMALL_M && path_env != 0 && !small_veto && !sharded_call;
       small_info_pending = false;
       static const int rows_env = [] {   // HMOGP_SMALL_ROWS=0: the regular row-pass kernels behind the fused M x M kernels (A/B runs)
         const char* e = getenv("HMOGP_SMALL_ROWS");
