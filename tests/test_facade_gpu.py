@@ -17,7 +17,7 @@ def rel(a, b):
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300))
 
 
-def build_model(g, batch_size=None):
+def build_model(g, batch_size=None, **model_kw):
     import hetmogp_amd as H
     specs = json.loads(str(g["spec"]))
     T, Q, P = int(g["T"]), int(g["Q"]), int(g["P"])
@@ -29,7 +29,7 @@ def build_model(g, batch_size=None):
     Y = [g["Yall_%d" % t] for t in range(T)]
     W_list = [g["W0"][q][:, None].copy() for q in range(Q)]
     model = H.SVMOGP(X=X, Y=Y, Z=g["Z"][:, :P].copy(), kern_list=kern_list, likelihood=likelihood, Y_metadata=md,
-                     batch_size=batch_size, W_list=W_list)
+                     batch_size=batch_size, W_list=W_list, **model_kw)
     model.q_u_means[...] = g["m_u"]
     model.q_u_chols[...] = g["L_flat"]
     model.Z[...] = g["Z"]

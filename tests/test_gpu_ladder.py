@@ -105,6 +105,25 @@ def test_strict_mode_vs_reference_run_in_the_ladder_regime(path, capsys):
             assert np.all(np.abs(a - b) <= bound), (k, "beyond 50 x the reference's own one-ulp sensitivity", rn, sr)
 
 
+@pytest.mark.parametrize("name", ["lad_h_mix_M128_ladder.npz", "lad_c1_offset_rung1.npz"])
+def test_facade_strict_qf_vs_reference_run_in_the_ladder_regime(name):
+    """The drop-in surface -- SVMOGP(X, Y, Z, kern_list, likelihood, Y_metadata, W_list, strict_qf=True) / parameters_changed() /
+    log_likelihood() -- where the reference's own jitchol took rung 0 / rung 1: the numbers its model object held afterwards."""
+    from test_facade_gpu import build_model
+    g = np.load(os.path.join(GOLDEN, name))
+    model = build_model(g, None, strict_qf=True)
+    model.parameters_changed()
+    got = dict(elbo=model.log_likelihood(), g_m_u=model.q_u_means.gradient, g_L_u=model.q_u_chols.gradient, g_Z=model.Z.gradient,
+               g_variance=[k.variance.gradient[0] for k in model.kern_list],
+               g_lengthscale=[k.lengthscale.gradient[0] for k in model.kern_list],
+               g_W=np.stack([B.W.gradient.ravel() for B in model.B_list]),
+               g_kappa=np.stack([B.kappa.gradient.ravel() for B in model.B_list]))
+    assert np.shape(got["elbo"]) == (1, 1)
+    for k, v in got.items():
+        assert rel_norm(v, g[k]) < 1e-7, (k, rel_norm(v, g[k]))
+        assert elementwise_excess(v, g[k]) <= 1.0, (k, elementwise_excess(v, g[k]))
+
+
 def test_default_mode_is_off_by_more_than_1e5_where_the_ladder_is_taken():
     """Documents WHY the strict mode exists: at rung 0 (cond 1e7) the explicit-inverse path is inside 1e-5 for the ELBO and the q(u)
     gradients and outside it for g_W / g_kappa / g_Z; if this ever stops failing the strict mode is no longer needed there."""
