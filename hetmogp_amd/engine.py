@@ -378,12 +378,20 @@ class Engine(object):
 _DEFAULT_DEVICE = 0
 
 
-def set_default_device(device):
+_DEFAULT_DEVICE_PINNED = False
+
+
+def set_default_device(device, from_model=False):
     """HIP device of the stand-alone building blocks below (var_exp, predictive, sample, gemm ...) when they are called
     without `device=`: a rank of a multi-GPU run sets it to its LOCAL_RANK once (SVMOGP(distributed=True) does), so that
-    likelihood-level helpers never land on GPU 0 from every rank."""
-    global _DEFAULT_DEVICE
+    likelihood-level helpers never land on GPU 0 from every rank.  A model constructor (`from_model=True`) only sets
+    it while nobody has chosen one explicitly and no earlier model has: with two models on two devices in one process the
+    stand-alone helpers of the first no longer move to the GPU of the last; a model's OWN calls always pass its device."""
+    global _DEFAULT_DEVICE, _DEFAULT_DEVICE_PINNED
+    if from_model and _DEFAULT_DEVICE_PINNED:
+        return
     _DEFAULT_DEVICE = int(device)
+    _DEFAULT_DEVICE_PINNED = True
 
 
 def _resolve_device(device):

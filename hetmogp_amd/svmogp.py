@@ -239,7 +239,7 @@ class SVMOGP(object):
             device = int(os.environ.get("LOCAL_RANK", "0")) if distributed else 0
         self._device = int(device)
         from .engine import set_default_device
-        set_default_device(self._device)           # stand-alone likelihood helpers (predictive, samples ...) follow the model
+        set_default_device(self._device, from_model=True)   # stand-alone likelihood helpers follow the FIRST model / an explicit choice
         self.name = name
         self.gradients_of_fixed = bool(gradients_of_fixed)
         self.batch_size = batch_size
