@@ -18,6 +18,7 @@ E_INVALID, E_NO_DEVICE, E_NOT_PD, E_SQI_UNSTABLE, E_STATE, E_COMM = -1, -2, -3, 
 NTIMINGS = 9
 COMM_ID_BYTES = 128
 FLAG_V_NEGATIVE = 1
+FLAG_ILL_CONDITIONED = 2
 GROUP_QU, GROUP_HYPER, GROUP_Z, GROUP_ALL = 1, 2, 4, 7
 CFG_EXACT_ZERO_WINDOWS = 1
 CFG_CACHE_KUU = 2
@@ -60,7 +61,7 @@ class Params(C.Structure):
 
 class Outputs(C.Structure):
     _fields_ = [("elbo", _vp), ("g_m_u", _vp), ("g_L_u", _vp), ("g_variance", _vp), ("g_lengthscale", _vp), ("g_W", _vp),
-                ("g_kappa", _vp), ("g_Z", _vp), ("dL_dS", _vp), ("rung", _vp), ("flags", _vp), ("kl", _vp)]
+                ("g_kappa", _vp), ("g_Z", _vp), ("dL_dS", _vp), ("rung", _vp), ("flags", _vp), ("kl", _vp), ("cond_est", _vp)]
 
 
 EXPORTS = {

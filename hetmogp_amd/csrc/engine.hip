@@ -786,7 +786,7 @@ struct hmogp_engine {
     dW.view(dsmall.d() + 2 * Q, sizeof(double) * Q * Df), dkap.view(dsmall.d() + 2 * Q + Q * Df, sizeof(double) * Q * Df);
     a.ensure(sizeof(double) * Q * M), Kr.ensure(sizeof(double) * Q * M), gmu.ensure(sizeof(double) * Q * M);
     gL.ensure(sizeof(double) * ((long long)M * (M + 1) / 2) * Q);
-    klout.ensure(sizeof(double) * Q * KL_BLOCKS * 5);
+    klout.ensure(sizeof(double) * Q * KL_BLOCKS * 6, true);   // KL partials [Q][KL_BLOCKS][5] | diag(K_uu^-1) block maxima [Q][KL_BLOCKS]
     rowout.ensure(sizeof(double) * Q * M * (2 + P));
     dinfo.ensure(sizeof(int) * (2 * HMOGP_MAXQ + 2), true), djit.ensure(sizeof(double) * Q), dscr.ensure(sizeof(double) * Q * M * M);
     rung.assign(Q, -1);
@@ -1519,7 +1519,7 @@ struct hmogp_engine {
     const long long Mtri = (long long)M * (M + 1) / 2;
     fl.want_qu = (group_mask & HMOGP_GROUP_QU) != 0 || out->dL_dS != nullptr;
     fl.want_hz = (group_mask & (HMOGP_GROUP_HYPER | HMOGP_GROUP_Z)) != 0;
-    fl.n_hg = NG, fl.n_kl = (size_t)Q * KL_BLOCKS * 5, fl.n_tail = (size_t)Q * (per_q - oDZ);
+    fl.n_hg = NG, fl.n_kl = (size_t)Q * KL_BLOCKS * 6, fl.n_tail = (size_t)Q * (per_q - oDZ);
     fl.n_row = fl.want_hz ? (size_t)Q * M * (2 + P) : 0, fl.n_all = fl.n_hg + fl.n_kl + fl.n_tail + fl.n_row;
     fl.qu_out = small_path && fl.want_qu && (group_mask & HMOGP_GROUP_QU) != 0;
     fl.n_gmu = fl.qu_out ? (size_t)M * Q : 0, fl.n_gl = fl.qu_out ? (size_t)Mtri * Q : 0;
@@ -1672,7 +1672,18 @@ struct hmogp_engine {
       ninf += k[4];
     }
     if (out->elbo) out->elbo[0] = hg[0] - KL;
-    if (out->flags) out->flags[0] = (hg[1] > 0.0) ? HMOGP_FLAG_V_NEGATIVE : 0u;
+    // [r5] condition estimate variance * max_i (K_uu^-1)_ii (a lower bound of cond(K_uu + jitter), 30-150x below it on RBF matrices)
+    // and the flag that says which mode can still be trusted with it: the explicit-C_q path keeps element-wise 1e-5 to cond ~ 1e4
+    // (estimate ~ 5e2), the strict path to ~ 1e7 (estimate ~ 5e5) -- tools/ladder_sweep.py, DESIGN 6a
+    bool ill = false;
+    for (int q = 0; q < Q; ++q) {
+      double kmax = 0.0;
+      for (int b = 0; b < KL_BLOCKS; ++b) kmax = std::max(kmax, hkl[(size_t)Q * KL_BLOCKS * 5 + (size_t)q * KL_BLOCKS + b]);
+      const double est = kmax * h_var[q];
+      if (out->cond_est) out->cond_est[q] = est;
+      ill = ill || est > (strict ? 5e5 : 5e2);
+    }
+    if (out->flags) out->flags[0] = ((hg[1] > 0.0) ? HMOGP_FLAG_V_NEGATIVE : 0u) | (ill ? HMOGP_FLAG_ILL_CONDITIONED : 0u);
     if (out->rung) std::copy(rung.begin(), rung.end(), out->rung);
     const bool hy = (group_mask & HMOGP_GROUP_HYPER) != 0, zz = (group_mask & HMOGP_GROUP_Z) != 0;
     const double* sgv = &hg[2];

@@ -488,6 +488,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   if (t == 0) s_info = 0, s_progress = 0;
   for (int e = t; e < KL_BLOCKS * 5; e += NT)          // KL partials: blocks 0 and 1 are written below / by block (q, 1)
     if (e >= 10) o[e] = 0.0;
+  for (int e = t; e < KL_BLOCKS; e += NT)              // ... and the block maxima of diag(K_uu^-1) behind them: slot 0 below
+    if (e >= 1) u.klout[(long long)Q * KL_BLOCKS * 5 + (long long)q * KL_BLOCKS + e] = 0.0;
   __syncthreads();
   SM_STAMP(1);
   if (u.stop_after == 1) return;
@@ -557,8 +559,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     u.Ctri[off + (long long)i * M + j] = tv;
   });
   // KL partials (svmogp_inf.py:245-249), kl_terms_kernel's layout: "block 0" of the latent
+  double kmax = (t < M) ? X0[t * SLD + t] : 0.0;       // max_i (K_uu^-1)_ii (kl_terms_kernel's condition estimate; M <= 64: wave 0)
+  for (int o2 = 32; o2; o2 >>= 1) kmax = fmax(kmax, __shfl_xor(kmax, o2, 64));
   sm_block_sum3(tr, ma, l1, red);
   if (t == 0) o[0] = tr, o[1] = ma, o[2] = l1, o[3] = 0.0, o[4] = 0.0;
+  if (t == 0) u.klout[(long long)Q * KL_BLOCKS * 5 + (long long)q * KL_BLOCKS] = kmax;
   SM_STAMP(8);
 }
 

@@ -182,7 +182,8 @@ class Engine(object):
         else:
             big = dict(g_m_u=np.zeros((M, Q)), g_L_u=np.zeros((self.Mtri, Q)), g_Z=np.zeros((M, Q * P)))
         o = dict(elbo=np.zeros(1), g_m_u=big["g_m_u"], g_L_u=big["g_L_u"], g_variance=np.zeros(Q),
-                 g_lengthscale=np.zeros(Q), g_W=np.zeros((Q, Df)), g_kappa=np.zeros((Q, Df)), g_Z=big["g_Z"], kl=np.zeros(Q))
+                 g_lengthscale=np.zeros(Q), g_W=np.zeros((Q, Df)), g_kappa=np.zeros((Q, Df)), g_Z=big["g_Z"], kl=np.zeros(Q),
+                 cond_est=np.zeros(Q))
         if want_dL_dS:
             o["dL_dS"] = np.zeros((Q, M, M))
         rung = np.zeros(Q, dtype=np.int32)
@@ -209,6 +210,9 @@ class Engine(object):
         res["KL"] = float(np.sum(o["kl"]))          # calculate_KL (svmogp_inf.py:227-250), summed over the latents
         res["rungs"] = [int(r) for r in o["rung"]]
         res["v_negative"] = bool(int(o["flags"][0]) & _lib.FLAG_V_NEGATIVE)
+        # cond_est[q] = variance_q max_i (K_uu^-1)_ii (lower bound of cond(K_uu), 30-150x below it); ill_conditioned: beyond what this
+        # engine's mode keeps within element-wise 1e-5 of the reference (default mode: take strict_qf=True)
+        res["ill_conditioned"] = bool(int(o["flags"][0]) & _lib.FLAG_ILL_CONDITIONED)
         self.last = res
         return res
 

@@ -409,6 +409,14 @@ class SVMOGP(object):
             batch_scale=self.batch_scale, row_begin=[r[0] for r in self._rows], row_end=[r[1] for r in self._rows],
             forced_rung=self.forced_rung, group_mask=mask)
         self.last = out
+        if out.get("ill_conditioned") and not getattr(self, "_warned_ill", False):
+            self._warned_ill = True      # (once per model; model.last["cond_est"] / ["ill_conditioned"] are there on every evaluation)
+            import warnings
+            warnings.warn("K_uu is ill-conditioned for the %s path (condition estimates %s, jitter rungs %s): its ELBO / gradients may "
+                          "differ from the reference's by more than 1e-5 element-wise%s (DESIGN.md 6a)" % (
+                              "strict q(f)" if self.strict_qf else "default (explicit-inverse)",
+                              ["%.1e" % c for c in out["cond_est"]], out["rungs"],
+                              "" if self.strict_qf else "; construct the model with strict_qf=True"), RuntimeWarning)
         self._log_marginal_likelihood = np.array([[out["elbo"]]])
         if not on_dev:                            # (device-resident q(u): its gradient stays in HBM for the optimiser)
             self.q_u_means.gradient = out["g_m_u"]

@@ -59,6 +59,10 @@ enum {
 
 /* output flags (hmogp_outputs.flags) */
 #define HMOGP_FLAG_V_NEGATIVE 1u /* some v_fd < 0: the reference prints 'v negative!' (svmogp_inf.py:221) */
+#define HMOGP_FLAG_ILL_CONDITIONED 2u /* ABI v6: hmogp_outputs.cond_est of some latent is beyond what this engine's mode keeps within
+   the north-star's element-wise 1e-5 of the reference: > 5e2 without HMOGP_CFG_STRICT_QF (cond(K_uu) ~ 1e4 and more: take the
+   strict mode), > 5e5 with it (cond ~ 1e7 and more: the reference's own numbers move by more than 1e-5 with the last bit of its
+   covariance there).  The reference has no such diagnostic (GPy's jitchol only reports a failed factorisation).              */
 
 /* Reference quirks (hmogp_config.quirks).  A set bit reproduces the reference's behaviour, a cleared
  * bit gives the mathematically exact quantity.  HMOGP_QUIRKS_REFERENCE (all set) is what parity is measured against;
@@ -163,6 +167,8 @@ typedef struct {
   uint32_t* flags;       /* [1] HMOGP_FLAG_*                                                          */
   double* kl;            /* [Q] or NULL: KL(q(u_q) || p(u_q)) per latent (calculate_KL, svmogp_inf.py:227-250);
                             elbo = (scaled data term) - sum_q kl[q]                      (ABI version 3) */
+  double* cond_est;      /* [Q] or NULL: variance_q * max_i (K_uu^-1)_ii of the (jittered) prior covariance of latent q: a lower
+                            bound of its condition number, 30-150x below it for RBF kernels          (ABI version 6) */
 } hmogp_outputs;
 
 /* ---- life cycle ------------------------------------------------------------------------------------ */

@@ -124,6 +124,39 @@ def test_facade_strict_qf_vs_reference_run_in_the_ladder_regime(name):
         assert elementwise_excess(v, g[k]) <= 1.0, (k, elementwise_excess(v, g[k]))
 
 
+def test_condition_estimate_and_flag_say_when_to_switch_modes():
+    """hmogp_outputs.cond_est = variance max_i (K_uu^-1)_ii (a lower bound of cond(K_uu), 30-150x below it) and HMOGP_FLAG_ILL_CONDITIONED:
+    raised by the default mode where it leaves element-wise 1e-5 (cond >= ~1e4), by the strict mode only beyond cond ~1e7."""
+    import warnings
+    from test_facade_gpu import build_model
+    seen = {}
+    for name in ("ref_c1_exact.npz", "lad_h_mix_M128_ladder.npz", "lad_c1_notebook_ell.npz"):
+        g = np.load(os.path.join(GOLDEN, name))
+        for strict in (False, True):
+            out, _, _ = _run(g, strict, forced=[int(r) for r in g["rungs"]] if "rungs" in g.files else None)
+            seen[(name, strict)] = (out["ill_conditioned"], [float(c) for c in out["cond_est"]])
+    assert seen[("ref_c1_exact.npz", False)][0] is False and seen[("ref_c1_exact.npz", True)][0] is False
+    assert max(seen[("ref_c1_exact.npz", False)][1]) < 5e2
+    assert seen[("lad_h_mix_M128_ladder.npz", False)][0] is True           # cond 1e7: the default path is 1e-4 off there ...
+    assert seen[("lad_h_mix_M128_ladder.npz", True)][0] in (False, True)    # (strict: at its own limit, either verdict is fair)
+    assert 1e4 < max(seen[("lad_h_mix_M128_ladder.npz", True)][1]) < 1e7    # the estimate itself: cond 1e7 / (30 ... 150)
+    assert seen[("lad_c1_notebook_ell.npz", True)][0] is True               # cond 1e12: flagged in either mode
+    # both modes compute the estimate from their own K_uu^-1: same number to rounding
+    a, b = seen[("lad_h_mix_M128_ladder.npz", False)][1], seen[("lad_h_mix_M128_ladder.npz", True)][1]
+    assert np.allclose(a, b, rtol=1e-6)
+    # the facade warns once, and says what to do
+    g = np.load(os.path.join(GOLDEN, "lad_h_mix_M128_ladder.npz"))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        model = build_model(g, None)             # (the constructor and every write to a parameter evaluate)
+        model.parameters_changed()
+        model._dirty = True
+        model.parameters_changed()
+    assert model.last["ill_conditioned"] and max(model.last["cond_est"]) > 1e5
+    msgs = [str(x.message) for x in w if "ill-conditioned" in str(x.message)]
+    assert len(msgs) == 1 and "strict_qf=True" in msgs[0]
+
+
 def test_default_mode_is_off_by_more_than_1e5_where_the_ladder_is_taken():
     """Documents WHY the strict mode exists: at rung 0 (cond 1e7) the explicit-inverse path is inside 1e-5 for the ELBO and the q(u)
     gradients and outside it for g_W / g_kappa / g_Z; if this ever stops failing the strict mode is no longer needed there."""
