@@ -1594,7 +1594,9 @@ struct hmogp_engine {
         // not finish before the copy does (363-438 us instead of 121 measured, whichever stream or priority it is on);
         // the small kernels behind it run beside the copy.
         if (want_qu) HIP_TRY(hipStreamWaitEvent(st, ev_S, 0));
-        mm(G.d(), false, KiS.d(), false, GSK.d());
+        // [r5] formed TRANSPOSED, K^-1 S G = (G S K^-1)^T (G is exactly symmetric; dL_dKmm only ever uses GSK + GSK^T): the
+        // operand layouts of this form take the k-major-B kernel variant, 120 instead of 212 us at M = 1024, Q = 3
+        mm(KiS.d(), false, G.d(), true, GSK.d());
         HIP_TRY(hipEventRecord(ev_gsk, st));
         if (want_qu) HIP_TRY(hipStreamWaitEvent(st3, ev_gsk, 0));
       }
