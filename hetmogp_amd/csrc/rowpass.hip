@@ -465,10 +465,10 @@ __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restri
     for (long long n = n0; n < n1; ++n) {
       double k0, k1, q0 = 0.0, q1 = 0.0;
       if (vec) {
-        const f64x2 kv = *reinterpret_cast<const f64x2*>(Kh + n * M + c);
+        const f64x2 kv = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(Kh + n * M + c));
         k0 = kv.x, k1 = kv.y;
         if (want_e) {
-          const f64x2 qv = *reinterpret_cast<const f64x2*>(Pt + n * M + c);
+          const f64x2 qv = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(Pt + n * M + c));
           q0 = qv.x, q1 = qv.y;
         }
       } else {
