@@ -19,6 +19,7 @@ NTIMINGS = 9
 COMM_ID_BYTES = 128
 FLAG_V_NEGATIVE = 1
 FLAG_ILL_CONDITIONED = 2
+EVAL_STRICT_QF = 1
 GROUP_QU, GROUP_HYPER, GROUP_Z, GROUP_ALL = 1, 2, 4, 7
 CFG_EXACT_ZERO_WINDOWS = 1
 CFG_CACHE_KUU = 2
@@ -56,7 +57,7 @@ _vp = C.c_void_p
 class Params(C.Structure):
     _fields_ = [("Z", _vp), ("m_u", _vp), ("L_flat", _vp), ("variance", _vp), ("lengthscale", _vp), ("W", _vp), ("kappa", _vp),
                 ("W0", _vp), ("kappa0", _vp), ("batch_scale", _vp), ("row_begin", _vp), ("row_end", _vp), ("forced_rung", _vp),
-                ("group_mask", C.c_uint32)]
+                ("group_mask", C.c_uint32), ("eval_flags", C.c_uint32)]
 
 
 class Outputs(C.Structure):

@@ -323,7 +323,8 @@ struct hmogp_engine {
   // A . K^ (:217-218), dVE_dmu = A^T alpha (:144), dVE_dS = A^T diag(beta) A (:145-148), dL_dKmn through A (S Kuu^-1 - I) (:157-161)
   // -- instead of through the explicit C_q = Kuu^-1 S Kuu^-1 - Kuu^-1, which differs from them by ~cond(Kuu) eps (1e-4 relative in
   // g_W / g_kappa / g_Z once GPy's jitter ladder is taken, cond ~ 1e7).  ~3.3x the step time at the headline size; for parity in that regime.
-  bool strict = false;
+  bool strict = false;         // ... of the CURRENT / last evaluation: strict_cfg (the config flag) or hmogp_params.eval_flags
+  bool strict_cfg = false;
   DevBuf Dm, Ah, vpg, vcg;
   unsigned quirks = HMOGP_QUIRKS_REFERENCE;
   std::vector<double> h_Z, kuu_key;
@@ -669,8 +670,7 @@ struct hmogp_engine {
     use_windows = (c->flags & HMOGP_CFG_EXACT_ZERO_WINDOWS) != 0;
     cache_kuu = (c->flags & HMOGP_CFG_CACHE_KUU) != 0;
     no_small = (c->flags & HMOGP_CFG_NO_SMALL_PATH) != 0;
-    strict = (c->flags & HMOGP_CFG_STRICT_QF) != 0;
-    if (strict) no_small = true;     // (the fused small-model kernels carry the explicit-inverse algebra only)
+    strict = strict_cfg = (c->flags & HMOGP_CFG_STRICT_QF) != 0;
     if (strict && use_windows) throw EngineError{HMOGP_E_INVALID, "HMOGP_CFG_STRICT_QF and HMOGP_CFG_EXACT_ZERO_WINDOWS exclude each other"};
     if (c->flags & ~(HMOGP_CFG_EXACT_ZERO_WINDOWS | HMOGP_CFG_CACHE_KUU | HMOGP_CFG_NO_SMALL_PATH | HMOGP_CFG_STRICT_QF))
       throw EngineError{HMOGP_E_INVALID, "unknown bits in hmogp_config.flags"};
@@ -767,7 +767,6 @@ struct hmogp_engine {
     // parameter + M x M buffers
     const size_t mmq = sizeof(double) * MM * Q;
     for (DevBuf* b : {&Kuu, &Luu, &Kuui, &L, &S, &KiS, &KSK, &C, &Ctri, &Sqi, &tmpA, &tmpB, &HK, &G, &GSK, &dKmm, &dLdS}) b->ensure(mmq, true);
-    if (strict) Dm.ensure(mmq, true);
     // ALL parameters live in ONE device block [ hypers + jitter | Z | m_u | L_flat ] (segments 16-byte aligned): large models fill
     // the segments by separate copies straight from the caller's arrays, small-problem mode by ONE copy from a page-locked image
     // (a host-bound small-model step pays ~4-8 us of API time and ~4 us of device time per hipMemcpyAsync)
@@ -819,7 +818,7 @@ struct hmogp_engine {
     staged_key.clear();
     drop_graphs(true);   // (the evaluation that grows the workspaces runs normally to its end: its key stays warm)
     for (DevBuf* b : {&vp, &vc, &vpt, &vct, &valpha, &vbeta, &valpha0, &vbeta0}) b->ensure(nv, true);
-    if (strict) Ah.ensure(nm), vpg.ensure(nv, true), vcg.ensure(nv, true);
+    ws_strict_rows = 0;          // (the strict mode's extra workspaces follow lazily: ensure_strict_workspace)
     colpart.ensure(sizeof(double) * std::max((rows + 255) / 256, (std::min<long long>(rows, 16384) + 31) / 32) * M * (2 + P) * Q);
     colred.ensure(sizeof(double) * M * Q);
     quadpart.ensure(sizeof(double) * (rows * 64 / 256 + 1 + HMOGP_QUAD_MULTI) * HMOGP_MAXSCAL);
@@ -829,6 +828,17 @@ struct hmogp_engine {
       winrow.ensure(sizeof(int) * 2 * tiles * Q), wincol.ensure(sizeof(int) * 2 * ncb * Q), winhit.ensure(tiles * ncb);
     }
     ws_rows = rows;
+  }
+
+  // the strict mode's own buffers, allocated when an evaluation first runs in that mode (config flag or per-evaluation flag)
+  long long ws_strict_rows = 0;
+  void ensure_strict_workspace() {
+    if (!strict) return;
+    Dm.ensure(sizeof(double) * (long long)M * M * Q, true);
+    if (ws_strict_rows >= ws_rows) return;
+    Ah.ensure(sizeof(double) * ws_rows * M * Q);
+    vpg.ensure(sizeof(double) * ws_rows * Q, true), vcg.ensure(sizeof(double) * ws_rows * Q, true);
+    ws_strict_rows = ws_rows;
   }
 
   // ------------------------------------------------------------------------------------------ parameters
@@ -976,6 +986,7 @@ struct hmogp_engine {
       key.insert(key.end(), h_var.begin(), h_var.end());
       key.insert(key.end(), h_ell.begin(), h_ell.end());
       for (int q = 0; q < Q; ++q) key.push_back((double)rung_request[q]);
+      key.push_back(strict ? 1.0 : 0.0);     // (the strict mode forms K_uu^-1 by substitution: not interchangeable)
     }
     const bool kuu_hit = cache_kuu && kuu_key_valid && key.size() == kuu_key.size() &&
                          std::memcmp(key.data(), kuu_key.data(), sizeof(double) * key.size()) == 0;
@@ -1434,7 +1445,11 @@ struct hmogp_engine {
         const long long b = p->row_begin ? p->row_begin[t] : 0, e = p->row_end ? p->row_end[t] : tasks[t].N;
         rows_eval += std::max<long long>(0, e - b);
       }
-      const bool want_small = !no_small && (small_env >= 0 ? small_env != 0 : (M <= 128 && rows_eval <= 65536 && !use_windows && !st2_masked));
+      // (strict q(f) -- config flag or this evaluation's HMOGP_EVAL_STRICT_QF -- runs on the regular kernels: the fused small-model
+      //  kernels carry the explicit-inverse algebra only)
+      strict = strict_cfg || (p && (p->eval_flags & HMOGP_EVAL_STRICT_QF) != 0);
+      if (strict && use_windows) throw EngineError{HMOGP_E_INVALID, "strict q(f) and HMOGP_CFG_EXACT_ZERO_WINDOWS exclude each other"};
+      const bool want_small = !no_small && !strict && (small_env >= 0 ? small_env != 0 : (M <= 128 && rows_eval <= 65536 && !use_windows && !st2_masked));
       if (want_small != small_mode) {     // (rare: drain the queues the previous evaluations used before re-wiring them)
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipStreamSynchronize(st2_own));
@@ -1473,6 +1488,7 @@ struct hmogp_engine {
     upload_params(p);
     HIP_TRY(hipEventRecord(ev_begin0, st));
     plan_pools();
+    ensure_strict_workspace();
     u_algebra();
     row_pass();
     HIP_TRY(hipEventRecord(ev_begin1, st));
@@ -1676,14 +1692,15 @@ struct hmogp_engine {
     if (out->elbo) out->elbo[0] = hg[0] - KL;
     // [r5] condition estimate variance * max_i (K_uu^-1)_ii (a lower bound of cond(K_uu + jitter), 30-150x below it on RBF matrices)
     // and the flag that says which mode can still be trusted with it: the explicit-C_q path keeps element-wise 1e-5 to cond ~ 1e4
-    // (estimate ~ 5e2), the strict path to ~ 1e7 (estimate ~ 5e5) -- tools/ladder_sweep.py, DESIGN 6a
+    // (estimate ~ 5e2), the strict path through everything GPy's jitter rung 0 leaves behind (cond ~ 1e7 ... 2e7, estimate 4e5 ... 8e5:
+    // threshold 1e6) -- tools/ladder_sweep.py, DESIGN 6a
     bool ill = false;
     for (int q = 0; q < Q; ++q) {
       double kmax = 0.0;
       for (int b = 0; b < KL_BLOCKS; ++b) kmax = std::max(kmax, hkl[(size_t)Q * KL_BLOCKS * 5 + (size_t)q * KL_BLOCKS + b]);
       const double est = kmax * h_var[q];
       if (out->cond_est) out->cond_est[q] = est;
-      ill = ill || est > (strict ? 5e5 : 5e2);
+      ill = ill || est > (strict ? 1e6 : 5e2);
     }
     if (out->flags) out->flags[0] = ((hg[1] > 0.0) ? HMOGP_FLAG_V_NEGATIVE : 0u) | (ill ? HMOGP_FLAG_ILL_CONDITIONED : 0u);
     if (out->rung) std::copy(rung.begin(), rung.end(), out->rung);
@@ -1929,6 +1946,7 @@ struct hmogp_engine {
     const long long MM = (long long)M * M;
     const int ldz = Q * P;
     ensure_workspace(std::min(chunk, std::max<long long>(Nnew, 1)));
+    ensure_strict_workspace();           // (predictions follow the mode of the evaluation they are taken from)
     const long long ldn = ws_rows;
     DevBuf dX, dm, dv;
     dX.ensure(sizeof(double) * ldn * P), dm.ensure(sizeof(double) * ldn * Df), dv.ensure(sizeof(double) * ldn * Df);

@@ -137,7 +137,7 @@ class Engine(object):
 
     # ------------------------------------------------------------------------------------------ params
     def _params(self, Z, m_u, L_flat, variance, lengthscale, W, kappa, W0=None, kappa0=None, batch_scale=None,
-                row_begin=None, row_end=None, forced_rung=None, group_mask=_lib.GROUP_ALL):
+                row_begin=None, row_end=None, forced_rung=None, group_mask=_lib.GROUP_ALL, strict_qf=None):
         """hmogp_params for one call.  The struct and the addresses of the arrays it points to are kept between calls: an
         argument that is THE SAME C-contiguous array object as last time (an optimiser updating its parameters in place) costs
         one identity check; anything else is converted (copied if it has to be) and its address taken again."""
@@ -166,6 +166,7 @@ class Engine(object):
             keep[k] = b
             last[k] = a if b is a else None      # (a converted copy does not follow later in-place changes of `a`: convert again)
         p.group_mask = int(group_mask)
+        p.eval_flags = _lib.EVAL_STRICT_QF if strict_qf else 0      # (per evaluation; Engine(strict_qf=True) has it always on)
         return p, keep
 
     def _outputs(self, want_dL_dS=False, skip_qu=False):

@@ -227,7 +227,8 @@ class SVMOGP(object):
                           (nothing to skip at that size, and the small-model kernels need the dense layout)
         quirks            "reference" (default: reproduce the reference's results including its known deviations from the
                           exact gradient) | "exact" (true ELBO gradients) | an int mask of _lib.QUIRK_*
-        strict_qf         HMOGP_CFG_STRICT_QF: q(f) and the row side of the gradients through the reference's solve-based forms
+        strict_qf         False | True | "auto" (default path, switching to the strict one while the engine reports an ill-conditioned
+                          K_uu -- one repeated evaluation at the switch).  True = HMOGP_CFG_STRICT_QF: q(f) and the row side of the gradients through the reference's solve-based forms
                           (svmogp_inf.py:214-218, :144-161) -- element-wise 1e-5 parity with the reference also where GPy's jitter
                           ladder is taken (K_uu with l >> inducing spacing, e.g. the notebook's own lengthscale 0.05 on
                           linspace(0, 1, M >= 24)); ~3.3x the step time at the headline size
@@ -265,7 +266,16 @@ class SVMOGP(object):
             exact_zero_windows = bool(self.Xdim == 1 and 128 <= self.num_inducing <= 8192 and
                                       all(x.shape[0] < 2 or bool(np.all(np.diff(x[:, 0]) >= 0.0)) for x in self.Xmulti_all))
         self.exact_zero_windows = bool(exact_zero_windows)
-        self.strict_qf = bool(strict_qf)
+        if isinstance(strict_qf, str) and strict_qf != "auto":
+            raise ValueError("strict_qf must be False, True or 'auto'")
+        # "auto": evaluate on the default path; the first evaluation the engine flags as ill-conditioned (hmogp_outputs.cond_est
+        # beyond what the explicit-inverse path keeps within 1e-5 of the reference) is repeated in the strict mode
+        # (HMOGP_EVAL_STRICT_QF), and so are the following ones until the estimate has fallen 10x below that threshold again
+        self._strict_auto = strict_qf == "auto"
+        self._strict_now = False
+        self.strict_switches = 0          # how often "auto" went from the default to the strict path
+        self.strict_qf = (strict_qf is True) or (not self._strict_auto and bool(strict_qf))
+        strict_qf = self.strict_qf
         self._engine = Engine(likelihood.specs(), self.num_latent_funcs, self.num_inducing, self.Xdim, device=device,
                               chunk_rows=chunk_rows, exact_zero_windows=exact_zero_windows, cache_kuu=True,
                               reuse_outputs=True, quirks=quirks, strict_qf=strict_qf,
@@ -400,7 +410,7 @@ class SVMOGP(object):
             hdist, reducer, rank, world = self._dist
             evaluate = lambda **kw: hdist.sharded_elbo_grad(self._engine, reducer, rank, world, **kw)  # noqa: E731
         on_dev = self._qu_on_device
-        out = evaluate(
+        args = dict(
             Z=self.Z.values, m_u=None if on_dev else self.q_u_means.values, L_flat=None if on_dev else self.q_u_chols.values,
             variance=[float(k.variance[0]) for k in self.kern_list],
             lengthscale=[float(k.lengthscale[0]) for k in self.kern_list],
@@ -408,15 +418,24 @@ class SVMOGP(object):
             kappa=np.stack([np.ravel(B.kappa.values) for B in self.B_list]), W0=W0, kappa0=k0,
             batch_scale=self.batch_scale, row_begin=[r[0] for r in self._rows], row_end=[r[1] for r in self._rows],
             forced_rung=self.forced_rung, group_mask=mask)
+        out = evaluate(strict_qf=self._strict_now, **args)
+        if self._strict_auto:
+            if not self._strict_now and out.get("ill_conditioned"):
+                self._strict_now = True                 # (every rank of a sharded model sees the same replicated estimate)
+                self.strict_switches += 1
+                out = evaluate(strict_qf=True, **args)  # the same parameters again, now through the reference's solve-based forms
+            elif self._strict_now and max(out["cond_est"]) < 50.0:
+                self._strict_now = False                # well-conditioned again (10x below the flag's threshold): default path next time
         self.last = out
         if out.get("ill_conditioned") and not getattr(self, "_warned_ill", False):
             self._warned_ill = True      # (once per model; model.last["cond_est"] / ["ill_conditioned"] are there on every evaluation)
             import warnings
             warnings.warn("K_uu is ill-conditioned for the %s path (condition estimates %s, jitter rungs %s): its ELBO / gradients may "
                           "differ from the reference's by more than 1e-5 element-wise%s (DESIGN.md 6a)" % (
-                              "strict q(f)" if self.strict_qf else "default (explicit-inverse)",
+                              "strict q(f)" if (self.strict_qf or self._strict_now) else "default (explicit-inverse)",
                               ["%.1e" % c for c in out["cond_est"]], out["rungs"],
-                              "" if self.strict_qf else "; construct the model with strict_qf=True"), RuntimeWarning)
+                              "" if (self.strict_qf or self._strict_now) else "; construct the model with strict_qf=True or 'auto'"),
+                          RuntimeWarning)
         self._log_marginal_likelihood = np.array([[out["elbo"]]])
         if not on_dev:                            # (device-resident q(u): its gradient stays in HBM for the optimiser)
             self.q_u_means.gradient = out["g_m_u"]

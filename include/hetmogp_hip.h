@@ -61,7 +61,7 @@ enum {
 #define HMOGP_FLAG_V_NEGATIVE 1u /* some v_fd < 0: the reference prints 'v negative!' (svmogp_inf.py:221) */
 #define HMOGP_FLAG_ILL_CONDITIONED 2u /* ABI v6: hmogp_outputs.cond_est of some latent is beyond what this engine's mode keeps within
    the north-star's element-wise 1e-5 of the reference: > 5e2 without HMOGP_CFG_STRICT_QF (cond(K_uu) ~ 1e4 and more: take the
-   strict mode), > 5e5 with it (cond ~ 1e7 and more: the reference's own numbers move by more than 1e-5 with the last bit of its
+   strict mode), > 1e6 with it (cond beyond the ~2e7 that GPy's jitter rung 0 leaves: the reference's own numbers move by more than 1e-5 with the last bit of its
    covariance there).  The reference has no such diagnostic (GPy's jitchol only reports a failed factorisation).              */
 
 /* Reference quirks (hmogp_config.quirks).  A set bit reproduces the reference's behaviour, a cleared
@@ -151,7 +151,11 @@ typedef struct {
   const int32_t* forced_rung; /* [Q] or NULL: -2 = run GPy's jitter ladder, -1 = no jitter,
                                  k>=0 = jitter mean(diag)*1e-6*10^k (compare CPU/GPU at equal rung)   */
   uint32_t group_mask;        /* HMOGP_GROUP_*                                                        */
+  uint32_t eval_flags;        /* HMOGP_EVAL_* of THIS evaluation (0 = none)                 (ABI version 6) */
 } hmogp_params;
+#define HMOGP_EVAL_STRICT_QF 1u /* run this evaluation in the strict q(f) mode (see HMOGP_CFG_STRICT_QF) whatever the engine was
+   created with: lets a caller re-evaluate, and go on evaluating, in that mode once hmogp_outputs.flags reported
+   HMOGP_FLAG_ILL_CONDITIONED -- the facade's strict_qf="auto".  Its extra workspaces are allocated at the first such call. */
 
 typedef struct {
   double* elbo;          /* [1]   log_marginal (svmogp_inf.py:88)                                     */
