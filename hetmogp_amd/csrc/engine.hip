@@ -1233,7 +1233,11 @@ struct hmogp_engine {
       const long long clen = (long long)M * (2 + P);          // one column-statistics slab: [ r (M) | dZ (M*P) | s2 (M) ]
       // [r5] the r2-weighted statistic of the lengthscale gradient comes from the column statistics (E and x - z are in hand there),
       // not from two more row statistics of the forward epilogue; strict q(f) keeps its own (strict_rowstats_kernel, GPy's r2 form)
-      const bool col_sl = want_hyper && !strict && !small_rows;
+      static const bool col_sl_env = [] {   // HMOGP_COL_SL=0 (TIMING ONLY: sl is then missing from the lengthscale gradient)
+        const char* e = getenv("HMOGP_COL_SL");
+        return !(e && e[0] == '0');
+      }();
+      const bool col_sl = want_hyper && !strict && !small_rows && col_sl_env;
       // slabs of the column statistics: 256-row splits
       const long long csplit = col_split(n);
       const long long nsp = (n + csplit - 1) / csplit;        // slabs of the column statistics
@@ -1284,15 +1288,18 @@ struct hmogp_engine {
         // streams K^ and P~ at 4.5 TB/s for 8.7 ms, evicts the Gram's operand panels from the L2s and stretches it from
         // 39.3 to 45.4 ms; 192 blocks take 32 ms of the Gram's 40 at 1.2 TB/s and stretch it to 39.9 (profiles/
         // r03_colstats_cap.txt: step 126.8 -> 120.7 ms).  Bytes per Gram flop scale with 1 / M, so the cap does too.
-        // [r5] the blocks also accumulate the r2-weighted statistic now (a third more arithmetic per element): 192 blocks took 42.7 ms,
-        // longer than the Gram's 39.6; 256 take 37.5 and leave the Gram at 39.4 (gpurun_out/cap_sweep.log -> profiles/r05_colstats_cap.txt).
+        // [r5] the blocks also accumulate the r2-weighted statistic now, and the kernel is instantiated per (strict, statistic)
+        // combination: with `want P~` a compile-time constant its row loop has no branch and a block streams 1.6x faster (192 blocks:
+        // 26.2 ms instead of 42.7 at the headline size, the Gram unchanged at 39.7).  The cap is no longer proportional to 1 / M:
+        // 256 blocks at M <= 512 (Gram 10.7 ms, column statistics 10.5: 33.5 ms per step instead of 34.9), 192 at M >= 1024
+        // (profiles/r05_colstats_cap.txt).
         static const int cap_env = [] {   // HMOGP_COLSTATS_CAP=<blocks in flight> (0 = one block per row split)
           const char* e = getenv("HMOGP_COLSTATS_CAP");
           return e ? atoi(e) : -1;
         }();
         // (exact-zero windows: the banded Gram is short; the cap was sized for the dense one)
         // (P > 1: more arithmetic per byte -- a block streams 4.8 instead of 6.3 GB/s at P = 2 -- so proportionally more of them)
-        const int cap = cap_env >= 0 ? cap_env : (use_windows ? 0 : std::max(48, (int)(262144.0 * (1.0 + 0.35 * (P - 1)) / std::max(1, M))));
+        const int cap = cap_env >= 0 ? cap_env : (use_windows ? 0 : (int)(std::min(256.0, std::max(192.0, 131072.0 / std::max(1, M))) * (1.0 + 0.35 * (P - 1))));
         launch_colstats(Kh.d() + off * M, Pt.d() + off * M, a.d(), valpha.d() + off, valpha0.d() + off, vbeta0.d() + off,
                         X + off * P, P, dZ.d(), ldz, rows, M, (int)csplit, want_z, colpart.d() + slab_first * clen, st2, cw, &cb, cap,
                         strict ? Ah.d() + off * M : nullptr, col_sl ? dell.d() : nullptr);

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void quad_multi_kernel(QuadMulti m) {
 // ---- colstats: thread = 2 columns, block = 512 columns x `rows` rows ----------------------------------------
 // STRICT (HMOGP_CFG_STRICT_QF only): r = A^T alpha from a second matrix and quirk Q10's r == 0 gating -- kept out of the hot-path
 // instantiation, which has to fit 64 registers to run beside the Gram.
-template <int P, bool STRICT>
+template <int P, bool STRICT, bool SL>
 __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restrict__ Kh, const double* __restrict__ Pt,
                                                        const double* __restrict__ a, const double* __restrict__ alpha,
                                                        const double* __restrict__ alpha0, const double* __restrict__ beta0,
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restri
   // [r5] ell != nullptr: also  s2[m] = sum_n E_nm |x_n - z_m|^2 / l^2  -- the r2-weighted statistic behind the lengthscale gradient
   // (sl = sum_m s2[m]; svmogp.py:140 -> GPy update_gradients_full).  It used to be carried by the forward contraction's epilogue
   // as two more row statistics (p~, c~) with the distances recomputed per element there; E_nm and x_n - z_m are in hand here.
-  const bool want_e = want_z || ell;
+  const bool want_e = want_z || SL;
   // A block takes the row splits blockIdx.y, blockIdx.y + gridDim.y, ...: the grid may be CAPPED (launch_colstats) so that
   // this HBM-bound pass occupies only a few CU slots at a time beside the FP64-MFMA Gram it runs next to -- a block that
   // holds half a CU while it waits for HBM keeps a Gram block (whose registers fill the other half) from being scheduled.
@@ -510,10 +510,9 @@ __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restri
           const double dx0 = x - z0[p], dx1 = x - z1[p];
           d0[p] += e0 * dx0;
           d1[p] += e1 * dx1;
-          q20 += dx0 * dx0, q21 += dx1 * dx1;
+          if (SL) q20 += dx0 * dx0, q21 += dx1 * dx1;
         }
-        s20 += e0 * q20;
-        s21 += e1 * q21;
+        if (SL) s20 += e0 * q20, s21 += e1 * q21;
       }
     }
     // partial layout per row-split: [ r (M) | dZ (M*P) | s2 (M) ]
@@ -952,13 +951,14 @@ void launch_colstats(const double* Kh, const double* Pt, const double* a, const 
     const long long per_y = (long long)grid.x * grid.z;
     grid.y = (unsigned)std::max<long long>(1, std::min<long long>(grid.y, max_blocks / per_y));
   }
-  if (Ar) {
-    DISPATCH_P(P, hipLaunchKernelGGL((colstats_kernel<PP, true>), grid, dim3(256), 0, s, Kh, Pt, a, alpha, alpha0, beta0, X, Z, ldz,
-                                     N, M, rows, want_z ? 1 : 0, partials, colwin, bt, Ar, ell));
-  } else {
-    DISPATCH_P(P, hipLaunchKernelGGL((colstats_kernel<PP, false>), grid, dim3(256), 0, s, Kh, Pt, a, alpha, alpha0, beta0, X, Z, ldz,
-                                     N, M, rows, want_z ? 1 : 0, partials, colwin, bt, Ar, ell));
-  }
+#define HM_COLSTATS(ST, SLV)                                                                                                        \
+  DISPATCH_P(P, hipLaunchKernelGGL((colstats_kernel<PP, ST, SLV>), grid, dim3(256), 0, s, Kh, Pt, a, alpha, alpha0, beta0, X, Z, ldz, \
+                                   N, M, rows, want_z ? 1 : 0, partials, colwin, bt, Ar, ell))
+  if (Ar && ell) { HM_COLSTATS(true, true); }
+  else if (Ar) { HM_COLSTATS(true, false); }
+  else if (ell) { HM_COLSTATS(false, true); }
+  else { HM_COLSTATS(false, false); }
+#undef HM_COLSTATS
 }
 
 // dst[q * sDst] += sum_m v[q][m]   (the per-column s2 of the column statistics -> the bundle's sl_q; fixed order)
