@@ -744,7 +744,7 @@ def other_configs(args):
     eng.set_data(X, Y)
     ms, cat, out = _time_steps(eng, prm, K, forced_rung=[4, 4, 4])
     entry("HD: headline shape (N_t=200000, M=1024, Q=3) with a dense-valued K^ (lengthscale = 40 spacings, jitter rung 4 forced)",
-          800000, 3, 1024, ms, cat, out, finite=bool(np.isfinite(out["elbo"])),
+          800000, 3, 1024, ms, cat, out, tag="HD", finite=bool(np.isfinite(out["elbo"])),
           note="timing record only: K_uu at this lengthscale is numerically singular, the ELBO is not a parity quantity")
     eng.close()
     return res
