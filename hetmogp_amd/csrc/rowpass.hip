@@ -7,6 +7,8 @@
 //                   101-131) -> row weights alpha/beta for the backward pass + scalar statistics
 //   colstats        r = K^T alpha, dZ numerators = colsum(E^ .* (x - z))                     (reads K^, P~ once)
 //   reducers        deterministic two-level sums (block partials -> bundle), no floating-point atomics
+#include <type_traits>
+
 #include "rowpass.h"
 #include "lik_device.h"
 #include "rbf_device.h"
@@ -62,34 +64,40 @@ __global__ __launch_bounds__(256) void rbf_kernel(const double* __restrict__ X, 
   const double zs0 = sumsq<P>(z0), zs1 = sumsq<P>(z1);
   const bool vec = two && ((M & 1) == 0);
   const int nr = (int)min((long long)RBF_ROWS, N - n0);
-  for (int r = 0; r < nr; ++r) {
-    double xv[P];
+  // (the row loop is instantiated for the vector-store and the scalar-store case: no per-row branch on a loop-invariant condition)
+  auto rows = [&](auto vec_c) {
+    constexpr bool VEC = decltype(vec_c)::value;
+    for (int r = 0; r < nr; ++r) {
+      double xv[P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) xv[p] = xs[r][p];
-    const double xsq = xs[r][P];
-    double r20, r21;
-    if (EXACT) {
-      r20 = rbf_r2<P>(xv, xsq, z0, zs0, ell), r21 = rbf_r2<P>(xv, xsq, z1, zs1, ell);
-    } else {
-      const double il2 = 1.0 / (ell * ell);
-      r20 = rbf_r2_fast<P>(xv, xsq, z0, zs0, il2), r21 = rbf_r2_fast<P>(xv, xsq, z1, zs1, il2);
+      for (int p = 0; p < P; ++p) xv[p] = xs[r][p];
+      const double xsq = xs[r][P];
+      double r20, r21;
+      if (EXACT) {
+        r20 = rbf_r2<P>(xv, xsq, z0, zs0, ell), r21 = rbf_r2<P>(xv, xsq, z1, zs1, ell);
+      } else {
+        const double il2 = 1.0 / (ell * ell);
+        r20 = rbf_r2_fast<P>(xv, xsq, z0, zs0, il2), r21 = rbf_r2_fast<P>(xv, xsq, z1, zs1, il2);
+      }
+      if (EXACT && same) {  // GPy's X2=None branch forces the diagonal distance to 0 (kern/stationary; K_uu-side calls only)
+        if (n0 + r == c) r20 = 0.0;
+        if (n0 + r == c + 1) r21 = 0.0;
+      }
+      // exp(-r2/2) underflows to exactly 0.0 beyond r2 ~ 1490.3: a wave whose 128 columns are all past that writes the
+      // zeros without evaluating the exponential (same values; NaNs fail the comparison and take the full path)
+      double k0 = 0.0, k1 = 0.0;
+      if (!__all(r20 > 1492.0 && r21 > 1492.0)) k0 = var * exp(-0.5 * r20), k1 = var * exp(-0.5 * r21);
+      double* out = K + (n0 + r) * M + c;
+      if (VEC)
+        *reinterpret_cast<f64x2*>(out) = f64x2{k0, k1};
+      else {
+        out[0] = k0;
+        if (two) out[1] = k1;
+      }
     }
-    if (same) {  // GPy's X2=None branch forces the diagonal distance to 0 (kern/stationary)
-      if (n0 + r == c) r20 = 0.0;
-      if (n0 + r == c + 1) r21 = 0.0;
-    }
-    // exp(-r2/2) underflows to exactly 0.0 beyond r2 ~ 1490.3: a wave whose 128 columns are all past that writes the
-    // zeros without evaluating the exponential (same values; NaNs fail the comparison and take the full path)
-    double k0 = 0.0, k1 = 0.0;
-    if (!__all(r20 > 1492.0 && r21 > 1492.0)) k0 = var * exp(-0.5 * r20), k1 = var * exp(-0.5 * r21);
-    double* out = K + (n0 + r) * M + c;
-    if (vec)
-      *reinterpret_cast<f64x2*>(out) = f64x2{k0, k1};
-    else {
-      out[0] = k0;
-      if (two) out[1] = k1;
-    }
-  }
+  };
+  if (vec) rows(std::true_type{});
+  else rows(std::false_type{});
 }
 
 // ---- exact-zero windows ----------------------------------------------------------------------------------------
