@@ -747,6 +747,21 @@ def other_configs(args):
           800000, 3, 1024, ms, cat, out, tag="HD", finite=bool(np.isfinite(out["elbo"])),
           note="timing record only: K_uu at this lengthscale is numerically singular, the ELBO is not a parity quantity")
     eng.close()
+    # HS -- the headline workload in the STRICT q(f) mode (HMOGP_CFG_STRICT_QF, DESIGN 6a: the reference's solve-based forms through
+    # blocked triangular solves; what parity in the jitter-ladder regime costs).  Reported beside `value`, never mixed into it.
+    prm, X, Y = make_case(SPECS, [200000] * 4, M=1024, Q=3, P=1, seed=20260929)
+    eng = Engine(SPECS, 3, 1024, 1, reuse_outputs=True, strict_qf=True)
+    eng.set_data(X, Y)
+    ms, cat, out = _time_steps(eng, prm, min(K, 3), warmup=1)
+    fl_strict = (5.0 + 1.0) * 800000 * 3 * 1024 ** 2 + 20.0 * 3 * 1024 ** 3   # two solves n M^2 each, T n M^2, P~ 2 n M^2, Gram n M^2
+    res.append({"workload": "HS: headline workload in the strict q(f) mode (HMOGP_CFG_STRICT_QF)", "ms_per_step": ms,
+                "steps_per_s": 1e3 / ms, "flops_executed": fl_strict, "tflops": fl_strict / ms / 1e9,
+                "frac_of_peak": fl_strict / ms / 1e9 / PEAK_FP64_MFMA_TFLOPS,
+                "kernel_ms_per_step": {k: round(v, 4) for k, v in cat.items()}, "elbo": out["elbo"], "steps": min(K, 3),
+                "cond_est": [float(c) for c in out["cond_est"]], "ill_conditioned": bool(out["ill_conditioned"]),
+                "note": "parity mode, not the headline: 6 n Q M^2 contraction flops instead of 3 n Q M^2, the triangular solves' "
+                        "GEMM updates at ~33 TFLOP/s"})
+    eng.close()
     return res
 
 
