@@ -215,3 +215,61 @@ def test_reducer_mode_negotiation_is_collective():
         assert r["native_preattached"] == ("native", False)
         assert r["agree_min_max"] == (3, 4)
     assert res[0]["native_partial"][2] == 1 and res[1]["native_partial"][2] == 0   # only the rank that had one destroyed it
+
+
+def _dry_run_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    import torch.distributed as dist
+    spec = importlib.util.spec_from_file_location("hm_dist", os.path.join(ROOT, "hetmogp_amd", "dist.py"))
+    hd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hd)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    calls = {"n": 0}
+    real = dist.all_reduce
+
+    def counting(*a, **kw):
+        calls["n"] += 1
+        return real(*a, **kw)
+    dist.all_reduce = counting
+    res = {}
+    res["plain_calls"] = (hd.all_agree(True), hd.agree_min_max(7), calls["n"])            # one rank: short-circuited, no collective
+    hd.force_collectives(True)
+    res["forced_calls"] = (hd.all_agree(True), hd.agree_min_max(7), calls["n"])           # forced: 1 + 2 flag reductions issued
+    api = (lambda: True, lambda: bytes(range(128)))
+    e = _FakeEngine(0)
+    red = hd.StatsReducer(e, mode="native", native_api=api, single_rank_exchange=True)     # one-rank world negotiates like a larger one
+    red()
+    res["native"] = (red.mode, e.comm, e.exchanged)
+    red.close()
+    e2 = _FakeEngine(0)
+    red2 = hd.StatsReducer(e2, single_rank_exchange=True)                                  # gloo: host mode, and it RUNS with one rank
+    red2()
+    res["host"] = (red2.mode, red2.n_calls, e2.wire.copy())
+    e3 = _FakeEngine(0)
+    red3 = hd.StatsReducer(e3)                                                             # default: a single rank skips the exchange
+    red3()
+    res["default_skips"] = (red3.mode, red3.n_calls)
+    hd.force_collectives(False)
+    dist.destroy_process_group()
+    q.put(res)
+
+
+@pytest.mark.timeout(300)
+def test_one_rank_dry_run_switches():
+    """bench.py --force-dist: `force_collectives` makes the negotiation's flag reductions real also in a world of one rank, and
+    `StatsReducer(single_rank_exchange=True)` negotiates ("native" first) and exchanges like a larger world."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_dry_run_worker, args=(_free_port(), q))
+    p.start()
+    r = q.get(timeout=240)
+    p.join(60)
+    assert p.exitcode == 0
+    assert r["plain_calls"] == (True, (7, 7), 0)
+    assert r["forced_calls"] == (True, (7, 7), 3)
+    assert r["native"] == ("native", (1, 0), 1)
+    assert r["host"][0] == "host" and r["host"][1] == 1 and np.array_equal(r["host"][2], np.arange(10) * 1.0)
+    assert r["default_skips"] == ("host", 0)
