@@ -32,7 +32,7 @@ __device__ __forceinline__ int diag_wm(int w) { return (0x4B >> w) & 1; }
 __device__ __forceinline__ int diag_wn(int w) { return (0x7E84 >> (2 * w)) & 3; }
 
 // One 128 x 128 tile of the contraction: main loop + epilogue (everything the kernel does once it knows its tile).
-template <int ROLE>
+template <int ROLE, bool FOLD = false>
 __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int ti, int tj, int split, Tile& lds, double* epi_a,
                                              int* hwinfo = nullptr) {
   const int batch = blockIdx.z;
@@ -55,6 +55,13 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lr = lane & 15, lk = lane >> 4;
   int wm = w >> 2, wn = w & 3;
+  // [r5] Triangular fold: inside the DIAGONAL 128-row block of C's fold (k in [j0, j0 + 128)) the wave column wn only meets
+  // non-zero entries from k = j0 + 32 wn on (op(B)[k][j] == 0 for k < j), so its MFMAs of the earlier k-steps are skipped: 8, 6,
+  // 4, 2 of the block's 8 k-steps for wn = 0 .. 3 (products with exact zeros: the accumulators keep their bits).  Waves w and
+  // w + 4 share a SIMD, so the upper four take the wave columns in REVERSE order: every SIMD carries 10 of 16 wave-steps.
+  // (FOLD: the paired kernel only -- the plain forward instantiation keeps its code)
+  if (FOLD && w >= 4) wn = 3 - wn;
+  const int klive = FOLD ? j0 + 32 * wn : 0;                    // first k-step whose MFMAs this wave issues
   unsigned sub = 0xFFu;                                         // bit a*2 + b: sub-tile (a, b) of the wave tile is computed
   const bool diag = ROLE == 2 && ti == tj && g.lower_only;
   // Diagonal tiles: the four (w, w + 4) wave pairs carry 8, 8, 10, 10 of the 36 needed sub-tiles, and a pair shares a SIMD,
@@ -211,11 +218,12 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
       cur ^= 1;
     }
   }
-  if (ROLE == 1 && kbeg < kend) frag(0, 0, 0);
+  if (ROLE == 1 && kbeg < kend && (!FOLD || kbeg >= klive)) frag(0, 0, 0);
 #define HM_SB __builtin_amdgcn_sched_barrier(0)
   for (int k0 = kbeg; ROLE == 1 && k0 < kend; k0 += BK) {
     const bool more = k0 + BK < kend;
-    if (live) {
+    const bool lv = !FOLD || k0 >= klive;                      // (wave-uniform; always true outside the fold's diagonal block)
+    if (lv) {
       frag(cur, 1, 1);
       HM_SB;
       mm8(0);
@@ -224,7 +232,7 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
     if (more) stage(cur ^ 1);
     if (k0 + 2 * BK < kend) load(k0 + 2 * BK);
     HM_SB;
-    if (live) {
+    if (lv) {
       frag(cur, 2, 0);
       HM_SB;
       mm8(1);
@@ -235,8 +243,8 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
       HM_SB;
     }
     __syncthreads();
-    if (live) {
-      if (more) frag(cur ^ 1, 0, 0);
+    if (more && (!FOLD || k0 + BK >= klive)) frag(cur ^ 1, 0, 0);
+    if (lv) {
       HM_SB;
       mm8(1);
       HM_SB;
@@ -383,13 +391,13 @@ __device__ __forceinline__ void rowpass_block(const GemmArgs& g, int tiles_n, in
     ti = v / tcols;
     tj = v - ti * tcols;
   }
-  rowpass_tile<ROLE>(g, tiles_n, ti, tj, split, lds, epi_a, hwinfo);
+  rowpass_tile<ROLE, PAIR>(g, tiles_n, ti, tj, split, lds, epi_a, hwinfo);
   // Triangular fold (b_tri > 0, the E-step's / predict_f's forward): the k-loop of column tile j starts at j, so the tiles of
   // a row panel do 8, 7, ... 1 eighths of a full tile's work.  In paired mode a block takes column tiles j and
   // tiles_n - 1 - j one after the other: every block does (tiles_n + 1) / tiles_n of a full tile -- equal durations.
   if (PAIR) {
     __syncthreads();                 // the epilogue of the first tile used the tile buffers as scratch
-    rowpass_tile<ROLE>(g, tiles_n, ti, tiles_n - 1 - tj, split, lds, epi_a);
+    rowpass_tile<ROLE, PAIR>(g, tiles_n, ti, tiles_n - 1 - tj, split, lds, epi_a);
   }
 }
 
