@@ -377,7 +377,21 @@ __global__ __launch_bounds__(256) void quad_kernel(QuadArgs a) {
 }
 
 // All segments of a pool in ONE launch (small models: three likelihood families of ~1000 rows each are three launches of a few
-// blocks otherwise); block -> segment by the prefix of block counts, likelihood by a block-uniform switch.
+// blocks otherwise); block -> segment by the prefix of block counts, likelihood by a block-uniform branch.
+// [r5] MASK = the likelihood families this instantiation carries (bit L for family L, bit 8 + d for Categorical with d latent
+// functions).  One kernel with all fifteen bodies inlined is allocated for the worst of them (256 VGPRs + 32 AGPRs, 380 spilled
+// SGPRs, one wave per SIMD); the sets of the BASELINE configurations get instantiations of their own (C1's
+// {HetGaussian, Bernoulli, Categorical(3)}: see the register table in DESIGN 11e), any other set the all-inclusive one.
+constexpr unsigned qm_bit(int lik, int dimf) { return lik == HMOGP_LIK_CATEGORICAL ? 1u << (8 + dimf) : 1u << lik; }
+constexpr unsigned QM_ALL = 0x1FFFFu & ~(1u << HMOGP_LIK_CATEGORICAL) & ~(1u << 8);
+constexpr unsigned QM_C1 = qm_bit(HMOGP_LIK_HETGAUSSIAN, 0) | qm_bit(HMOGP_LIK_BERNOULLI, 0) | qm_bit(HMOGP_LIK_CATEGORICAL, 2);
+constexpr unsigned QM_H4 = qm_bit(HMOGP_LIK_GAUSSIAN, 0) | qm_bit(HMOGP_LIK_BERNOULLI, 0) | qm_bit(HMOGP_LIK_POISSON, 0) |
+                           qm_bit(HMOGP_LIK_GAMMA, 0);
+constexpr unsigned QM_C5 = qm_bit(HMOGP_LIK_GAUSSIAN, 0) | qm_bit(HMOGP_LIK_CATEGORICAL, 3);
+constexpr unsigned QM_LIGHT = qm_bit(HMOGP_LIK_GAUSSIAN, 0) | qm_bit(HMOGP_LIK_BERNOULLI, 0) | qm_bit(HMOGP_LIK_HETGAUSSIAN, 0) |
+                              qm_bit(HMOGP_LIK_POISSON, 0) | qm_bit(HMOGP_LIK_EXPONENTIAL, 0);
+
+template <unsigned MASK>
 __global__ __launch_bounds__(256) void quad_multi_kernel(QuadMulti m) {
   __shared__ QuadShared sh;
   int s = 0;
@@ -396,28 +410,23 @@ __global__ __launch_bounds__(256) void quad_multi_kernel(QuadMulti m) {
   a.partials = m.partials + g.part0;
   a.out_mu = a.out_v = a.out_gm = a.out_gv = nullptr;
   const unsigned blk = blockIdx.x - g.blk0;
-#define QB(L) quad_body<L, 0, true>(a, blk, sh)
-#define QBC(D) quad_body<HMOGP_LIK_CATEGORICAL, D, true>(a, blk, sh)
-  switch (g.lik) {
-    case HMOGP_LIK_GAUSSIAN: QB(HMOGP_LIK_GAUSSIAN); break;
-    case HMOGP_LIK_BERNOULLI: QB(HMOGP_LIK_BERNOULLI); break;
-    case HMOGP_LIK_HETGAUSSIAN: QB(HMOGP_LIK_HETGAUSSIAN); break;
-    case HMOGP_LIK_POISSON: QB(HMOGP_LIK_POISSON); break;
-    case HMOGP_LIK_EXPONENTIAL: QB(HMOGP_LIK_EXPONENTIAL); break;
-    case HMOGP_LIK_GAMMA: QB(HMOGP_LIK_GAMMA); break;
-    case HMOGP_LIK_BETA: QB(HMOGP_LIK_BETA); break;
-    default:
-      switch (g.dimf) {
-        case 1: QBC(1); break;
-        case 2: QBC(2); break;
-        case 3: QBC(3); break;
-        case 4: QBC(4); break;
-        case 5: QBC(5); break;
-        case 6: QBC(6); break;
-        case 7: QBC(7); break;
-        default: QBC(8); break;
-      }
+#define QB(L)                                                  \
+  if constexpr ((MASK & qm_bit(L, 0)) != 0) {                  \
+    if (g.lik == L) {                                          \
+      quad_body<L, 0, true>(a, blk, sh);                       \
+      return;                                                  \
+    }                                                          \
   }
+#define QBC(D)                                                 \
+  if constexpr ((MASK & qm_bit(HMOGP_LIK_CATEGORICAL, D)) != 0) { \
+    if (g.lik == HMOGP_LIK_CATEGORICAL && g.dimf == D) {       \
+      quad_body<HMOGP_LIK_CATEGORICAL, D, true>(a, blk, sh);   \
+      return;                                                  \
+    }                                                          \
+  }
+  QB(HMOGP_LIK_GAUSSIAN) QB(HMOGP_LIK_BERNOULLI) QB(HMOGP_LIK_HETGAUSSIAN) QB(HMOGP_LIK_POISSON) QB(HMOGP_LIK_EXPONENTIAL)
+  QB(HMOGP_LIK_GAMMA) QB(HMOGP_LIK_BETA)
+  QBC(1) QBC(2) QBC(3) QBC(4) QBC(5) QBC(6) QBC(7) QBC(8)
 #undef QB
 #undef QBC
 }
@@ -876,7 +885,20 @@ void launch_quad_multi(const QuadMulti& m_in, hipStream_t s) {
     part += nb * (2 + 2 * m.Q + g.dimf + m.Q * g.dimf);
   }
   if (blocks == 0) return;
-  hipLaunchKernelGGL(quad_multi_kernel, dim3(blocks), dim3(256), 0, s, m);
+  unsigned need = 0;
+  for (int i = 0; i < m.nseg; ++i) need |= qm_bit(m.seg[i].lik, m.seg[i].dimf);
+  static const bool generic_only = [] {   // HMOGP_QUAD_GENERIC=1: always the all-inclusive instantiation (A/B runs)
+    const char* e = getenv("HMOGP_QUAD_GENERIC");
+    return e && e[0] == '1';
+  }();
+#define QML(MASK)                                                                             \
+  if (!generic_only && (need & ~(MASK)) == 0) {                                               \
+    hipLaunchKernelGGL((quad_multi_kernel<MASK>), dim3(blocks), dim3(256), 0, s, m);          \
+    return;                                                                                   \
+  }
+  QML(QM_C1) QML(QM_C5) QML(QM_H4) QML(QM_LIGHT)
+#undef QML
+  hipLaunchKernelGGL((quad_multi_kernel<QM_ALL>), dim3(blocks), dim3(256), 0, s, m);
 }
 
 void launch_var_exp(int lik, int J, double param, long long N, const double* y, const double* m, const double* v, double* ve,
