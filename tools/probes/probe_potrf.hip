@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <vector>
 #include <cmath>
+#include <cstring>
 extern long long* g_potrf_stamps;
 int main(int argc, char** argv) {
   const int Q = 3, M = argc > 1 ? atoi(argv[1]) : 1024;
@@ -31,6 +32,17 @@ int main(int argc, char** argv) {
     for (int i = 1; i < 8; ++i) printf(" %lld", st[i] - st[0]);
     printf("\n");
   }
+  // bit-level fingerprint of the factor (lower triangles): A/B runs of kernel variants must print the same value
+  HIP_TRY(hipMemcpy(h.data(), A, sizeof(double) * Q * MM, hipMemcpyDeviceToHost));
+  unsigned long long fp = 1469598103934665603ull;
+  for (int q = 0; q < Q; ++q)
+    for (int i = 0; i < M; ++i)
+      for (int j = 0; j <= i; ++j) {
+        unsigned long long b;
+        memcpy(&b, &h[q * MM + i * M + j], 8);
+        fp = (fp ^ b) * 1099511628211ull;
+      }
+  printf("factor fingerprint %016llx\n", fp);
   int hi[3]; HIP_TRY(hipMemcpy(hi, info, sizeof hi, hipMemcpyDeviceToHost));
   printf("info %d %d %d\n", hi[0], hi[1], hi[2]);
   return 0;
