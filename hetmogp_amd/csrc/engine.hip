@@ -241,12 +241,23 @@ void potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL
   // Two-level blocking: the bulk of the flops sits in updates of 128 columns at a time (full MFMA tiles: an update of a 32-column
   // block alone uses a quarter of a 128 x 128 tile), the 32-column substitution steps and their short updates stay inside a
   // 128-column block (strict forward at the headline size: 568 ms one-level, 337 ms two-level).
+  // [r5] inside a 128-column block the short updates ride in the substitution launches (right-looking, on the matrix cores, x taken
+  // from LDS: trsm_diag_kernel) where the shape allows it: 7 launches and ~740 column passes over HBM per block become 4 and 640
+  static const bool fuse_env = [] {   // HMOGP_TRSM_FUSE=0: separate 32-column GEMM updates (A/B runs)
+    const char* e = getenv("HMOGP_TRSM_FUSE");
+    return !(e && e[0] == '0');
+  }();
+  const bool fuse = fuse_env && trsm_diag_can_fuse(V, sV, M);
   constexpr int NB = 128;
   for (int J0 = 0; J0 < M; J0 += NB) {                        // X Luu^T = V   (forward over the columns)
     const int J1 = std::min(M, J0 + NB);
     if (J0 > 0) update(J0, J1 - J0, 0, J0, Luu + (long long)J0 * M, 0);
     for (int j0 = J0; j0 < J1; j0 += 32) {
       const int nb = std::min(32, J1 - j0);
+      if (fuse) {
+        launch_trsm_diag(0, V, sV, Luu, sL, M, j0, nb, n, Q, st, j0 + 32, J1);
+        continue;
+      }
       if (j0 > J0) update(j0, nb, J0, j0 - J0, Luu + (long long)j0 * M + J0, 0);
       launch_trsm_diag(0, V, sV, Luu, sL, M, j0, nb, n, Q, st);
     }
@@ -256,6 +267,10 @@ void potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL
     if (J1 < M) update(J0, J1 - J0, J1, M - J1, Luu + (long long)J1 * M + J0, 1);
     for (int j0 = J0 + ((J1 - J0 - 1) / 32) * 32; j0 >= J0; j0 -= 32) {
       const int nb = std::min(32, J1 - j0), j1 = j0 + nb;
+      if (fuse) {
+        launch_trsm_diag(1, V, sV, Luu, sL, M, j0, nb, n, Q, st, J0, j0);
+        continue;
+      }
       if (j1 < J1) update(j0, nb, j1, J1 - j1, Luu + (long long)j1 * M + j0, 1);
       launch_trsm_diag(1, V, sV, Luu, sL, M, j0, nb, n, Q, st);
     }

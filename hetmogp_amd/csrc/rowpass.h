@@ -57,8 +57,11 @@ struct StrictRows {
 };
 void launch_strict_rowstats(const StrictRows& a, hipStream_t s);
 // one <= 32-column diagonal block of the blocked triangular solves V L^T = B (dir 0) / A L = V (dir 1), in place, batched over Q
+// [u0, u1): columns of the same 128-column block that receive the block's right-looking update inside the launch (needs
+// trsm_diag_can_fuse; u0 == u1: none)
 void launch_trsm_diag(int dir, double* V, long long sV, const double* L, long long sL, int M, int j0, int nb, long long n, int Q,
-                      hipStream_t s);
+                      hipStream_t s, int u0 = 0, int u1 = 0);
+bool trsm_diag_can_fuse(const double* V, long long sV, int M);
 
 // [r4] every segment (task x row range) of a pool in one launch -- small models only: the weights are read from device memory
 #define HMOGP_QUAD_MULTI 8

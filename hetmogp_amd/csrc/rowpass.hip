@@ -1061,21 +1061,35 @@ __global__ __launch_bounds__(256) void strict_rowstats_kernel(StrictRows a) {
 // off-diagonal updates between two such steps are plain GEMMs (launch_gemm_f64, alpha = -1, beta = 1).
 template <int DIR>
 __global__ __launch_bounds__(256) void trsm_diag_kernel(double* __restrict__ V, long long sV, const double* __restrict__ L,
-                                                        long long sL, int M, int j0, int nb, long long n) {
+                                                        long long sL, int M, int j0, int nb, long long n, int wide, int u0, int u1) {
   // (the unknowns live in LDS, one column of 256 lanes per unknown -- conflict-free -- and the loops run at run time: with
   //  x[32] in registers and both loops unrolled the compiler hoists all 528 broadcast reads and spills ~1 KB per lane)
   __shared__ double Ls[32][33];
-  __shared__ double xs[32][256];
+  __shared__ double xs[32][258];
   V += (long long)blockIdx.y * sV, L += (long long)blockIdx.y * sL;
   const int t = threadIdx.x;
   for (int e = t; e < 32 * 32; e += 256) {
     const int r = e >> 5, c = e & 31;
     Ls[r][c] = (r < nb && c < nb) ? L[(long long)(j0 + r) * M + j0 + c] : (r == c ? 1.0 : 0.0);
   }
-  const long long row = (long long)blockIdx.x * 256 + t;
+  const long long row0 = (long long)blockIdx.x * 256, row = row0 + t;
   const bool valid = row < n;
   double* v = V + (valid ? row : 0) * M + j0;
-  for (int c = 0; c < 32; ++c) xs[c][t] = (valid && c < nb) ? v[c] : 0.0;
+  // [r5] the block's 256 x 32 right-hand sides enter (and leave) through 16-byte accesses in which 16 consecutive lanes cover one
+  // row's 256 bytes: one row per lane (32 loads of 8 bytes, lanes 8 KB apart) touched 64 cache lines per instruction
+  // (47 -> see DESIGN 12g ms per strict step at the headline size)
+  // (`wide` is decided by the launcher: nb == 32, even M / j0 / batch stride, 16-byte aligned V)
+  if (wide) {
+#pragma unroll 4
+    for (int e = t; e < 256 * 16; e += 256) {
+      const int r = e >> 4, ch = e & 15;
+      f64x2 v2 = f64x2{0.0, 0.0};
+      if (row0 + r < n) v2 = *reinterpret_cast<const f64x2*>(V + (row0 + r) * M + j0 + 2 * ch);
+      xs[2 * ch][r] = v2.x, xs[2 * ch + 1][r] = v2.y;
+    }
+  } else {
+    for (int c = 0; c < 32; ++c) xs[c][t] = (valid && c < nb) ? v[c] : 0.0;
+  }
   __syncthreads();
   // Chunks of 8 unknowns: their right-hand sides sit in 8 registers while the contributions of the unknowns solved before are
   // subtracted (one LDS read of the unknown + 8 broadcast reads of L feed 8 INDEPENDENT fused multiply-adds: the first version
@@ -1122,15 +1136,79 @@ __global__ __launch_bounds__(256) void trsm_diag_kernel(double* __restrict__ V, 
       for (int r = 0; r < 8; ++r) xs[c0 + r][t] = acc[r];
     }
   }
+  if (wide) {
+    __syncthreads();
+#pragma unroll 4
+    for (int e = t; e < 256 * 16; e += 256) {
+      const int r = e >> 4, ch = e & 15;
+      if (row0 + r < n) *reinterpret_cast<f64x2*>(V + (row0 + r) * M + j0 + 2 * ch) = f64x2{xs[2 * ch][r], xs[2 * ch + 1][r]};
+    }
+    // [r5] The RIGHT-LOOKING update of the columns [u0, u1) that this block's unknowns still feed inside the current 128-column
+    // block of the two-level scheme -- V[:, c] -= sum_k x[:, j0 + k] L[c][j0 + k] (DIR 0) / L[j0 + k][c] (DIR 1) -- on the
+    // matrix cores, 32 columns at a time, with the freshly solved x read from LDS where it already sits: the separate
+    // 32-column GEMM updates (one quarter of a 128-wide tile used, A and C streamed from HBM again) cost as much as the
+    // 128-column updates that carry 12 x their flops.  A wave owns 64 rows; D fragment: col = lane & 15, row = (lane >> 4) + 4 reg.
+    const int lane = t & 63, w = t >> 6, lr = lane & 15, lk = lane >> 4;
+    for (int g0 = u0; g0 < u1; g0 += 32) {
+      __syncthreads();                      // Ls: the substitution / the previous group's products are done with it
+      for (int e = t; e < 32 * 32; e += 256) {
+        if (DIR == 0) {
+          const int c = e >> 5, k = e & 31;
+          Ls[k][c] = L[(long long)(g0 + c) * M + j0 + k];
+        } else {
+          const int k = e >> 5, c = e & 31;
+          Ls[k][c] = L[(long long)(j0 + k) * M + g0 + c];
+        }
+      }
+      f64x4 acc[4][2];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long long rr = row0 + w * 64 + a * 16 + 4 * r + lk;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b][r] = rr < n ? V[rr * M + g0 + b * 16 + lr] : 0.0;
+        }
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        double fa[4], fb[2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) fa[a] = -xs[kk * 4 + lk][w * 64 + a * 16 + lr];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) fb[b] = Ls[kk * 4 + lk][b * 16 + lr];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long long rr = row0 + w * 64 + a * 16 + 4 * r + lk;
+          if (rr >= n) continue;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) V[rr * M + g0 + b * 16 + lr] = acc[a][b][r];
+        }
+    }
+    return;
+  }
   if (valid)
     for (int c = 0; c < nb; ++c) v[c] = xs[c][t];
 }
+bool trsm_diag_can_fuse(const double* V, long long sV, int M) {
+  return (M % 32) == 0 && (sV & 1) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0;
+}
 void launch_trsm_diag(int dir, double* V, long long sV, const double* L, long long sL, int M, int j0, int nb, long long n, int Q,
-                      hipStream_t s) {
+                      hipStream_t s, int u0, int u1) {
   if (n <= 0 || nb <= 0) return;
   dim3 grid((unsigned)((n + 255) / 256), Q);
-  if (dir == 0) hipLaunchKernelGGL((trsm_diag_kernel<0>), grid, dim3(256), 0, s, V, sV, L, sL, M, j0, nb, n);
-  else hipLaunchKernelGGL((trsm_diag_kernel<1>), grid, dim3(256), 0, s, V, sV, L, sL, M, j0, nb, n);
+  const int wide = (nb == 32 && (M & 1) == 0 && (j0 & 1) == 0 && (sV & 1) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0) ? 1 : 0;
+  if (u1 > u0 && (!wide || ((u1 - u0) & 31) || (u0 & 31)))
+    throw HipError{hipErrorInvalidValue, "trsm_diag: fused update needs full 32-column blocks and aligned rows", __FILE__, __LINE__};
+  if (dir == 0) hipLaunchKernelGGL((trsm_diag_kernel<0>), grid, dim3(256), 0, s, V, sV, L, sL, M, j0, nb, n, wide, u0, u1);
+  else hipLaunchKernelGGL((trsm_diag_kernel<1>), grid, dim3(256), 0, s, V, sV, L, sL, M, j0, nb, n, wide, u0, u1);
 }
 void launch_strict_rowstats(const StrictRows& a, hipStream_t s) {
   if (a.n <= 0) return;

@@ -297,7 +297,8 @@ def test_het_likelihood_samples_run_on_the_device():
 
 
 # ------------------------------------------------------------------------------------------------ specialised row-pass GEMMs
-@pytest.mark.parametrize("M,Ns,P", [(128, [777, 130, 1], 1), (256, [1030, 515], 2), (320, [900, 333], 1), (384, [2049, 17, 640], 1)])
+@pytest.mark.parametrize("M,Ns,P", [(128, [777, 130, 1], 1), (256, [1030, 515], 2), (320, [900, 333], 1), (384, [2049, 17, 640], 1),
+                                    (512, [1500, 700], 1)])     # (512: four column tiles = two fold pairs, diagonal-block skipping)
 def test_specialised_rowpass_kernels_vs_oracle(M, Ns, P):
     """gemm_rowpass.hip (8-wave forward / Gram kernels, taken when the inducing dimension is a multiple of 128) with ragged
     row counts (not multiples of 128 nor of 16, a 1-row task), full gradients and the E-step's triangular fold, against
