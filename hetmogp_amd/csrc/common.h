@@ -86,6 +86,9 @@ struct GemmArgs {
   int fs_ldz = 0, fs_P = 1, fs_hyper = 0;
   long long fs_sPart = 0, fs_sA = 0, fs_sZ = 0;
   int store_c = 1;               // 0: do not write P~ at all (no consumer when the Z gradient is not requested)
+  int fs_sq = 0;                 // role 1, specialised kernel: the ONE fused statistic is rowsum(C .* C) of the product itself (slot of
+                                 // `c`; fs_a / fs_x / fs_z unused) -- strict q(f): rowsum(T .* T) of T = A L_q without storing T
+  int c_sub = 0;                 // role 1, specialised kernel: C -= op(A) op(B)  (set by its launcher for alpha = -1, beta = 1)
   // Triangular operands: op(A) is M x K, op(B) is K x N; the k-loop of tile (i0, j0) is trimmed to the products that
   // can be non-zero.   a_tri = +1: op(A)[i][k] == 0 for k > i (lower)  -> k < i0 + 128;   -1: == 0 for k < i -> k >= i0
   //                    b_tri = +1: op(B)[k][j] == 0 for k < j (lower)  -> k >= j0;        -1: == 0 for k > j -> k < j0 + 128
@@ -112,6 +115,7 @@ void launch_gemm_f64(const GemmArgs& g, hipStream_t stream);
 bool gemm_rowpass_eligible(const GemmArgs& g);
 void launch_gemm_rowpass(const GemmArgs& g, hipStream_t stream);
 int launch_gemm_rowpass_or_general(const GemmArgs& g, hipStream_t stream);
+bool gemm_rowpass_would_take(const GemmArgs& g);   // will launch_gemm_rowpass_or_general use the specialised kernel for g?
 constexpr int GEMM_MAX_FWD_PARTS = 4;
 // 64 x 64-tile kernel for the replicated M x M products (gemm_small.hip); launch_gemm_f64 picks it when the 128-tile grid
 // would leave the device under-filled (env HMOGP_SMALL_GEMM=0 disables it).

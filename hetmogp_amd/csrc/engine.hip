@@ -226,8 +226,12 @@ void jitchol_batched(const double* Kuu, double* Luu, int Q, int M, const double*
 // V <- V Luu^-T Luu^-1 = dpotrs(Luu, V^T)^T for the n rows of V (n x M row-major, in place; batched over Q with strides sV / sL):
 // two BLOCKED TRIANGULAR SOLVES, 32-column diagonal blocks by true substitution (trsm_diag_kernel), the updates between them as
 // GEMMs (alpha = -1, beta = 1) -- backward stable like LAPACK's dtrsm.  Used by the strict q(f) mode and hmogp_potrs_rows.
-void potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL, int M, long long n, int Q, hipStream_t st) {
+void potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL, int M, long long n, int Q, hipStream_t st,
+                        double* Lsym = nullptr) {
   // C[:, c0:c0+nc] -= V[:, a0:a0+k] op(B)   (op(B) = Luu[c0.., a0..]^T for the forward solve, Luu[a0.., c0..] for the backward one)
+  // [r5] `role` 1 offers the update to the specialised 8-wave kernel (gemm_rowpass.hip, C -= A B form: 128-column updates with a
+  // k-major B); it falls back to the general kernel by itself.  The forward solve's B is the TRANSPOSE of a block of Luu: with
+  // `Lsym` (a Q x M x M scratch) it is read k-major from a mirrored copy of the factor.
   auto update = [&](int c0, int nc, int a0, int k, const double* B_, int b_kmajor) {
     GemmArgs g;
     g.A = V + a0, g.lda = M, g.a_kmajor = 0, g.sA = sV;
@@ -236,8 +240,14 @@ void potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL
     g.M = (int)n, g.N = nc, g.K = k;
     g.alpha = -1.0, g.beta = 1.0;
     g.nbatch = Q;
-    launch_gemm_f64(g, st);
+    g.role = 1;
+    launch_gemm_rowpass_or_general(g, st);
   };
+  const bool sym = Lsym != nullptr && n >= 4096 && sL == (long long)M * M;
+  if (sym) {
+    HIP_TRY(hipMemcpyAsync(Lsym, Luu, sizeof(double) * sL * Q, hipMemcpyDeviceToDevice, st));
+    launch_mirror_lower(Lsym, Q, M, sL, st);       // Lsym[k][j] = Luu[j][k] above the diagonal
+  }
   // Two-level blocking: the bulk of the flops sits in updates of 128 columns at a time (full MFMA tiles: an update of a 32-column
   // block alone uses a quarter of a 128 x 128 tile), the 32-column substitution steps and their short updates stay inside a
   // 128-column block (strict forward at the headline size: 568 ms one-level, 337 ms two-level).
@@ -251,7 +261,10 @@ void potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL
   constexpr int NB = 128;
   for (int J0 = 0; J0 < M; J0 += NB) {                        // X Luu^T = V   (forward over the columns)
     const int J1 = std::min(M, J0 + NB);
-    if (J0 > 0) update(J0, J1 - J0, 0, J0, Luu + (long long)J0 * M, 0);
+    if (J0 > 0) {
+      if (sym) update(J0, J1 - J0, 0, J0, Lsym + J0, 1);       // op(B)[k][j] = Luu[J0 + j][k] = Lsym[k][J0 + j]
+      else update(J0, J1 - J0, 0, J0, Luu + (long long)J0 * M, 0);
+    }
     for (int j0 = J0; j0 < J1; j0 += 32) {
       const int nb = std::min(32, J1 - j0);
       if (fuse) {
@@ -1203,15 +1216,41 @@ struct hmogp_engine {
     };
     for (int q = 0; q < Q; ++q)
       HIP_TRY(hipMemcpyAsync(Ah.d() + q * sK, Kh.d() + q * sK, sizeof(double) * n * M, hipMemcpyDeviceToDevice, st));
-    potrs_rows_inplace(Ah.d(), sK, Luu.d(), MM, M, n, Q, st);   // A = dpotrs(Luu, K^T)^T        (svmogp_inf.py:214-215)
-    rows_gemm(Ah.d(), L.d(), 1, +1, Pt.d());        // T = A L_q    = dtrmm(L_q^T, R)^T          (:217)
+    potrs_rows_inplace(Ah.d(), sK, Luu.d(), MM, M, n, Q, st, tmpB.d());   // A = dpotrs(Luu, K^T)^T   (svmogp_inf.py:214-215; tmpB: free here)
+    // T = A L_q = dtrmm(L_q^T, R)^T (:217) is only ever consumed as rowsum(T .* T) (:218): where the specialised fold kernel takes
+    // the product, its epilogue forms that sum from the accumulators and T is neither written nor read back (2 x 19.7 GB at H)
+    bool t2_fused = false;
+    {
+      GemmArgs g;
+      g.A = Ah.d(), g.lda = M, g.a_kmajor = 0, g.sA = sK;
+      g.B = L.d(), g.ldb = M, g.b_kmajor = 1, g.sB = MM, g.b_tri = +1;
+      g.C = Pt.d(), g.ldc = M, g.sC = sK;
+      g.M = (int)n, g.N = M, g.K = M;
+      g.nbatch = Q;
+      g.role = 1;
+      const int tiles = (M + 127) / 128;
+      g.fs_part = fwdpart.d(), g.fs_sPart = 4LL * FWD_PARTS * tiles * ldn, g.fs_sq = 1, g.store_c = 0;
+      static const bool t2_env = [] {   // HMOGP_STRICT_T2=0: T stored and squared by strict_rowstats_kernel (A/B runs)
+        const char* e = getenv("HMOGP_STRICT_T2");
+        return !(e && e[0] == '0');
+      }();
+      if (t2_env && gemm_rowpass_would_take(g)) {
+        const int nparts = launch_gemm_rowpass_or_general(g, st);
+        launch_combine_parts(fwdpart.d(), nparts * tiles, n, nullptr, vct.d(), nullptr, nullptr, st, Q, g.fs_sPart, ldn);
+        t2_fused = true;
+      } else {
+        rows_gemm(Ah.d(), L.d(), 1, +1, Pt.d());
+      }
+    }
     StrictRows sr;
     sr.M = M, sr.Q = Q, sr.P = P, sr.ldz = Q * P, sr.n = n, sr.ldn = ldn, sr.sK = sK, sr.sZ = P;
     sr.Kh = Kh.d(), sr.Ah = Ah.d(), sr.Tt = Pt.d(), sr.Pt = Pt.d(), sr.mu = dmu.d(), sr.a = a.d();
     sr.X = X, sr.Z = dZ.d(), sr.ell = dell.d();
     sr.p = vp.d(), sr.c = vc.d(), sr.pg = vpg.d(), sr.cg = vcg.d(), sr.pt = hyper ? vpt.d() : nullptr, sr.ct = hyper ? vct.d() : nullptr;
     sr.phase = 0;
+    sr.t2 = t2_fused ? vct.d() : nullptr;           // (vct: free until phase 1 writes the r2-weighted twin into it)
     launch_strict_rowstats(sr, st);                 // p = A m, c = rowsum(T^2) - rowsum(A .* K^)   (:216, :218)
+    sr.t2 = nullptr;
     if (!grads) return;
     rows_gemm(Ah.d(), Dm.d(), 1, 0, Pt.d());        // P~ = A (S Kuu^-1 - I)                      (:157-161)
     sr.phase = 1;

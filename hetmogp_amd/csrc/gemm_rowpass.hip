@@ -254,7 +254,23 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
 #undef HM_SB
 
   // ---- epilogue: D fragment of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg --------------------------
-  if (ROLE == 1 && fs_part) {
+  if (ROLE == 1 && fs_part && g.fs_sq) {
+    // [r5] strict q(f): the only statistic is rowsum(T .* T) of the product itself -- in-lane squares of the lane's 8 values per
+    // slice + the two shuffles over the four lanes of a row; same partial layout as `c` below (slot 1 of [stat][4 tiles_n][M])
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      double sq = 0.0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sq = fma(acc[a][b][r], acc[a][b][r], sq);
+      sq += __shfl_xor(sq, 16, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      const int rl = wm * 64 + a * 16 + lr;
+      if (lk == 0 && i0 + rl < M) fs_part[((long long)NWN * tiles_n + NWN * tj + wn) * M + (i0 + rl)] = sq;
+    }
+    if (!g.store_c) return;
+  } else if (ROLE == 1 && fs_part) {
     // Fused row statistics (GemmArgs::fs_*): lane (lr, lk) owns row rl = wm*64 + a*16 + lr and the column quads
     // wn*32 + b*16 + 4*lk + (0..3), b < 2, of slice a; it re-reads exactly its own 8 values of the K^ tile per slice
     // (L2/MALL-warm) with LDS-DMA loads (global_load_lds_dwordx4: lane l's 16 bytes land at base + 16*l) into a
@@ -326,6 +342,15 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
       const int row = i0 + wm * 64 + a * 16 + lr;
       if (row >= M) continue;
       double* crow = C + (long long)row * g.ldc + j0 + wn * WN + 4 * lk;
+      if (g.c_sub) {   // [r5] C -= op(A) op(B): the 128-column updates of the strict mode's blocked triangular solves
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const f64x2 c01 = *reinterpret_cast<const f64x2*>(crow + b * 16), c23 = *reinterpret_cast<const f64x2*>(crow + b * 16 + 2);
+          *reinterpret_cast<f64x2*>(crow + b * 16) = f64x2{c01.x - acc[a][b][0], c01.y - acc[a][b][1]};
+          *reinterpret_cast<f64x2*>(crow + b * 16 + 2) = f64x2{c23.x - acc[a][b][2], c23.y - acc[a][b][3]};
+        }
+        continue;
+      }
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         *reinterpret_cast<f64x2*>(crow + b * 16) = f64x2{acc[a][b][0], acc[a][b][1]};
@@ -423,19 +448,24 @@ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // Can this contraction take the specialised kernel?  (full 128-column tiles of the inducing dimension, k-extent a
 // multiple of 16 for the forward, even leading dimensions and 16-byte aligned operands, none of the general kernel's extras)
 bool gemm_rowpass_eligible(const GemmArgs& g) {
-  if (g.nouter != 1 || g.alpha != 1.0 || g.beta != 0.0 || g.win || g.M_last || g.N_last || g.K_last || g.a_tri) return false;
+  // [r5] role 1 also as the in-place update C -= op(A) op(B) (alpha = -1, beta = 1, no statistics, any k-extent that is a
+  // multiple of 16): launch_gemm_rowpass sets c_sub
+  const bool sub = g.role == 1 && g.alpha == -1.0 && g.beta == 1.0 && !g.fs_part && g.b_tri == 0 && g.store_c;
+  if (g.nouter != 1 || (!sub && (g.alpha != 1.0 || g.beta != 0.0)) || g.win || g.M_last || g.N_last || g.K_last || g.a_tri) return false;
   if ((g.lda & 1) || (g.ldb & 1) || (g.ldc & 1) || !aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return false;
   if ((g.sA & 1) || (g.sB & 1) || (g.sC & 1) || (g.sSplit & 1)) return false;
   if (g.role == 1)
     return !g.a_kmajor && g.b_kmajor && !g.lower_only && g.ksplit == 1 && !g.kscale && g.b_tri >= 0 && (g.N % BN) == 0 &&
-           (g.K % BK) == 0 && g.K == g.N && g.M >= 1;
+           (g.K % BK) == 0 && (g.K == g.N || sub) && g.K >= BK && g.M >= 1;
   if (g.role == 2)
     return g.a_kmajor && g.b_kmajor && g.kscale && g.b_tri == 0 && g.M == g.N && (g.N % BN) == 0 &&
            g.lda == g.ldb && g.K >= 1;
   return false;
 }
 
-void launch_gemm_rowpass(const GemmArgs& g, hipStream_t stream) {
+void launch_gemm_rowpass(const GemmArgs& g_in, hipStream_t stream) {
+  GemmArgs g = g_in;
+  g.c_sub = (g.role == 1 && g.alpha == -1.0 && g.beta == 1.0) ? 1 : 0;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   const int ntiles = g.lower_only ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
   const int gx = (g.ksplit > 1) ? ntiles * ((g.ksplit + 7) / 8) * 8 : ntiles;
@@ -454,14 +484,28 @@ void launch_gemm_rowpass(const GemmArgs& g, hipStream_t stream) {
   }
 }
 
-int launch_gemm_rowpass_or_general(const GemmArgs& g, hipStream_t stream) {
+static bool rowpass_enabled() {
   static const bool enabled = [] {   // HMOGP_ROWPASS=0 forces the general kernel (A/B measurements)
     const char* e = getenv("HMOGP_ROWPASS");
     return !(e && e[0] == '0');
   }();
+  return enabled;
+}
+bool gemm_rowpass_would_take(const GemmArgs& g) { return rowpass_enabled() && gemm_rowpass_eligible(g); }
+
+int launch_gemm_rowpass_or_general(const GemmArgs& g, hipStream_t stream) {
+  const bool enabled = rowpass_enabled();
+  if (g.fs_sq && !(enabled && gemm_rowpass_eligible(g)))
+    throw HipError{hipErrorInvalidValue, "fs_sq is a statistic of the specialised forward kernel only", __FILE__, __LINE__};
   if (enabled && gemm_rowpass_eligible(g)) {
     launch_gemm_rowpass(g, stream);
     return NWN;
+  }
+  if (g.role == 1 && (g.alpha != 1.0 || g.beta != 0.0)) {   // the general kernel's role-1 epilogue stores op(A) op(B) as it is
+    GemmArgs h = g;
+    h.role = 0;
+    launch_gemm_f64(h, stream);
+    return 2;
   }
   launch_gemm_f64(g, stream);
   return 2;

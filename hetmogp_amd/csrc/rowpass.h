@@ -54,6 +54,7 @@ struct StrictRows {
   const double* a = nullptr;      // [Q][M] Kuu^-1 m
   const double *X = nullptr, *Z = nullptr, *ell = nullptr;
   double *p = nullptr, *c = nullptr, *pg = nullptr, *cg = nullptr, *pt = nullptr, *ct = nullptr;   // [Q][ldn]
+  const double* t2 = nullptr;     // [Q][ldn] phase 0: rowsum(T .* T) already formed by the product's epilogue (Tt is not read)
 };
 void launch_strict_rowstats(const StrictRows& a, hipStream_t s);
 // one <= 32-column diagonal block of the blocked triangular solves V L^T = B (dir 0) / A L = V (dir 1), in place, batched over Q

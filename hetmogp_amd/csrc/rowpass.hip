@@ -1018,8 +1018,18 @@ __global__ __launch_bounds__(256) void strict_rowstats_kernel(StrictRows a) {
   const double* kh = a.Kh + q * a.sK + n * M;
   if (a.phase == 0) {
     const double* ah = a.Ah + q * a.sK + n * M;
-    const double* tt = a.Tt + q * a.sK + n * M;
     double sp = 0.0, st = 0.0, sk = 0.0;
+    if (a.t2) {        // rowsum(T .* T) came out of the product's epilogue (gemm_rowpass.hip, fs_sq): T was never stored
+      for (int m = lane; m < M; m += 64) {
+        const double av = ah[m];
+        sp += av * a.mu[(long long)m * a.Q + q];
+        sk += av * kh[m];
+      }
+      sp = wave_sum(sp), sk = wave_sum(sk);
+      if (lane == 0) a.p[q * a.ldn + n] = sp, a.c[q * a.ldn + n] = a.t2[q * a.ldn + n] - sk;
+      return;
+    }
+    const double* tt = a.Tt + q * a.sK + n * M;
     for (int m = lane; m < M; m += 64) {
       const double av = ah[m], tv = tt[m];
       sp += av * a.mu[(long long)m * a.Q + q];
