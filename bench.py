@@ -862,8 +862,9 @@ def svi_config(args, K):
             "svi_exact_zero_windows_elbo_last": w_elbo,       # (same iterates as svi_elbo_last: only products with exact zeros are skipped)
             "svi_natgrad_ms_per_iteration": ng_ms, "svi_natgrad_elbo_last": ng_elbo, "svi_natgrad_gamma": ng.gamma_used,
             "svi_natgrad_rejected_steps": ng.rejected,
-            "svi_natgrad_note": "same loop, E-steps = natural-gradient step of the device-resident q(u) (hmogp_qu_natgrad: "
-                                "one M^3/3 factorisation of the reversed precision + one triangular inverse per step, no host copy of q(u)); rows "
+            "svi_natgrad_note": "same loop, E-steps = natural-gradient step of the device-resident q(u) (hmogp_qu_natgrad_async: "
+                                "one M^3/3 factorisation of the reversed precision + one triangular inverse per step, committed on the device, "
+                                "no host synchronisation and no host copy of q(u); E-step evaluations skip dL/dS L, HMOGP_EVAL_NO_G_L); rows "
                                 "shuffled once, q(u) started at the prior, step size log-linear 1e-5 -> gamma over 20 E-steps "
                                 "(DeviceNatGrad); elbo_last after 35 + timed iterations vs the Adadelta loop's after 6 + timed"}
 

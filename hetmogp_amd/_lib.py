@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMOGP_LIB_PATH") or os.path.join(_HERE, "libhetmogp_hip.so")   # (override: A/B experiments)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 # likelihood ids (class names of the reference's likelihoods/<name>.py)
 LIK_GAUSSIAN, LIK_BERNOULLI, LIK_HETGAUSSIAN, LIK_CATEGORICAL, LIK_POISSON, LIK_EXPONENTIAL, LIK_GAMMA, LIK_BETA = range(8)
 LIK_IDS_BY_NAME = dict(Gaussian=0, Bernoulli=1, HetGaussian=2, Categorical=3, Poisson=4, Exponential=5, Gamma=6, Beta=7)
@@ -20,6 +20,7 @@ COMM_ID_BYTES = 128
 FLAG_V_NEGATIVE = 1
 FLAG_ILL_CONDITIONED = 2
 EVAL_STRICT_QF = 1
+EVAL_NO_G_L = 2           # (ABI v7) skip dL/dS L of this evaluation: natural-gradient E-steps
 GROUP_QU, GROUP_HYPER, GROUP_Z, GROUP_ALL = 1, 2, 4, 7
 CFG_EXACT_ZERO_WINDOWS = 1
 CFG_CACHE_KUU = 2
@@ -93,6 +94,8 @@ EXPORTS = {
     "hmogp_posterior_u": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "hmogp_natgrad_step": (C.c_int, [C.c_void_p, C.c_double, c_double_p, c_double_p]),
     "hmogp_qu_natgrad": (C.c_int, [C.c_void_p, C.c_double]),
+    "hmogp_qu_natgrad_async": (C.c_int, [C.c_void_p, C.c_double]),
+    "hmogp_qu_natgrad_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "hmogp_graph_stats": (C.c_int, [C.c_void_p, c_int64_p, c_int64_p]),
     "hmogp_predict_f": (C.c_int, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p]),
     "hmogp_last_timings": (C.c_int, [C.c_void_p, c_double_p, c_int64_p]),

@@ -671,6 +671,7 @@ struct hmogp_engine {
     comm_destroy();
     for (auto e : pool) (void)hipEventDestroy(e);
     if (h_info2) (void)hipHostFree(h_info2);
+    if (ev_ng) (void)hipEventDestroy(ev_ng);
     if (h_small) (void)hipHostFree(h_small);
     for (auto e : {ev_begin0, ev_begin1, ev_fin0, ev_fin1, ev_fork, ev_gsk, ev_zero, ev_info, ev_S, ev_join, ev_col, ev_kuf, ev_params, ev_ua, ev_qu})
       if (e) (void)hipEventDestroy(e);
@@ -1509,6 +1510,7 @@ struct hmogp_engine {
       // (strict q(f) -- config flag or this evaluation's HMOGP_EVAL_STRICT_QF -- runs on the regular kernels: the fused small-model
       //  kernels carry the explicit-inverse algebra only)
       strict = strict_cfg || (p && (p->eval_flags & HMOGP_EVAL_STRICT_QF) != 0);
+      skip_g_L = p && (p->eval_flags & HMOGP_EVAL_NO_G_L) != 0;
       if (strict && use_windows) throw EngineError{HMOGP_E_INVALID, "strict q(f) and HMOGP_CFG_EXACT_ZERO_WINDOWS exclude each other"};
       const bool want_small = !no_small && !strict && (small_env >= 0 ? small_env != 0 : (M <= 128 && rows_eval <= 65536 && !use_windows && !st2_masked));
       if (want_small != small_mode) {     // (rare: drain the queues the previous evaluations used before re-wiring them)
@@ -1537,6 +1539,7 @@ struct hmogp_engine {
     }
 
   bool sharded_call = false;
+  bool skip_g_L = false;        // HMOGP_EVAL_NO_G_L of this evaluation
   void begin(const hmogp_params* p, bool sync = true, bool will_exchange = false) {
     HIP_TRY(hipSetDevice(device));
     sharded_call = will_exchange || sync;      // (hmogp_step_begin is the first half of a split, i.e. exchanged, step)
@@ -1661,8 +1664,10 @@ struct hmogp_engine {
       if (want_qu) {
         launch_dlds(G.d(), Kuui.d(), Sqi.d(), dLdS.d(), MM * Q, st3);
         HIP_TRY(hipEventRecord(ev_S, st3));
-        mm(dLdS.d(), false, L.d(), true, tmpA.d(), 1.0, -1, -1, st3, 0, +1);  // dL_dS L (:175-177), L lower
-        launch_pack_gl(tmpA.d(), gL.d(), Q, M, st3);
+        if (!skip_g_L) {   // (HMOGP_EVAL_NO_G_L: a natural-gradient E-step consumes dL/dS and dL/dm only)
+          mm(dLdS.d(), false, L.d(), true, tmpA.d(), 1.0, -1, -1, st3, 0, +1);  // dL_dS L (:175-177), L lower
+          launch_pack_gl(tmpA.d(), gL.d(), Q, M, st3);
+        }
         launch_gmu(Kr.d(), a.d(), gmu.d(), Q, M, st3);
       }
       if (want_hz) {
@@ -1679,7 +1684,7 @@ struct hmogp_engine {
       }
       if (want_qu) {
         // the large gradient leaves on this stream as soon as it exists, beside the K_uu-side tail of the main stream
-        if (out->g_L_u && (group_mask & HMOGP_GROUP_QU))
+        if (out->g_L_u && (group_mask & HMOGP_GROUP_QU) && !skip_g_L)
           HIP_TRY(hipMemcpyAsync(out->g_L_u, gL.p, sizeof(double) * Mtri * Q, hipMemcpyDeviceToHost, st3));
         if (out->g_m_u && (group_mask & HMOGP_GROUP_QU))
           HIP_TRY(hipMemcpyAsync(out->g_m_u, gmu.p, sizeof(double) * M * Q, hipMemcpyDeviceToHost, st3));
@@ -1719,7 +1724,7 @@ struct hmogp_engine {
     const double *hg = hstage, *hkl = hstage + n_hg, *htail = hstage + n_hg + n_kl, *hrow = hstage + n_hg + n_kl + n_tail;
     const bool qu = (group_mask & HMOGP_GROUP_QU) != 0;
     if (out->g_m_u && !qu) std::memset(out->g_m_u, 0, sizeof(double) * M * Q);      // (copied on the second stream otherwise)
-    if (out->g_L_u && !qu) std::memset(out->g_L_u, 0, sizeof(double) * Mtri * Q);
+    if (out->g_L_u && (!qu || (skip_g_L && !small_path))) std::memset(out->g_L_u, 0, sizeof(double) * Mtri * Q);
     if (exchanged && comm) wait_exchanged();          // a collective is in flight: watchdog instead of a blind wait
     HIP_TRY(hipStreamSynchronize(st));
     if (small_path && small_failed()) {               // a latent needs GPy's jitter ladder: the regular path owns it
@@ -1850,6 +1855,8 @@ struct hmogp_engine {
   void qu_adadelta(int phase, double rate, double m, double d, double omd, double o) {
     if (!qu_resident) throw EngineError{HMOGP_E_STATE, "no resident q(u)"};
     if (phase == 1 && !evaluated) throw EngineError{HMOGP_E_STATE, "Adadelta update without a finished evaluation"};
+    if (phase == 1 && skip_g_L && !small_path && (group_mask & HMOGP_GROUP_QU) != 0)
+      throw EngineError{HMOGP_E_STATE, "the last evaluation ran with HMOGP_EVAL_NO_G_L: it left no gradient of q(u)'s factor"};
     HIP_TRY(hipSetDevice(device));
     const long long nm = (long long)M * Q, nl = ((long long)M * (M + 1) / 2) * Q;
     const bool has = phase == 1 && (group_mask & HMOGP_GROUP_QU) != 0;
@@ -1943,7 +1950,7 @@ struct hmogp_engine {
   // Core of the natural-gradient step: leaves the new m_u ([M, Q], the layout of dmu) in ng_mq and the new packed Cholesky
   // factor in ng_lflat; throws HMOGP_E_NOT_PD (nothing modified) when the step leaves the positive-definite cone.  ONE host
   // synchronisation (the two info words) at the end; everything else is enqueued back to back on the engine's stream.
-  void natgrad_core(double gamma) {
+  void natgrad_core(double gamma, bool sync = true) {
     if (!evaluated || !have_qu_grads) throw EngineError{HMOGP_E_STATE, "natural-gradient step needs a finished evaluation with the q(u) group"};
     if (!(gamma > 0.0)) throw EngineError{HMOGP_E_INVALID, "bad natural-gradient arguments"};
     HIP_TRY(hipSetDevice(device));
@@ -1951,6 +1958,7 @@ struct hmogp_engine {
     for (DevBuf* b : {&ng_t1, &ng_t2, &ng_th, &ng_mnew}) b->ensure(sizeof(double) * Q * M);
     ng_mq.ensure(sizeof(double) * M * Q), ng_lflat.ensure(sizeof(double) * Mtri * Q);
     if (!h_info2) HIP_TRY(hipHostMalloc((void**)&h_info2, sizeof(int) * 2 * HMOGP_MAXQ, hipHostMallocDefault));
+    if (ng_pending) (void)qu_natgrad_status();                                       // (its info words sit where this step's will land)
     HIP_TRY(hipStreamWaitEvent(st, ev_join, 0));                                     // the q(u) tail of the evaluation (third stream)
     // Lambda = S^-1 - 2 gamma dL/dS is the new precision.  It is factorised REVERSED (rows and columns): J Lambda J = R R^T
     // gives Lambda = U U^T with U = J R J upper triangular, hence S_new = Lambda^-1 = U^-T U^-1 and L_new = U^-T = the
@@ -1970,6 +1978,7 @@ struct hmogp_engine {
     launch_gemv_batched(GSK.d(), ng_t1.d(), ng_mnew.d(), Q, M, M, 1, st);            // m_new = S_new theta1 = L (L^T theta1)
     launch_pack_tril(GSK.d(), ng_lflat.d(), Q, M, 1.0, st);
     launch_scatter_mq(ng_mnew.d(), ng_mq.d(), Q, M, st);
+    if (!sync) return;               // hmogp_qu_natgrad_async: the commit is decided on the device, the host looks later
     HIP_TRY(hipStreamSynchronize(st));
     // (a failed step has only written scratch -- G, GSK, tmpA, tmpB -- none of which is an input of the step: the caller
     //  may retry with a smaller gamma straight away, no new evaluation needed)
@@ -1998,6 +2007,35 @@ struct hmogp_engine {
     HIP_TRY(hipMemcpyAsync(dLflat.p, ng_lflat.p, sizeof(double) * Mtri * Q, hipMemcpyDeviceToDevice, st));
     // (no synchronisation: the next evaluation reads q(u) on streams ordered behind this one -- see upload_params)
     HIP_TRY(hipEventRecord(ev_qu, st));
+  }
+
+  // [r5, ABI v7] hmogp_qu_natgrad without the host synchronisation: the commit into the resident q(u) is conditional ON THE DEVICE
+  // (commit_if_ok_kernel reads the factorisation's info words), the call returns with everything enqueued, and the caller goes
+  // straight on to the next evaluation -- whose parameter upload, pool staging and K_uf construction (second stream) then run BESIDE
+  // this step's latency-bound factorisation chain instead of behind a host round trip.  hmogp_qu_natgrad_status waits and reports.
+  hipEvent_t ev_ng = nullptr;
+  bool ng_pending = false, ng_last_taken = true;
+  void qu_natgrad_async(double gamma) {
+    if (!qu_resident) throw EngineError{HMOGP_E_STATE, "no resident q(u) (hmogp_qu_load)"};
+    if (ng_pending) throw EngineError{HMOGP_E_STATE, "a natural-gradient step is pending (hmogp_qu_natgrad_status)"};
+    natgrad_core(gamma, false);
+    const long long Mtri = (long long)M * (M + 1) / 2;
+    launch_commit_if_ok(dinfo.as<int>(), Q, ng_mq.d(), dmu.d(), (long long)M * Q, ng_lflat.d(), dLflat.d(), Mtri * Q, st);
+    HIP_TRY(hipEventRecord(ev_qu, st));
+    if (!ev_ng) HIP_TRY(hipEventCreateWithFlags(&ev_ng, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev_ng, st));
+    ng_pending = true;
+    evaluated = false;               // q(u) (probably) moves on: posterior / predict / another step need a fresh evaluation
+  }
+  int qu_natgrad_status() {
+    if (ng_pending) {
+      HIP_TRY(hipSetDevice(device));
+      HIP_TRY(hipEventSynchronize(ev_ng));
+      ng_pending = false;
+      ng_last_taken = true;
+      for (int q = 0; q < Q; ++q) ng_last_taken = ng_last_taken && h_info2[q] == 0;
+    }
+    return ng_last_taken ? 1 : 0;
   }
 
   void predict_f(const double* Xnew, long long Nnew, double* m, double* v) {
@@ -2318,6 +2356,14 @@ int hmogp_graph_stats(hmogp_handle h, int64_t* captures, int64_t* replays) {
   return HMOGP_OK;
 }
 
+int hmogp_qu_natgrad_async(hmogp_handle h, double gamma) {
+  if (!h) return HMOGP_E_INVALID;
+  return guarded(h, [&] { h->qu_natgrad_async(gamma); });
+}
+int hmogp_qu_natgrad_status(hmogp_handle h, int32_t* taken) {
+  if (!h || !taken) return HMOGP_E_INVALID;
+  return guarded(h, [&] { *taken = h->qu_natgrad_status(); });
+}
 int hmogp_qu_natgrad(hmogp_handle h, double gamma) {
   if (!h) return HMOGP_E_INVALID;
   return guarded(h, [&] { h->qu_natgrad(gamma); });

@@ -25,6 +25,8 @@ void launch_qf_combine(const double* p, const double* c, long long ldn, long lon
 // natural-gradient step of q(u)
 void launch_natgrad_prec(const double* Sqi, const double* dLdS, double gamma, double* out, int Q, int M, bool reversed,
                          hipStream_t s);
+void launch_commit_if_ok(const int* info, int Q, const double* src1, double* dst1, long long n1, const double* src2, double* dst2,
+                         long long n2, hipStream_t s);
 void launch_antitranspose(const double* T, double* L, int Q, int M, hipStream_t s);  // L[i][j] = T[M-1-j][M-1-i]
 void launch_gemv_t_batched(const double* A, const double* x, double* y, int Q, int M, hipStream_t s);  // y = A^T x, [Q][M]
 void launch_natgrad_theta1(const double* t1, const double* t2, const double* gm, double gamma, double* out, int Q, int M,

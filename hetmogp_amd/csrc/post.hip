@@ -307,6 +307,26 @@ void launch_natgrad_theta1(const double* t1, const double* t2, const double* gm,
 void launch_pack_tril(const double* T, double* out, int Q, int M, double scale, hipStream_t s) {
   hipLaunchKernelGGL(pack_tril_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, T, out, Q, M, scale);
 }
+// dst1 <- src1, dst2 <- src2 unless one of the Q info words is non-zero (hmogp_qu_natgrad_async: a step that left the
+// positive-definite cone commits nothing -- decided on the device, the host looks at the info words later)
+__global__ __launch_bounds__(256) void commit_if_ok_kernel(const int* __restrict__ info, int Q, const double* __restrict__ src1,
+                                                           double* __restrict__ dst1, long long n1, const double* __restrict__ src2,
+                                                           double* __restrict__ dst2, long long n2) {
+  for (int q = 0; q < Q; ++q)
+    if (info[q] != 0) return;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += stride) {
+    if (i < n1) dst1[i] = src1[i];
+    else dst2[i - n1] = src2[i - n1];
+  }
+}
+void launch_commit_if_ok(const int* info, int Q, const double* src1, double* dst1, long long n1, const double* src2, double* dst2,
+                         long long n2, hipStream_t s) {
+  const long long n = n1 + n2;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(commit_if_ok_kernel, dim3((unsigned)std::min<long long>(2048, (n + 255) / 256)), dim3(256), 0, s, info, Q,
+                     src1, dst1, n1, src2, dst2, n2);
+}
 void launch_scatter_mq(const double* v, double* out, int Q, int M, hipStream_t s) {
   hipLaunchKernelGGL(scatter_mq_kernel, dim3((M + 255) / 256, Q), dim3(256), 0, s, v, out, Q, M);
 }

@@ -137,7 +137,7 @@ class Engine(object):
 
     # ------------------------------------------------------------------------------------------ params
     def _params(self, Z, m_u, L_flat, variance, lengthscale, W, kappa, W0=None, kappa0=None, batch_scale=None,
-                row_begin=None, row_end=None, forced_rung=None, group_mask=_lib.GROUP_ALL, strict_qf=None):
+                row_begin=None, row_end=None, forced_rung=None, group_mask=_lib.GROUP_ALL, strict_qf=None, skip_g_L=False):
         """hmogp_params for one call.  The struct and the addresses of the arrays it points to are kept between calls: an
         argument that is THE SAME C-contiguous array object as last time (an optimiser updating its parameters in place) costs
         one identity check; anything else is converted (copied if it has to be) and its address taken again."""
@@ -166,7 +166,7 @@ class Engine(object):
             keep[k] = b
             last[k] = a if b is a else None      # (a converted copy does not follow later in-place changes of `a`: convert again)
         p.group_mask = int(group_mask)
-        p.eval_flags = _lib.EVAL_STRICT_QF if strict_qf else 0      # (per evaluation; Engine(strict_qf=True) has it always on)
+        p.eval_flags = (_lib.EVAL_STRICT_QF if strict_qf else 0) | (_lib.EVAL_NO_G_L if skip_g_L else 0)   # (per evaluation)
         return p, keep
 
     def _outputs(self, want_dL_dS=False, skip_qu=False):
@@ -337,6 +337,17 @@ class Engine(object):
         """Natural-gradient step on the DEVICE-RESIDENT q(u) (hmogp_qu_natgrad): in place in HBM, from the gradients of the
         last evaluation.  Raises LinAlgError (HMOGP_E_NOT_PD) with q(u) untouched when gamma is too large."""
         check(lib.hmogp_qu_natgrad(self._h, float(gamma)), self._h)
+
+    def qu_natgrad_async(self, gamma=1.0):
+        """hmogp_qu_natgrad_async (ABI v7): the same step without the host synchronisation -- committed on the device only if it
+        stays inside the positive-definite cone; `qu_natgrad_status()` tells later.  The next evaluation may be enqueued at once."""
+        check(lib.hmogp_qu_natgrad_async(self._h, float(gamma)), self._h)
+
+    def qu_natgrad_status(self):
+        """True if the last asynchronous natural-gradient step was committed (waits for it if it is still pending)."""
+        t = C.c_int32(0)
+        check(lib.hmogp_qu_natgrad_status(self._h, C.byref(t)), self._h)
+        return bool(t.value)
 
     def qu_adadelta(self, phase, step_rate, momentum, decay, offset):
         check(lib.hmogp_qu_adadelta(self._h, int(phase), float(step_rate), float(momentum), float(decay), float(1 - decay),

@@ -132,10 +132,20 @@ class DeviceNatGrad(DeviceAdadelta):
     on the device (`hmogp_qu_natgrad`: in place, no host copy of q(u)), the remaining free parameters keep their Adadelta
     recurrence on the host and only move on M-steps (their E-step gradients are gated to zero by the reference's own
     logic).  A step that would leave the positive-definite cone is retried with gamma halved (q(u) untouched by a failed
-    step); `gamma_used` records the last accepted value."""
+    step); `gamma_used` records the last accepted value.
+    `overlap=True` (default; single-process models): the step is enqueued with `hmogp_qu_natgrad_async` -- committed on the device
+    only if it stays inside the cone -- and the loop goes straight on to the next minibatch, whose upload, staging and K_uf
+    construction run beside the step's factorisation chain; the outcome is read after that next evaluation (`step_taken` /
+    `gamma` of an iteration then describe the PREVIOUS E-step's update).  A refused step is not retried on the spot (its gradients
+    are gone): the step size of the following E-steps is halved until one is accepted.  E-step evaluations also skip the
+    gradient of q(u)'s factor (HMOGP_EVAL_NO_G_L: the update consumes dL/dS and dL/dm only)."""
 
-    def __init__(self, model, gamma=0.1, step_rate=1.0, decay=0.9, momentum=0.0, offset=1e-4, gamma_start=1e-5, warmup=20):
+    def __init__(self, model, gamma=0.1, step_rate=1.0, decay=0.9, momentum=0.0, offset=1e-4, gamma_start=1e-5, warmup=20,
+                 overlap=True):
         DeviceAdadelta.__init__(self, model, step_rate=step_rate, decay=decay, momentum=momentum, offset=offset)
+        self.overlap = bool(overlap) and getattr(model, "_dist", None) is None
+        self._backoff = 1.0          # overlap mode: factor on the scheduled step size after refused steps (halved per refusal)
+        self._pending = False
         self.gamma = float(gamma)
         self.gamma_used = float(gamma)
         self.rejected = 0            # step sizes refused by hmogp_qu_natgrad (halved and retried)
@@ -148,8 +158,27 @@ class DeviceNatGrad(DeviceAdadelta):
         # be comparable with K_uu^-1 damps it; the schedule is the usual remedy for non-conjugate natural-gradient VI.
         self.gamma_start, self.warmup, self.e_steps = float(min(gamma_start, gamma)), int(warmup), 0
 
+    def _resolve_pending(self, eng):
+        """Outcome of the natural-gradient step that was enqueued in the previous E-step (overlap mode)."""
+        taken = eng.qu_natgrad_status()
+        self._pending = False
+        self.step_taken = bool(taken)
+        if taken:
+            self.gamma_used, self._backoff = self._gam_pending, 1.0
+        else:
+            self.rejected += 1
+            self.gamma_used = 0.0
+            self._backoff *= 0.5
+            if self._backoff < 2.0 ** -8:      # eight refusals in a row: say so (q(u) has not moved since) and start over
+                self.skipped += 1
+                self._backoff = 1.0
+                import warnings
+                warnings.warn("natural-gradient E-steps refused eight times in a row down to gamma = %.3g (q(u) unchanged)"
+                              % (self._gam_pending,), RuntimeWarning)
+
     def __iter__(self):
         m, eng = self.model, self.model._engine
+        self._pending = False
         try:
             while True:
                 d, o, mom, rate = self.decay, self.offset, self.momentum, self.step_rate
@@ -158,7 +187,13 @@ class DeviceNatGrad(DeviceAdadelta):
                 m.set_data(*m.new_batch())                         # stochastic_grad, svmogp.py:188-199
                 self._set_small()
                 e_step = bool(m.vem_step)
-                m.parameters_changed()
+                m._skip_g_L = e_step and m._dist is None           # (E-steps: dL/dS and dL/dm are all the update reads)
+                try:
+                    m.parameters_changed()                         # (a pending step completes on the device in front of it)
+                finally:
+                    m._skip_g_L = False
+                if self._pending:
+                    self._resolve_pending(eng)
                 g = self._small_gradient()
                 if m.vem_step:
                     if m.ve_count > 2:
@@ -185,6 +220,16 @@ class DeviceNatGrad(DeviceAdadelta):
                     frac = min(1.0, self.e_steps / float(self.warmup)) if self.warmup > 0 else 1.0
                     gam = float(np.exp(np.log(self.gamma_start) + frac * (np.log(self.gamma) - np.log(self.gamma_start))))
                     self.e_steps += 1
+                    if self.overlap:
+                        self._gam_pending = gam * self._backoff
+                        eng.qu_natgrad_async(self._gam_pending)
+                        self._pending = True
+                        m._qu_host_stale = True
+                        m._dirty = True
+                        self.n_iter += 1
+                        yield dict(n_iter=self.n_iter, gradient=g, step=self.step, gamma=self.gamma_used,
+                                   step_taken=bool(self.step_taken))
+                        continue
                     self.step_taken = False
                     for _ in range(8):
                         try:
@@ -207,6 +252,8 @@ class DeviceNatGrad(DeviceAdadelta):
                            step_taken=bool(self.step_taken) if e_step else None)
         finally:
             try:
+                if self._pending:
+                    self._resolve_pending(eng)
                 self.finish()
             except Exception:
                 pass
@@ -418,6 +465,8 @@ class SVMOGP(object):
             kappa=np.stack([np.ravel(B.kappa.values) for B in self.B_list]), W0=W0, kappa0=k0,
             batch_scale=self.batch_scale, row_begin=[r[0] for r in self._rows], row_end=[r[1] for r in self._rows],
             forced_rung=self.forced_rung, group_mask=mask)
+        if getattr(self, "_skip_g_L", False) and self._dist is None:
+            args["skip_g_L"] = True              # (set by DeviceNatGrad around its E-step evaluations)
         out = evaluate(strict_qf=self._strict_now, **args)
         if self._strict_auto:
             if not self._strict_now and out.get("ill_conditioned"):
@@ -553,7 +602,7 @@ class SVMOGP(object):
         return DeviceAdadelta(self, step_rate=step_rate, decay=decay, momentum=momentum, offset=offset)
 
     def device_natgrad(self, gamma=0.1, step_rate=1.0, decay=0.9, momentum=0.0, offset=1e-4, shuffle=True, seed=0,
-                       init="prior"):
+                       init="prior", overlap=True):
         """The SVI loop with natural-gradient E-steps on the device-resident q(u) (DeviceNatGrad); None when it does not
         apply (same conditions as `device_adadelta`).  `shuffle` (default on): `shuffle_rows(seed)` first -- natural-gradient
         steps need minibatches that represent the whole data set.  `init="prior"` (default) starts q(u) at p(u)
@@ -566,7 +615,7 @@ class SVMOGP(object):
             self.init_q_u_to_prior()
         elif init is not None:
             raise ValueError("init must be 'prior' or None")
-        return DeviceNatGrad(self, gamma=gamma, step_rate=step_rate, decay=decay, momentum=momentum, offset=offset)
+        return DeviceNatGrad(self, gamma=gamma, step_rate=step_rate, decay=decay, momentum=momentum, offset=offset, overlap=overlap)
 
     def callback(self, i, max_iter, verbose=True, verbose_plot=False):
         """svmogp.py:201-217."""

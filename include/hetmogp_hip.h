@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMOGP_ABI_VERSION 6
+#define HMOGP_ABI_VERSION 7
 
 /* likelihood ids (class names of /root/reference/likelihoods/<name>.py) */
 enum {
@@ -156,6 +156,10 @@ typedef struct {
 #define HMOGP_EVAL_STRICT_QF 1u /* run this evaluation in the strict q(f) mode (see HMOGP_CFG_STRICT_QF) whatever the engine was
    created with: lets a caller re-evaluate, and go on evaluating, in that mode once hmogp_outputs.flags reported
    HMOGP_FLAG_ILL_CONDITIONED -- the facade's strict_qf="auto".  Its extra workspaces are allocated at the first such call. */
+#define HMOGP_EVAL_NO_G_L 2u /* (ABI v7) the gradient of q(u)'s Cholesky factor is not wanted from this evaluation: dL/dS L and its packing
+                             * are skipped (outputs.g_L_u, if given, is zero-filled).  A natural-gradient E-step consumes dL/dS and dL/dm
+                             * only (hmogp_natgrad_step / hmogp_qu_natgrad*).  hmogp_qu_adadelta phase 1 refuses to follow such an
+                             * evaluation (HMOGP_E_STATE).  Ignored by the fused small-model path (M <= 64), which forms it anyway. */
 
 typedef struct {
   double* elbo;          /* [1]   log_marginal (svmogp_inf.py:88)                                     */
@@ -268,6 +272,15 @@ int hmogp_natgrad_step(hmogp_handle h, double gamma, double* m_u_new, double* L_
  * gradients of the last evaluation untouched (the step only wrote scratch), so the caller can retry at once with a smaller
  * gamma.  After a successful step posterior_u / predict_f / another step need a new evaluation (HMOGP_E_STATE otherwise).  */
 int hmogp_qu_natgrad(hmogp_handle h, double gamma);
+/* (ABI v7) The same in-place step WITHOUT the host synchronisation.  Everything is enqueued, the commit into the resident q(u) is
+ * decided on the device (a step that leaves the positive-definite cone writes nothing), and the call returns at once: the caller
+ * can enqueue the next evaluation straight away -- its parameter upload, row staging and K_uf construction then run beside this
+ * step's factorisation chain instead of behind a host round trip (0.3 ms per SVI iteration at M = 1024, Q = 3).
+ * hmogp_qu_natgrad_status waits for the pending step (if any) and sets *taken = 1 if it was committed, 0 if it was refused (q(u)
+ * unchanged; the gradients it was computed from are gone once a new evaluation has run: take a smaller step from the new ones).
+ * At most one step may be pending (HMOGP_E_STATE); the synchronous entry points resolve a pending step first.              */
+int hmogp_qu_natgrad_async(hmogp_handle h, double gamma);
+int hmogp_qu_natgrad_status(hmogp_handle h, int32_t* taken);
 
 /* ---- device-resident q(u) and its Adadelta state: the SVI loop without moving 2 x 12.6 MB per iteration ------ */
 /* The reference's stochastic driver (util.py:321-329) runs climin.Adadelta over the flat optimiser vector, 98 % of which

@@ -82,6 +82,13 @@ def test_monotone_elbo_headline_mix_M1024_and_rejected_steps():
     assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
     e.qu_natgrad(0.05)                                           # no new evaluation in between
     assert e.elbo_grad(m_u=None, L_flat=None, **small)["elbo"] > prev
+    # the same absurd step through the asynchronous entry point (ABI v7): refused ON THE DEVICE, nothing committed, reported later
+    before = e.qu_read()
+    e.qu_natgrad_async(1e6)
+    assert e.qu_natgrad_status() is False
+    after = e.qu_read()
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    e.elbo_grad(m_u=None, L_flat=None, **small)
     with pytest.raises(Exception):
         e.qu_natgrad(0.05)
         e.qu_natgrad(0.05)                                       # two steps from one evaluation: E_STATE
@@ -112,3 +119,74 @@ def test_facade_svi_loop_with_natural_gradient_e_steps():
     # q(u) came back to the host arrays when the loop ended and the model evaluates consistently from them
     m_ng.parameters_changed()
     assert np.isfinite(m_ng.log_likelihood()[0, 0])
+
+
+def test_async_step_equals_synchronous_step_and_refused_steps_commit_nothing():
+    """hmogp_qu_natgrad_async (ABI v7): committed on the device only inside the positive-definite cone; bit for bit the synchronous
+    step; a refused step leaves the resident q(u) as it was; the next evaluation may be enqueued before the status is read.
+    HMOGP_EVAL_NO_G_L: same ELBO, dL/dm and dL/dS, no factor gradient; Adadelta refuses to follow it."""
+    from hetmogp_amd.engine import Engine
+    from hetmogp_amd import _lib
+    specs = [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {}), ("Poisson", {})]
+    M, Q = 256, 2
+    prm, X, Y = _case(specs, 3000, M, Q, 104)
+    small = {k: v for k, v in prm.items() if k not in ("m_u", "L_flat")}
+    es = []
+    for _ in range(2):
+        e = Engine(specs, Q, M, 1)
+        e.set_data(X, Y)
+        e.qu_load(prm["m_u"], prm["L_flat"])
+        es.append(e)
+    a, b = es
+    ra = a.elbo_grad(m_u=None, L_flat=None, group_mask=_lib.GROUP_QU, want_dL_dS=True, **small)
+    rb = b.elbo_grad(m_u=None, L_flat=None, group_mask=_lib.GROUP_QU, want_dL_dS=True, skip_g_L=True, **small)
+    assert ra["elbo"] == rb["elbo"] and np.array_equal(ra["dL_dS"], rb["dL_dS"])
+    with pytest.raises(_lib.HetMOGPError):
+        b.qu_adadelta(1, 0.01, 0.9, 0.9, 1e-4)                  # no gradient of the factor to feed it
+    a.qu_natgrad(0.1)
+    b.qu_natgrad_async(0.1)
+    nb = b.elbo_grad(m_u=None, L_flat=None, group_mask=_lib.GROUP_QU, **small)     # enqueued BEFORE the status is read
+    assert b.qu_natgrad_status() is True
+    na = a.elbo_grad(m_u=None, L_flat=None, group_mask=_lib.GROUP_QU, **small)
+    assert na["elbo"] == nb["elbo"] > ra["elbo"]
+    qa, qb = a.qu_read(), b.qu_read()
+    assert np.array_equal(qa[0], qb[0]) and np.array_equal(qa[1], qb[1])
+    # (refused steps: test_monotone_elbo_headline_mix_M1024_and_rejected_steps)
+    # two pending steps are an error; a synchronous step resolves a pending one first
+    b.qu_natgrad_async(0.05)
+    with pytest.raises(_lib.HetMOGPError):
+        b.qu_natgrad_async(0.05)
+    assert b.qu_natgrad_status() is True
+    for e in es:
+        e.close()
+
+
+def test_facade_natgrad_loop_overlapped_equals_synchronous():
+    """DeviceNatGrad(overlap=True) (asynchronous steps, E-step evaluations without the factor gradient) walks through the same
+    iterates as the synchronous loop while no step is refused."""
+    import hetmogp_amd as H
+    from hetmogp_amd.kern import RBF
+    specs = [("Gaussian", {"sigma": 0.5}), ("Bernoulli", {}), ("Poisson", {})]
+    M, Q, N, B = 128, 2, 4000, 500
+    prm, X, Y = _case(specs, N, M, Q, 105)
+    elbos = []
+    for overlap in (False, True):
+        lik = H.HetLikelihood([H.Gaussian(sigma=0.5), H.Bernoulli(), H.Poisson()])
+        np.random.seed(3)
+        kern = [RBF(1, variance=float(prm["variance"][q]), lengthscale=float(prm["lengthscale"][q])) for q in range(Q)]
+        m = H.SVMOGP(X=X, Y=[y[:, None] for y in Y], Z=prm["Z"][:, :1].copy(), kern_list=kern, likelihood=lik,
+                     Y_metadata=lik.generate_metadata(), batch_size=B)
+        m[".*.lengthscale"].fix()
+        m[".*.kappa"].fix()
+        m.Z.fix()
+        m.stochastic = True
+        opt = m.device_natgrad(gamma=0.1, step_rate=0.01, overlap=overlap)
+        it = iter(opt)
+        tr = []
+        for _ in range(30):
+            next(it)
+            tr.append(float(m._log_marginal_likelihood[0, 0]))
+        it.close()
+        assert opt.rejected == 0
+        elbos.append(tr)
+    assert elbos[0] == elbos[1]
