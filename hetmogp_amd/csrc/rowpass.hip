@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(256) void trsm_diag_kernel(double* __restrict__ V, 
   double* v = V + (valid ? row : 0) * M + j0;
   // [r5] the block's 256 x 32 right-hand sides enter (and leave) through 16-byte accesses in which 16 consecutive lanes cover one
   // row's 256 bytes: one row per lane (32 loads of 8 bytes, lanes 8 KB apart) touched 64 cache lines per instruction
-  // (47 -> see DESIGN 12g ms per strict step at the headline size)
+  // (substitution launches 47 -> 30 ms per strict step at the headline size: DESIGN 12g)
   // (`wide` is decided by the launcher: nb == 32, even M / j0 / batch stride, 16-byte aligned V)
   if (wide) {
 #pragma unroll 4
