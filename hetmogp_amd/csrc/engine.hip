@@ -1409,12 +1409,21 @@ struct hmogp_engine {
       SmallQuadRed qred;
       long long qblocks = 0;
       for (auto& sg : pl) qblocks += quad_blocks(tasks[sg.t].lik, sg.n);
-      const bool quad_multi = small_rows && (int)pl.size() <= HMOGP_QUAD_MULTI && qblocks <= 2048;
-      if (quad_multi) {
-        Scope sc(this, CAT_QUAD, 1);
+      // [r5] ... and on the regular path too where the pool is SHORT (minibatches, rank shares: four launches of a few dozen blocks
+      // + four reductions were 0.17 ms between the forward and the Gram of an 8192-row step) and its likelihood set has an
+      // instantiation of its own; the full-batch sizes keep one launch per task (each with its own register allocation)
+      static const bool qm_regular_env = [] {   // HMOGP_QUAD_MULTI_REGULAR=0: one quadrature launch per task on the regular path
+        const char* e = getenv("HMOGP_QUAD_MULTI_REGULAR");
+        return !(e && e[0] == '0');
+      }();
+      bool quad_multi = small_rows && (int)pl.size() <= HMOGP_QUAD_MULTI && qblocks <= 2048;
+      const bool qm_regular = !small_rows && !strict && qm_regular_env && pl.size() >= 2 && (int)pl.size() <= HMOGP_QUAD_MULTI &&
+                              qblocks <= 2048;
+      if (quad_multi || qm_regular) {
         QuadMulti qm;
         qm.nseg = (int)pl.size(), qm.Q = Q, qm.Df = Df, qm.ldn = ldn;
-        qm.p = vp.d(), qm.c = vc.d(), qm.pt = want_hyper ? vpt.d() : nullptr, qm.ct = want_hyper ? vct.d() : nullptr;
+        const bool row_sl = want_hyper && !col_sl;    // (sl from the row statistics p~, c~: small-model path only)
+        qm.p = vp.d(), qm.c = vc.d(), qm.pt = row_sl ? vpt.d() : nullptr, qm.ct = row_sl ? vct.d() : nullptr;
         qm.Wd = dW.d(), qm.W0d = dsmall.d() + oW0, qm.kapd = dkap.d(), qm.vard = dvar.d(), qm.scale_base = dsmall.d() + oBs;
         qm.quirks = quirks;
         qm.alpha = valpha.d(), qm.beta = vbeta.d(), qm.alpha0 = valpha0.d(), qm.beta0 = vbeta0.d(), qm.partials = quadpart.d();
@@ -1429,7 +1438,14 @@ struct hmogp_engine {
           r.part = quadpart.d() + part, r.nrows = quad_blocks(k.lik, sg.n), r.nscal = k.nscal, r.off = k.offsets.as<long long>();
           part += r.nrows * k.nscal;
         }
-        launch_quad_multi(qm, st);
+        if (quad_multi || quad_multi_specialised(qm)) {
+          Scope sc(this, CAT_QUAD, quad_multi ? 1 : 2);
+          launch_quad_multi(qm, st);
+          if (!quad_multi) launch_reduce_rows_multi(qred, stats.d(), st);   // (small models: summed by small_red_kernel)
+        } else {
+          Scope sc(this, CAT_QUAD, 2 * (int)pl.size());
+          for (auto& sg : pl) quad_segment(sg);
+        }
       } else {
         Scope sc(this, CAT_QUAD, 2 * (int)pl.size());
         for (auto& sg : pl) quad_segment(sg);

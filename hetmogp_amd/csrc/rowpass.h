@@ -98,7 +98,25 @@ struct ColBatch {
   long long sK = 0, sA = 0, sV = 0, sZ = 0, sPart = 0, sWin = 0;
 };
 
+// the quadrature's block partials of every segment of the pool, summed into the bundle by small_red_kernel's extra plane (small models) or by
+// reduce_rows_multi_kernel (regular path)
+struct SmallQuadRed {
+  int nseg = 0;
+  struct {
+    const double* part = nullptr;  // [nrows][nscal]
+    long long nrows = 0;
+    int nscal = 0;
+    const long long* off = nullptr;   // [nscal] slot -> bundle offset (distinct within a segment)
+  } s[8];
+};
+
 long long quad_blocks(int lik, long long N);
+// [r5] is there an instantiation of quad_multi_kernel for exactly this set of likelihoods (other than the all-inclusive one, which
+// runs one wave per SIMD)?
+bool quad_multi_specialised(const QuadMulti& m);
+// the block partials of every segment of a quad_multi launch -> bundle, segment after segment per slot (the order and the per-
+// segment sums of launch_reduce_rows called once per segment: same bits)
+void launch_reduce_rows_multi(const SmallQuadRed& qr, double* dst, hipStream_t s);
 void launch_quad(const QuadArgs& a, hipStream_t s);
 void launch_quad_multi(const QuadMulti& m, hipStream_t s);   // fills blk0 / part0 of the segments; partials laid out segment by segment
 void launch_var_exp(int lik, int J, double param, long long N, const double* y, const double* m, const double* v, double* ve,

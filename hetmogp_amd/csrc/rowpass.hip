@@ -871,6 +871,14 @@ void launch_quad(const QuadArgs& a, hipStream_t s) {
 #undef QKC
 }
 
+bool quad_multi_specialised(const QuadMulti& m) {
+  unsigned need = 0;
+  for (int i = 0; i < m.nseg; ++i) need |= qm_bit(m.seg[i].lik, m.seg[i].dimf);
+  for (unsigned mask : {QM_C1, QM_C5, QM_H4, QM_LIGHT})
+    if ((need & ~mask) == 0) return true;
+  return false;
+}
+
 void launch_quad_multi(const QuadMulti& m_in, hipStream_t s) {
   QuadMulti m = m_in;
   unsigned blocks = 0;
@@ -1224,6 +1232,28 @@ void launch_strict_rowstats(const StrictRows& a, hipStream_t s) {
   if (a.n <= 0) return;
   dim3 grid((unsigned)((a.n + 3) / 4), a.Q);
   DISPATCH_P(a.P, hipLaunchKernelGGL((strict_rowstats_kernel<PP>), grid, dim3(256), 0, s, a));
+}
+
+namespace {
+__global__ __launch_bounds__(256) void reduce_rows_multi_kernel(SmallQuadRed qr, double* __restrict__ dst) {
+  __shared__ double scratch[16];
+  const int k = blockIdx.x;
+  for (int sg = 0; sg < qr.nseg; ++sg) {
+    const auto& g = qr.s[sg];
+    if (k >= g.nscal) continue;              // (block-uniform)
+    double s = 0.0;
+    for (long long b = threadIdx.x; b < g.nrows; b += blockDim.x) s += g.part[b * g.nscal + k];
+    s = block_sum(s, scratch);
+    if (threadIdx.x == 0) dst[g.off[k]] += s;
+    __syncthreads();
+  }
+}
+}  // namespace
+void launch_reduce_rows_multi(const SmallQuadRed& qr, double* dst, hipStream_t s) {
+  int len = 0;
+  for (int i = 0; i < qr.nseg; ++i) len = std::max(len, qr.s[i].nscal);
+  if (len <= 0) return;
+  hipLaunchKernelGGL(reduce_rows_multi_kernel, dim3(len), dim3(256), 0, s, qr, dst);
 }
 
 void launch_reduce_rows(const double* partials, long long nrows, int len, const long long* off, double* dst, bool accumulate,

@@ -1,6 +1,7 @@
 // small_model.h -- the fused small-model kernels (small_model.hip): M <= HMOGP_SMALL_M, one block per latent GP.
 #pragma once
 #include "common.h"
+#include "rowpass.h"   // SmallQuadRed
 
 #define HMOGP_SMALL_M 64
 
@@ -50,16 +51,6 @@ struct SmallF {   // finish_small_kernel
   int* counter = nullptr;          // blocks finished so far (zero between launches: the last block resets it)
 };
 
-// the quadrature's block partials of every segment of the pool, summed into the bundle by small_red_kernel's extra plane
-struct SmallQuadRed {
-  int nseg = 0;
-  struct {
-    const double* part = nullptr;  // [nrows][nscal]
-    long long nrows = 0;
-    int nscal = 0;
-    const long long* off = nullptr;   // [nscal] slot -> bundle offset (distinct within a segment)
-  } s[8];
-};
 
 struct SmallRows {   // small_fwd_kernel / small_bwd_kernel / small_red_kernel: the row pass of one pool of n rows, 64 rows per block
   int M = 0, Q = 0, P = 1, ldz = 0, hyper = 1, want_z = 1;
