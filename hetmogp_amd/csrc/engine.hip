@@ -142,7 +142,12 @@ int gram_ksplit(long long n, int M) {
   const long long ksteps = (n + 15) / 16;
   // enough blocks to fill the chip several times over, and row ranges of at most ~8192 rows (the tiles of one range drift
   // apart as they stream it; shorter ranges keep the shared K^ rows in that XCD's L2)
-  long long want = std::max<long long>((8 * 256 + ntl - 1) / ntl, n / 8192);
+  // [r5] ... but every range costs a slab that reduce_slabs_lower has to stream again (M = 1024, Q = 3: 14 MB per range, 147 us for
+  // 56 of them behind the Gram of an 8192-row minibatch step): short passes take ranges of >= 2048 rows as long as >= 4.5 rounds
+  // of blocks remain (M = 1024: 32 ranges instead of 56 at 4 x 8192 rows: 7.67 -> 7.59 ms per step; M >= 2048 and the
+  // full-batch sizes are unchanged)
+  const long long floor8 = (((4 * 256 + 128 + ntl - 1) / ntl + 7) / 8) * 8;
+  long long want = std::max<long long>(std::max<long long>(floor8, std::min<long long>((8 * 256 + ntl - 1) / ntl, n / 2048)), n / 8192);
   want = std::min<long long>(std::min<long long>(KS_MAX, std::max<long long>(1, ksteps / 32)), want);
   // [r4] short passes (a few thousand rows, small M: BASELINE config 1): a handful of blocks each looping over hundreds of rows
   // is latency-bound (77 us for 3000 rows at M = 50) -- row ranges of 8 k-steps while the grid stays below one block per CU
