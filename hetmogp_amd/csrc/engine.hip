@@ -231,13 +231,15 @@ void jitchol_batched(const double* Kuu, double* Luu, int Q, int M, const double*
 // V <- V Luu^-T Luu^-1 = dpotrs(Luu, V^T)^T for the n rows of V (n x M row-major, in place; batched over Q with strides sV / sL):
 // two BLOCKED TRIANGULAR SOLVES, 32-column diagonal blocks by true substitution (trsm_diag_kernel), the updates between them as
 // GEMMs (alpha = -1, beta = 1) -- backward stable like LAPACK's dtrsm.  Used by the strict q(f) mode and hmogp_potrs_rows.
+// `Vsrc` (optional, same layout as V): the right-hand sides; they reach V either by a copy in front of the solve or -- where every
+// launch of the forward solve is one of the specialised ones -- through the FIRST touch of each column (no copy: 8.4 ms at H).
 void potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL, int M, long long n, int Q, hipStream_t st,
-                        double* Lsym = nullptr) {
+                        double* Lsym = nullptr, const double* Vsrc = nullptr) {
   // C[:, c0:c0+nc] -= V[:, a0:a0+k] op(B)   (op(B) = Luu[c0.., a0..]^T for the forward solve, Luu[a0.., c0..] for the backward one)
   // [r5] `role` 1 offers the update to the specialised 8-wave kernel (gemm_rowpass.hip, C -= A B form: 128-column updates with a
   // k-major B); it falls back to the general kernel by itself.  The forward solve's B is the TRANSPOSE of a block of Luu: with
   // `Lsym` (a Q x M x M scratch) it is read k-major from a mirrored copy of the factor.
-  auto update = [&](int c0, int nc, int a0, int k, const double* B_, int b_kmajor) {
+  auto update_args = [&](int c0, int nc, int a0, int k, const double* B_, int b_kmajor) {
     GemmArgs g;
     g.A = V + a0, g.lda = M, g.a_kmajor = 0, g.sA = sV;
     g.B = B_, g.ldb = M, g.b_kmajor = b_kmajor, g.sB = sL;
@@ -246,6 +248,11 @@ void potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL
     g.alpha = -1.0, g.beta = 1.0;
     g.nbatch = Q;
     g.role = 1;
+    return g;
+  };
+  auto update = [&](int c0, int nc, int a0, int k, const double* B_, int b_kmajor, const double* c_src = nullptr) {
+    GemmArgs g = update_args(c0, nc, a0, k, B_, b_kmajor);
+    g.c_src = c_src ? c_src + c0 : nullptr;
     launch_gemm_rowpass_or_general(g, st);
   };
   const bool sym = Lsym != nullptr && n >= 4096 && sL == (long long)M * M;
@@ -264,16 +271,34 @@ void potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL
   }();
   const bool fuse = fuse_env && trsm_diag_can_fuse(V, sV, M);
   constexpr int NB = 128;
+  // first touch instead of a copy: every 128-column update of the forward solve must be taken by the specialised kernel (the
+  // general one has no separate source) and every block's first substitution launch by the row-coalesced one
+  bool first_touch = false;
+  if (Vsrc) {
+    static const bool ft_env = [] {   // HMOGP_STRICT_FIRST_TOUCH=0: copy the right-hand sides in front of the solve (A/B runs)
+      const char* e = getenv("HMOGP_STRICT_FIRST_TOUCH");
+      return !(e && e[0] == '0');
+    }();
+    first_touch = ft_env && fuse && sym && (M % NB) == 0 && (reinterpret_cast<uintptr_t>(Vsrc) & 15) == 0;
+    for (int J0 = NB; first_touch && J0 < M; J0 += NB) {
+      GemmArgs g = update_args(J0, NB, 0, J0, Lsym + J0, 1);
+      g.c_src = Vsrc + J0;
+      first_touch = gemm_rowpass_would_take(g);
+    }
+    if (!first_touch)
+      for (int q = 0; q < Q; ++q)
+        HIP_TRY(hipMemcpyAsync(V + q * sV, Vsrc + q * sV, sizeof(double) * n * M, hipMemcpyDeviceToDevice, st));
+  }
   for (int J0 = 0; J0 < M; J0 += NB) {                        // X Luu^T = V   (forward over the columns)
     const int J1 = std::min(M, J0 + NB);
     if (J0 > 0) {
-      if (sym) update(J0, J1 - J0, 0, J0, Lsym + J0, 1);       // op(B)[k][j] = Luu[J0 + j][k] = Lsym[k][J0 + j]
+      if (sym) update(J0, J1 - J0, 0, J0, Lsym + J0, 1, first_touch ? Vsrc : nullptr);   // op(B)[k][j] = Luu[J0 + j][k] = Lsym[k][J0 + j]
       else update(J0, J1 - J0, 0, J0, Luu + (long long)J0 * M, 0);
     }
     for (int j0 = J0; j0 < J1; j0 += 32) {
       const int nb = std::min(32, J1 - j0);
       if (fuse) {
-        launch_trsm_diag(0, V, sV, Luu, sL, M, j0, nb, n, Q, st, j0 + 32, J1);
+        launch_trsm_diag(0, V, sV, Luu, sL, M, j0, nb, n, Q, st, j0 + 32, J1, (first_touch && j0 == 0) ? Vsrc : nullptr);
         continue;
       }
       if (j0 > J0) update(j0, nb, J0, j0 - J0, Luu + (long long)j0 * M + J0, 0);
@@ -1220,9 +1245,7 @@ struct hmogp_engine {
       g.role = 1;                       // (no fused statistics: fs_part stays null) the specialised 8-wave forward kernel where the
       launch_gemm_rowpass_or_general(g, st);   // shape allows it -- incl. its triangular-fold pairing for T = A L_q -- else the general one
     };
-    for (int q = 0; q < Q; ++q)
-      HIP_TRY(hipMemcpyAsync(Ah.d() + q * sK, Kh.d() + q * sK, sizeof(double) * n * M, hipMemcpyDeviceToDevice, st));
-    potrs_rows_inplace(Ah.d(), sK, Luu.d(), MM, M, n, Q, st, tmpB.d());   // A = dpotrs(Luu, K^T)^T   (svmogp_inf.py:214-215; tmpB: free here)
+    potrs_rows_inplace(Ah.d(), sK, Luu.d(), MM, M, n, Q, st, tmpB.d(), Kh.d());   // A = dpotrs(Luu, K^T)^T   (svmogp_inf.py:214-215; tmpB: free here)
     // T = A L_q = dtrmm(L_q^T, R)^T (:217) is only ever consumed as rowsum(T .* T) (:218): where the specialised fold kernel takes
     // the product, its epilogue forms that sum from the accumulators and T is neither written nor read back (2 x 19.7 GB at H)
     bool t2_fused = false;
@@ -1359,7 +1382,8 @@ struct hmogp_engine {
         }();
         // (exact-zero windows: the banded Gram is short; the cap was sized for the dense one)
         // (P > 1: more arithmetic per byte -- a block streams 4.8 instead of 6.3 GB/s at P = 2 -- so proportionally more of them)
-        const int cap = cap_env >= 0 ? cap_env : (use_windows ? 0 : (int)(std::min(256.0, std::max(192.0, 131072.0 / std::max(1, M))) * (1.0 + 0.35 * (P - 1))));
+        // (strict q(f): the kernel streams a third matrix -- 256 blocks keep it as long as the Gram of A: 313.5 -> 310.7 ms at H)
+        const int cap = cap_env >= 0 ? cap_env : (use_windows ? 0 : (int)(std::min(256.0, std::max(strict ? 256.0 : 192.0, 131072.0 / std::max(1, M))) * (1.0 + 0.35 * (P - 1))));
         launch_colstats(Kh.d() + off * M, Pt.d() + off * M, a.d(), valpha.d() + off, valpha0.d() + off, vbeta0.d() + off,
                         X + off * P, P, dZ.d(), ldz, rows, M, (int)csplit, want_z, colpart.d() + slab_first * clen, st2, cw, &cb, cap,
                         strict ? Ah.d() + off * M : nullptr, col_sl ? dell.d() : nullptr);

@@ -343,9 +343,11 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
       if (row >= M) continue;
       double* crow = C + (long long)row * g.ldc + j0 + wn * WN + 4 * lk;
       if (g.c_sub) {   // [r5] C -= op(A) op(B): the 128-column updates of the strict mode's blocked triangular solves
+        // (c_src: the columns' FIRST touch reads them from the matrix the solve started from -- no copy of it beforehand)
+        const double* srow = g.c_src ? g.c_src + (long long)batch * g.sC + (long long)row * g.ldc + j0 + wn * WN + 4 * lk : crow;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-          const f64x2 c01 = *reinterpret_cast<const f64x2*>(crow + b * 16), c23 = *reinterpret_cast<const f64x2*>(crow + b * 16 + 2);
+          const f64x2 c01 = *reinterpret_cast<const f64x2*>(srow + b * 16), c23 = *reinterpret_cast<const f64x2*>(srow + b * 16 + 2);
           *reinterpret_cast<f64x2*>(crow + b * 16) = f64x2{c01.x - acc[a][b][0], c01.y - acc[a][b][1]};
           *reinterpret_cast<f64x2*>(crow + b * 16 + 2) = f64x2{c23.x - acc[a][b][2], c23.y - acc[a][b][3]};
         }
@@ -453,6 +455,7 @@ bool gemm_rowpass_eligible(const GemmArgs& g) {
   const bool sub = g.role == 1 && g.alpha == -1.0 && g.beta == 1.0 && !g.fs_part && g.b_tri == 0 && g.store_c;
   if (g.nouter != 1 || (!sub && (g.alpha != 1.0 || g.beta != 0.0)) || g.win || g.M_last || g.N_last || g.K_last || g.a_tri) return false;
   if ((g.lda & 1) || (g.ldb & 1) || (g.ldc & 1) || !aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return false;
+  if (g.c_src && (!sub || !aligned16(g.c_src))) return false;
   if ((g.sA & 1) || (g.sB & 1) || (g.sC & 1) || (g.sSplit & 1)) return false;
   if (g.role == 1)
     return !g.a_kmajor && g.b_kmajor && !g.lower_only && g.ksplit == 1 && !g.kscale && g.b_tri >= 0 && (g.N % BN) == 0 &&

@@ -61,7 +61,7 @@ void launch_strict_rowstats(const StrictRows& a, hipStream_t s);
 // [u0, u1): columns of the same 128-column block that receive the block's right-looking update inside the launch (needs
 // trsm_diag_can_fuse; u0 == u1: none)
 void launch_trsm_diag(int dir, double* V, long long sV, const double* L, long long sL, int M, int j0, int nb, long long n, int Q,
-                      hipStream_t s, int u0 = 0, int u1 = 0);
+                      hipStream_t s, int u0 = 0, int u1 = 0, const double* Vsrc = nullptr);
 bool trsm_diag_can_fuse(const double* V, long long sV, int M);
 
 // [r4] every segment (task x row range) of a pool in one launch -- small models only: the weights are read from device memory

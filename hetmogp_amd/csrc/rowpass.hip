@@ -1079,12 +1079,16 @@ __global__ __launch_bounds__(256) void strict_rowstats_kernel(StrictRows a) {
 // off-diagonal updates between two such steps are plain GEMMs (launch_gemm_f64, alpha = -1, beta = 1).
 template <int DIR>
 __global__ __launch_bounds__(256) void trsm_diag_kernel(double* __restrict__ V, long long sV, const double* __restrict__ L,
-                                                        long long sL, int M, int j0, int nb, long long n, int wide, int u0, int u1) {
+                                                        long long sL, int M, int j0, int nb, long long n, int wide, int u0, int u1,
+                                                        const double* __restrict__ Vsrc) {
   // (the unknowns live in LDS, one column of 256 lanes per unknown -- conflict-free -- and the loops run at run time: with
   //  x[32] in registers and both loops unrolled the compiler hoists all 528 broadcast reads and spills ~1 KB per lane)
   __shared__ double Ls[32][33];
   __shared__ double xs[32][258];
   V += (long long)blockIdx.y * sV, L += (long long)blockIdx.y * sL;
+  // Vsrc (wide launches only): this launch is the FIRST touch of its columns -- x and the updated columns are read from the matrix
+  // the solve started from (same layout as V) and written to V: no copy of that matrix beforehand
+  const double* Vin = Vsrc ? Vsrc + (long long)blockIdx.y * sV : V;
   const int t = threadIdx.x;
   for (int e = t; e < 32 * 32; e += 256) {
     const int r = e >> 5, c = e & 31;
@@ -1102,7 +1106,7 @@ __global__ __launch_bounds__(256) void trsm_diag_kernel(double* __restrict__ V, 
     for (int e = t; e < 256 * 16; e += 256) {
       const int r = e >> 4, ch = e & 15;
       f64x2 v2 = f64x2{0.0, 0.0};
-      if (row0 + r < n) v2 = *reinterpret_cast<const f64x2*>(V + (row0 + r) * M + j0 + 2 * ch);
+      if (row0 + r < n) v2 = *reinterpret_cast<const f64x2*>(Vin + (row0 + r) * M + j0 + 2 * ch);
       xs[2 * ch][r] = v2.x, xs[2 * ch + 1][r] = v2.y;
     }
   } else {
@@ -1185,7 +1189,7 @@ __global__ __launch_bounds__(256) void trsm_diag_kernel(double* __restrict__ V, 
         for (int r = 0; r < 4; ++r) {
           const long long rr = row0 + w * 64 + a * 16 + 4 * r + lk;
 #pragma unroll
-          for (int b = 0; b < 2; ++b) acc[a][b][r] = rr < n ? V[rr * M + g0 + b * 16 + lr] : 0.0;
+          for (int b = 0; b < 2; ++b) acc[a][b][r] = rr < n ? Vin[rr * M + g0 + b * 16 + lr] : 0.0;
         }
       __syncthreads();
 #pragma unroll
@@ -1219,14 +1223,16 @@ bool trsm_diag_can_fuse(const double* V, long long sV, int M) {
   return (M % 32) == 0 && (sV & 1) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0;
 }
 void launch_trsm_diag(int dir, double* V, long long sV, const double* L, long long sL, int M, int j0, int nb, long long n, int Q,
-                      hipStream_t s, int u0, int u1) {
+                      hipStream_t s, int u0, int u1, const double* Vsrc) {
   if (n <= 0 || nb <= 0) return;
   dim3 grid((unsigned)((n + 255) / 256), Q);
   const int wide = (nb == 32 && (M & 1) == 0 && (j0 & 1) == 0 && (sV & 1) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0) ? 1 : 0;
   if (u1 > u0 && (!wide || ((u1 - u0) & 31) || (u0 & 31)))
     throw HipError{hipErrorInvalidValue, "trsm_diag: fused update needs full 32-column blocks and aligned rows", __FILE__, __LINE__};
-  if (dir == 0) hipLaunchKernelGGL((trsm_diag_kernel<0>), grid, dim3(256), 0, s, V, sV, L, sL, M, j0, nb, n, wide, u0, u1);
-  else hipLaunchKernelGGL((trsm_diag_kernel<1>), grid, dim3(256), 0, s, V, sV, L, sL, M, j0, nb, n, wide, u0, u1);
+  if (Vsrc && (!wide || (reinterpret_cast<uintptr_t>(Vsrc) & 15)))
+    throw HipError{hipErrorInvalidValue, "trsm_diag: a first-touch source needs the row-coalesced path", __FILE__, __LINE__};
+  if (dir == 0) hipLaunchKernelGGL((trsm_diag_kernel<0>), grid, dim3(256), 0, s, V, sV, L, sL, M, j0, nb, n, wide, u0, u1, Vsrc);
+  else hipLaunchKernelGGL((trsm_diag_kernel<1>), grid, dim3(256), 0, s, V, sV, L, sL, M, j0, nb, n, wide, u0, u1, Vsrc);
 }
 void launch_strict_rowstats(const StrictRows& a, hipStream_t s) {
   if (a.n <= 0) return;

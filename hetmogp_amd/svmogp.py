@@ -278,7 +278,7 @@ class SVMOGP(object):
                           K_uu -- one repeated evaluation at the switch).  True = HMOGP_CFG_STRICT_QF: q(f) and the row side of the gradients through the reference's solve-based forms
                           (svmogp_inf.py:214-218, :144-161) -- element-wise 1e-5 parity with the reference also where GPy's jitter
                           ladder is taken (K_uu with l >> inducing spacing, e.g. the notebook's own lengthscale 0.05 on
-                          linspace(0, 1, M >= 24)); ~2.7x the step time at the headline size
+                          linspace(0, 1, M >= 24)); ~2.5x the step time at the headline size
         gradients_of_fixed  batch mode only: also evaluate the gradient groups whose parameters are all fixed (the
                           reference always computes them and the optimiser never reads them); default off, which makes
                           the VE steps of `vem_algorithm` skip the hyper-parameter / Z path."""

@@ -118,7 +118,7 @@ typedef struct {
    A (S K_uu^-1 - I) at :144-161); the default path uses the algebraically equal explicit C_q = K_uu^-1 S K_uu^-1 - K_uu^-1, which
    differs from that by ~cond(K_uu) * 2^-53.  Once GPy's jitter ladder is taken (cond ~ 1e7) the default path's g_W / g_kappa / g_Z
    are 1e-4 .. 1e-3 away from the reference's; with this flag the engine follows the reference's forms (two blocked triangular
-   solves against Luu, the Gram of A, ...) and stays within 1e-5 element-wise there (tests/test_gpu_ladder.py).  ~2.7x the step
+   solves against Luu, the Gram of A, ...) and stays within 1e-5 element-wise there (tests/test_gpu_ladder.py).  ~2.5x the step
    time, regular kernels only (no fused small-model path), excludes HMOGP_CFG_EXACT_ZERO_WINDOWS.  bench.py never sets it.   */
 #define HMOGP_CFG_NO_SMALL_PATH 4u /* ABI v5: keep the regular kernels and three streams also for small models (M <= 64 would
                                     * otherwise take the fused small-model kernels, M <= 128 with <= 65536 rows one stream): A/B
