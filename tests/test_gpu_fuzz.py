@@ -58,10 +58,17 @@ def _case(seed, ms, one_d):
     tol = 1e-8 if P == 1 else (2e-7 if out["ill_conditioned"] else 2e-8)
     flagged = bool(out["ill_conditioned"]) and P > 1
     lit = so.elbo_grad_literal(prm, prob, X, Y) if (P > 1 and quirks == "reference" and min(Ns) > 0 and not flagged) else None
+    # [r5] quirk Q10: GPy's expanded-form distances clip |x - z| <~ 1e-8 to exactly 0 and its gradient code drops entries
+    # with r == 0; the oracle follows it, the default path keeps the (true) term E K (x - z) / l^2.  A data point that close to an
+    # inducing point is a ~1 % event per random configuration (tools/soak_parity.py, seed 3117: |x - z| = 4.7e-9, ONE entry of g_Z
+    # 2.8e-7 of its value away, everything else 1e-13): g_Z is then held to 1e-5 like the reference-run fixtures.
+    near = min([float(np.min(np.max(np.abs(x[:, None, :] - prm["Z"][None, :, q * P:(q + 1) * P]), axis=2))) for x in X if len(x) for q in range(Q)] or [1.0])
     for k in KEYS:
         tk = tol if lit is None else min(tol, max(1e-8, 10.0 * rel(want[k], lit[k])))
         if flagged and k == "g_variance":      # (a difference of sums ~100x its size: 3e-7 at cond 3.6e5 in the 300-seed soak)
             tk = 5e-7
+        if k == "g_Z" and near < 1e-7:
+            tk = max(tk, 1e-5)
         assert rel(out[k], want[k]) < tk, (k, M, P, Q, specs, Ns, tk)
     # a minibatch: a random contiguous range of every task with the reference's batch scale (svmogp.py:101-105)
     rb = [int(rng.randint(0, n // 2 + 1)) for n in Ns]
@@ -72,4 +79,4 @@ def _case(seed, ms, one_d):
     wantb = so.elbo_grad_fused(prm, probs, Xs, Ys, batch_scale=bs)
     outb = run(e, prm, bs, row_begin=rb, row_end=re)
     for k in KEYS:
-        assert rel(outb[k], wantb[k]) < tol, ("minibatch", k, M, P, Q, specs, Ns, rb, re)
+        assert rel(outb[k], wantb[k]) < (max(tol, 1e-5) if (k == "g_Z" and near < 1e-7) else tol), ("minibatch", k, M, P, Q, specs, Ns, rb, re)
