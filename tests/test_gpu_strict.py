@@ -49,13 +49,21 @@ LIKS = [("Gaussian", {"sigma": 0.7}), ("Bernoulli", {}), ("Poisson", {}), ("Gamm
         ("Beta", {}), ("Categorical", {"K": 3})]
 
 
+STRICT_MS = [16, 33, 50, 64, 96, 100, 128, 160, 256, 272, 384, 50, 144, 256]
+
+
 @pytest.mark.parametrize("seed", range(14))
 def test_strict_random_configuration_vs_strict_oracle(seed):
+    _strict_case(seed)
+
+
+def _strict_case(seed):
+    """(seeds beyond the suite's 14 cycle through the same inducing counts: tools/soak_parity.py)"""
     from oracle import svmogp_oracle as so
     from hetmogp_amd import _lib
     rng = np.random.RandomState(5000 + seed)
-    M = [16, 33, 50, 64, 96, 100, 128, 160, 256, 272, 384, 50, 144, 256][seed]
-    P = 2 if seed >= 11 else 1
+    M = STRICT_MS[seed % len(STRICT_MS)]
+    P = 2 if (seed % len(STRICT_MS)) >= 11 else 1
     Q = int(rng.randint(1, 4))
     T = int(rng.randint(1, 4))
     specs = [LIKS[i] for i in rng.choice(len(LIKS), T, replace=False)]
@@ -77,6 +85,28 @@ def test_strict_random_configuration_vs_strict_oracle(seed):
     for k in ("elbo", "g_m_u", "g_L_u"):
         assert rel(outb[k], wantb[k]) < 1e-8, ("E-step", k, rel(outb[k], wantb[k]))
     assert not np.any(outb["g_Z"]) and not np.any(outb["g_W"])
+    e.close()
+
+
+@pytest.mark.parametrize("M,Ns", [(256, [3000, 2600]), (512, [2500, 2200, 1900]), (384, [4100, 300])])
+def test_strict_solves_through_the_specialised_update_kernel(M, Ns):
+    """>= 4096 rows and M a multiple of 128: the 128-column updates of the two triangular solves run through rowpass_gemm_kernel<1>
+    (C -= A B, mirrored factor for the forward solve), every column block reaches A by its first touch (no copy of K^), the in-block
+    updates ride in the substitution launches and rowsum(T^2) comes out of the fold kernel -- against the oracle's strict
+    restatement, full gradients and an E-step."""
+    from oracle import svmogp_oracle as so
+    from hetmogp_amd import _lib
+    specs = [("Gaussian", {"sigma": 0.5}), ("Poisson", {}), ("Bernoulli", {})][:len(Ns)]
+    prm, prob, X, Y = synth(7000 + M, specs, Ns, M, 2, 1, (1.0, 1.2))
+    sprob = dict(prob, strict_qf=True)
+    want = so.elbo_grad_fused(prm, sprob, X, Y)
+    e = _engine(prob, X, Y)
+    out = run(e, prm)
+    for k in KEYS:
+        assert rel(out[k], want[k]) < 1e-8, (k, M, rel(out[k], want[k]))
+    qu = run(e, prm, group_mask=_lib.GROUP_QU)
+    for k in ("elbo", "g_m_u", "g_L_u"):
+        assert rel(qu[k], want[k]) < 1e-8, ("E-step", k, rel(qu[k], want[k]))
     e.close()
 
 

@@ -1,5 +1,5 @@
 """Parity soak (not part of the suite): many more seeds of the randomized engine-vs-oracle comparisons than the tests run.
-python tools/soak_parity.py [first_seed] [count]"""
+python tools/soak_parity.py [first_seed] [count] [strict_count]"""
 import os
 import sys
 import traceback
@@ -20,6 +20,15 @@ for s in range(first, first + count):
         bad += 1
         print("default-mode seed", s, "FAILED")
         traceback.print_exc(limit=2)
-for s in range(14):
-    pass
 print("default-mode soak: %d seeds, %d failures" % (count, bad))
+nstrict = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # strict q(f) mode: seeds beyond the suite's 14
+sbad = 0
+for s in range(first, first + nstrict):
+    try:
+        st._strict_case(s)
+    except Exception:                # noqa: BLE001
+        sbad += 1
+        print("strict-mode seed", s, "FAILED")
+        traceback.print_exc(limit=2)
+if nstrict:
+    print("strict-mode soak: %d seeds, %d failures" % (nstrict, sbad))
