@@ -135,9 +135,12 @@ class DeviceNatGrad(DeviceAdadelta):
     step); `gamma_used` records the last accepted value.
     `overlap=True` (default; single-process models): the step is enqueued with `hmogp_qu_natgrad_async` -- committed on the device
     only if it stays inside the cone -- and the loop goes straight on to the next minibatch, whose upload, staging and K_uf
-    construction run beside the step's factorisation chain; the outcome is read after that next evaluation (`step_taken` /
-    `gamma` of an iteration then describe the PREVIOUS E-step's update).  A refused step is not retried on the spot (its gradients
-    are gone): the step size of the following E-steps is halved until one is accepted.  E-step evaluations also skip the
+    construction run beside the step's factorisation chain; the outcome is read after that next evaluation.  The info dict of an
+    E-step therefore carries `gamma=None, step_taken=None, pending=True, gamma_requested=<enqueued step size>` and
+    `last_resolved = {gamma, step_taken}` of the most recent step whose outcome is known (None before the first); `ng.step_taken` /
+    `ng.gamma_used` / `ng.rejected` follow with one E-step of delay.  A refused step is not retried on the spot (its gradients
+    are gone, the minibatch is lost): the step size of the following E-steps is halved until one is accepted.  Callers that
+    monitor gamma / step_taken per iteration as the synchronous loop allows pass `overlap=False`.  E-step evaluations also skip the
     gradient of q(u)'s factor (HMOGP_EVAL_NO_G_L: the update consumes dL/dS and dL/dm only)."""
 
     def __init__(self, model, gamma=0.1, step_rate=1.0, decay=0.9, momentum=0.0, offset=1e-4, gamma_start=1e-5, warmup=20,
@@ -146,6 +149,7 @@ class DeviceNatGrad(DeviceAdadelta):
         self.overlap = bool(overlap) and getattr(model, "_dist", None) is None
         self._backoff = 1.0          # overlap mode: factor on the scheduled step size after refused steps (halved per refusal)
         self._pending = False
+        self._n_resolved = 0         # overlap mode: steps whose outcome has been read back
         self.gamma = float(gamma)
         self.gamma_used = float(gamma)
         self.rejected = 0            # step sizes refused by hmogp_qu_natgrad (halved and retried)
@@ -162,6 +166,7 @@ class DeviceNatGrad(DeviceAdadelta):
         """Outcome of the natural-gradient step that was enqueued in the previous E-step (overlap mode)."""
         taken = eng.qu_natgrad_status()
         self._pending = False
+        self._n_resolved += 1
         self.step_taken = bool(taken)
         if taken:
             self.gamma_used, self._backoff = self._gam_pending, 1.0
@@ -227,8 +232,13 @@ class DeviceNatGrad(DeviceAdadelta):
                         m._qu_host_stale = True
                         m._dirty = True
                         self.n_iter += 1
-                        yield dict(n_iter=self.n_iter, gradient=g, step=self.step, gamma=self.gamma_used,
-                                   step_taken=bool(self.step_taken))
+                        #  the outcome of THIS step is not known yet: gamma / step_taken are None while it is pending;
+                        # `gamma_requested` is what was enqueued, `last_resolved` the most recent step whose outcome has been read
+                        # (None before the first one) -- the synchronous loop's per-iteration meaning is kept by overlap=False
+                        yield dict(n_iter=self.n_iter, gradient=g, step=self.step, gamma=None, step_taken=None, pending=True,
+                                   gamma_requested=self._gam_pending,
+                                   last_resolved=(dict(gamma=self.gamma_used, step_taken=bool(self.step_taken))
+                                                  if self._n_resolved else None))
                         continue
                     self.step_taken = False
                     for _ in range(8):
@@ -262,7 +272,7 @@ class DeviceNatGrad(DeviceAdadelta):
 class SVMOGP(object):
     def __init__(self, X, Y, Z, kern_list, likelihood, Y_metadata, name="SVMOGP", batch_size=None, W_list=None,
                  device=None, chunk_rows=0, exact_zero_windows=False, distributed=False, quirks="reference",
-                 gradients_of_fixed=False, strict_qf=False):
+                 gradients_of_fixed=False, strict_qf=None):
         """The reference's constructor (svmogp.py:17) plus engine options (no reference equivalent):
         device            HIP device ordinal; default: LOCAL_RANK when `distributed`, else 0
         distributed       one process per GPU inside an initialised torch.distributed group: rows are sharded over ranks
@@ -274,11 +284,16 @@ class SVMOGP(object):
                           (nothing to skip at that size, and the small-model kernels need the dense layout)
         quirks            "reference" (default: reproduce the reference's results including its known deviations from the
                           exact gradient) | "exact" (true ELBO gradients) | an int mask of _lib.QUIRK_*
-        strict_qf         False | True | "auto" (default path, switching to the strict one while the engine reports an ill-conditioned
-                          K_uu -- one repeated evaluation at the switch).  True = HMOGP_CFG_STRICT_QF: q(f) and the row side of the gradients through the reference's solve-based forms
-                          (svmogp_inf.py:214-218, :144-161) -- element-wise 1e-5 parity with the reference also where GPy's jitter
-                          ladder is taken (K_uu with l >> inducing spacing, e.g. the notebook's own lengthscale 0.05 on
-                          linspace(0, 1, M >= 24)); ~2.5x the step time at the headline size
+        strict_qf         None (default) | "auto" | True | False.  "auto": evaluate on the default (explicit-inverse) path; the first
+                          evaluation the engine flags as ill-conditioned (hmogp_outputs.cond_est beyond what that path keeps within
+                          element-wise 1e-5 of the reference) is REPEATED through the reference's solve-based forms
+                          (svmogp_inf.py:214-218, :144-161; HMOGP_EVAL_STRICT_QF) and so are the following ones until the estimate
+                          has fallen 10x below the threshold again: the reference's numbers also where GPy's jitter ladder is
+                          taken (K_uu with l >> inducing spacing, e.g. the notebook's own lengthscale 0.05 on
+                          linspace(0, 1, M >= 24)), the ~2x step time paid only while K_uu is ill-conditioned.
+                          None = "auto", except with exact_zero_windows on (the two exclude each other in the engine): then
+                          False, and the ill-conditioned warning says so.  True = every evaluation strict (HMOGP_CFG_STRICT_QF).
+                          False = never (the rounds 1-5 default; a flagged evaluation warns once per model).
         gradients_of_fixed  batch mode only: also evaluate the gradient groups whose parameters are all fixed (the
                           reference always computes them and the optimiser never reads them); default off, which makes
                           the VE steps of `vem_algorithm` skip the hyper-parameter / Z path."""
@@ -307,20 +322,28 @@ class SVMOGP(object):
         self.Ymulti_all = [np.ascontiguousarray(y, dtype=float).reshape(-1, 1) for y in Y]
         T = len(self.Ymulti_all)
         self.Xdim = Z.shape[1]
+        if isinstance(strict_qf, str) and strict_qf != "auto":
+            raise ValueError("strict_qf must be None, False, True or 'auto'")
         if isinstance(exact_zero_windows, str):
             if exact_zero_windows != "auto":
                 raise ValueError("exact_zero_windows must be False, True or 'auto'")
-            exact_zero_windows = bool(self.Xdim == 1 and 128 <= self.num_inducing <= 8192 and
+            # (an explicit strict_qf=True / "auto" wins over windows="auto": the engine has no windowed strict kernels)
+            exact_zero_windows = bool(strict_qf in (None, False) and self.Xdim == 1 and 128 <= self.num_inducing <= 8192 and
                                       all(x.shape[0] < 2 or bool(np.all(np.diff(x[:, 0]) >= 0.0)) for x in self.Xmulti_all))
         self.exact_zero_windows = bool(exact_zero_windows)
-        if isinstance(strict_qf, str) and strict_qf != "auto":
-            raise ValueError("strict_qf must be False, True or 'auto'")
-        # "auto": evaluate on the default path; the first evaluation the engine flags as ill-conditioned (hmogp_outputs.cond_est
-        # beyond what the explicit-inverse path keeps within 1e-5 of the reference) is repeated in the strict mode
-        # (HMOGP_EVAL_STRICT_QF), and so are the following ones until the estimate has fallen 10x below that threshold again
+        # The engine refuses strict q(f) together with exact-zero windows (decide_mode: HMOGP_E_INVALID).  An EXPLICIT request for
+        # both fails here, at construction ("auto" used to construct, train, and raise at the first flagged evaluation);
+        # the default (None) resolves to "auto" without windows and to False with them.
+        if strict_qf is None:
+            strict_qf = False if self.exact_zero_windows else "auto"
+        elif self.exact_zero_windows and (strict_qf is True or strict_qf == "auto"):
+            raise ValueError("strict_qf=%r and exact_zero_windows exclude each other (the solve-based forms have no windowed "
+                             "kernels): choose one" % (strict_qf,))
         self._strict_auto = strict_qf == "auto"
         self._strict_now = False
         self.strict_switches = 0          # how often "auto" went from the default to the strict path
+        self.strict_evaluations = 0       # evaluations that ran through the strict forms (either mode)
+        self.evaluations = 0              # parameters_changed() calls (a repeated evaluation at a switch counts once)
         self.strict_qf = (strict_qf is True) or (not self._strict_auto and bool(strict_qf))
         strict_qf = self.strict_qf
         self._engine = Engine(likelihood.specs(), self.num_latent_funcs, self.num_inducing, self.Xdim, device=device,
@@ -468,13 +491,17 @@ class SVMOGP(object):
         if getattr(self, "_skip_g_L", False) and self._dist is None:
             args["skip_g_L"] = True              # (set by DeviceNatGrad around its E-step evaluations)
         out = evaluate(strict_qf=self._strict_now, **args)
+        ran_strict = self.strict_qf or self._strict_now
         if self._strict_auto:
             if not self._strict_now and out.get("ill_conditioned"):
-                self._strict_now = True                 # (every rank of a sharded model sees the same replicated estimate)
-                self.strict_switches += 1
                 out = evaluate(strict_qf=True, **args)  # the same parameters again, now through the reference's solve-based forms
+                self._strict_now = True                 # (only once that evaluation has succeeded; every rank of a sharded
+                self.strict_switches += 1               #  model sees the same replicated estimate and switches with the others)
+                ran_strict = True
             elif self._strict_now and max(out["cond_est"]) < 50.0:
                 self._strict_now = False                # well-conditioned again (10x below the flag's threshold): default path next time
+        self.evaluations += 1
+        self.strict_evaluations += int(bool(ran_strict))
         self.last = out
         if out.get("ill_conditioned") and not getattr(self, "_warned_ill", False):
             self._warned_ill = True      # (once per model; model.last["cond_est"] / ["ill_conditioned"] are there on every evaluation)
@@ -483,7 +510,9 @@ class SVMOGP(object):
                           "differ from the reference's by more than 1e-5 element-wise%s (DESIGN.md 6a)" % (
                               "strict q(f)" if (self.strict_qf or self._strict_now) else "default (explicit-inverse)",
                               ["%.1e" % c for c in out["cond_est"]], out["rungs"],
-                              "" if (self.strict_qf or self._strict_now) else "; construct the model with strict_qf=True or 'auto'"),
+                              "" if (self.strict_qf or self._strict_now) else
+                              ("; exact_zero_windows is on, which excludes the strict q(f) forms -- construct the model without it"
+                               if self.exact_zero_windows else "; construct the model with strict_qf=True or 'auto'")),
                           RuntimeWarning)
         self._log_marginal_likelihood = np.array([[out["elbo"]]])
         if not on_dev:                            # (device-resident q(u): its gradient stays in HBM for the optimiser)
@@ -606,7 +635,9 @@ class SVMOGP(object):
         """The SVI loop with natural-gradient E-steps on the device-resident q(u) (DeviceNatGrad); None when it does not
         apply (same conditions as `device_adadelta`).  `shuffle` (default on): `shuffle_rows(seed)` first -- natural-gradient
         steps need minibatches that represent the whole data set.  `init="prior"` (default) starts q(u) at p(u)
-        (`init_q_u_to_prior`); None keeps the model's current q(u)."""
+        (`init_q_u_to_prior`); None keeps the model's current q(u).  `overlap=True` (default since round 5) enqueues the E-step's
+        update and reads its outcome one evaluation later: the yielded info has `gamma=None, step_taken=None, pending=True` for
+        that step (see DeviceNatGrad); pass `overlap=False` for the synchronous loop's per-iteration `gamma` / `step_taken`."""
         if not self.stochastic or self.q_u_means.is_fixed or self.q_u_chols.is_fixed:
             return None
         if shuffle:                 # (distributed: every rank holds all rows and the same seed gives the same permutation)

@@ -178,3 +178,29 @@ def test_strict_flag_exclusions():
     from hetmogp_amd._lib import InvalidArgument
     with pytest.raises(InvalidArgument):
         Engine([("Gaussian", {"sigma": 0.5})], 1, 128, 1, strict_qf=True, exact_zero_windows=True)
+
+
+def test_unknown_eval_flag_bits_are_refused():
+    """[r6] ADVICE r5: hmogp_params.eval_flags (ABI v6/v7) was masked for its two known bits; a caller that fills a v5-sized struct
+    without zeroing the new field could switch the strict mode on, or get a zero-filled g_L_u, with no error.  Unknown bits now
+    return HMOGP_E_INVALID like those of hmogp_config.flags / quirks; the two defined bits still pass."""
+    import ctypes as C
+    from hetmogp_amd import _lib
+    from hetmogp_amd.engine import Engine
+    from hetmogp_amd.synthetic import make_case
+    specs = [("Gaussian", {"sigma": 0.5})]
+    prm, X, Y = make_case(specs, [600], M=32, Q=1, P=1, seed=3)
+    e = Engine(specs, 1, 32, 1)
+    e.set_data(X, Y)
+    good = e.elbo_grad(**prm)["elbo"]
+    p, keep = e._params(**prm)
+    c, o = e._outputs()
+    for bad in (4, 0x80000000, 1 | 8):
+        p.eval_flags = bad
+        rc = _lib.lib.hmogp_elbo_grad(e._h, C.byref(p), C.byref(c))
+        assert rc == _lib.E_INVALID, (bad, rc)
+        assert b"eval_flags" in _lib.lib.hmogp_last_error(e._h)
+    p.eval_flags = _lib.EVAL_STRICT_QF | _lib.EVAL_NO_G_L
+    assert _lib.lib.hmogp_elbo_grad(e._h, C.byref(p), C.byref(c)) == 0
+    assert abs(e.elbo_grad(**prm)["elbo"] - good) <= 1e-12 * abs(good)      # and the engine is still usable afterwards
+    e.close()

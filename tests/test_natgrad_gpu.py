@@ -182,11 +182,22 @@ def test_facade_natgrad_loop_overlapped_equals_synchronous():
         m.stochastic = True
         opt = m.device_natgrad(gamma=0.1, step_rate=0.01, overlap=overlap)
         it = iter(opt)
-        tr = []
+        tr, infos = [], []
         for _ in range(30):
-            next(it)
+            infos.append(next(it))
             tr.append(float(m._log_marginal_likelihood[0, 0]))
         it.close()
         assert opt.rejected == 0
         elbos.append(tr)
+        # [r6] ADVICE r5: what an E-step's info dict says about its OWN update.  Synchronous: the outcome; overlapped: pending
+        # (gamma / step_taken None, the enqueued step size under gamma_requested, the last READ outcome under last_resolved --
+        # None on the very first E-step, where nothing has been resolved yet)
+        e_infos = [i for i in infos if i["step_taken"] is not None or i.get("pending")]
+        assert len(e_infos) >= 20
+        if overlap:
+            assert all(i["gamma"] is None and i["step_taken"] is None and i["pending"] and i["gamma_requested"] > 0 for i in e_infos)
+            assert e_infos[0]["last_resolved"] is None
+            assert e_infos[2]["last_resolved"] == dict(gamma=e_infos[1]["gamma_requested"], step_taken=True)
+        else:
+            assert all(i["step_taken"] is True and i["gamma"] > 0 and "pending" not in i for i in e_infos)
     assert elbos[0] == elbos[1]
