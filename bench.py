@@ -152,16 +152,9 @@ def main():
         hdist.force_collectives(True)      # the negotiation's flag reductions are issued for real, also with one rank
     reducer = hdist.StatsReducer(eng, device=local_rank, single_rank_exchange=args.force_dist) if distm else None
 
-    def step(red=reducer):
-        # world > 1, default: the engine holds its own RCCL communicator ("native") and hmogp_elbo_grad_sharded IS the step
-        # (row pass -> pack / ncclAllReduce / unpack on the engine's stream -> replicated finish, one host sync at the end)
-        if not distm:
-            return eng.elbo_grad(**prm)
-        if red.mode == "native":
-            return eng.elbo_grad(sharded=True, **prm)
-        eng.step_begin(**prm)
-        red()
-        return eng.step_finish()
+    # (the step closure, the timed loop, the exchange-mode sweep and the teardown live in hetmogp_amd/dist.py so that the CPU suite
+    #  runs THIS control flow under gloo at world size 8 with a stand-in engine: tests/test_dist_cpu.py::test_world8_bench_control_flow)
+    step = hdist.make_step(eng, prm, reducer, distm)
 
     def fence():
         if distm:
@@ -184,66 +177,24 @@ def main():
         out = step()
     fence()
     guard.__exit__()
-    if reducer is not None:
-        reducer.total_ms, reducer.n_calls = 0.0, 0
-    t0 = time.perf_counter()
-    cat_ms, cat_n, step_walls = {}, {}, []
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        out = step()
-        step_walls.append(1e3 * (time.perf_counter() - ts))
-        ms, nl = eng.timings()              # HIP-event spans on the engine's streams, per kernel family
-        for k in ms:
-            cat_ms[k] = cat_ms.get(k, 0.0) + ms[k]
-            cat_n[k] = cat_n.get(k, 0) + nl[k]
-    tf = time.perf_counter()
-    fence()
-    elapsed = time.perf_counter() - t0
-    closing_fence_ms = 1e3 * (time.perf_counter() - tf)
+    elapsed, cat_ms, cat_n, step_walls, closing_fence_ms, out = hdist.timed_steps(step, eng, args.steps, fence, reducer)
     # (the collector stays off for the other timed loops of this process; they collect explicitly between workloads)
     rows_all = [rows_rank]
+    fwd_rank = [[cat_ms.get("forward_gemm", 0.0), float(cat_n.get("forward_gemm", 0)), float(rows_rank)]]
     if distm:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        gathered = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
-        dist.all_gather(gathered, torch.tensor([float(rows_rank)], dtype=torch.float64, device="cuda"))
-        rows_all = [int(g.item()) for g in gathered]
+        elapsed = hdist.max_over_ranks(elapsed, local_rank)
+        fwd_rank = hdist.gather_floats(fwd_rank[0], world, local_rank)
+        rows_all = [int(r[2]) for r in fwd_rank]
     if not np.isfinite(out["elbo"]):
         raise SystemExit("bench.py: non-finite ELBO")
 
     # ---- N > 1: the same steps with the other exchange modes (reported, not `value`) ------------------------------------
     exchange_modes, repl_all = {}, None
     if distm:
-        def timed_mode(red):
-            for _ in range(max(1, args.warmup)):
-                step(red)
-            fence()
-            t0m, ex = time.perf_counter(), 0.0
-            red.total_ms, red.n_calls = 0.0, 0
-            for _ in range(args.steps):
-                step(red)
-                ex += eng.timings()[0]["exchange"]
-            fence()
-            el = torch.tensor([time.perf_counter() - t0m], dtype=torch.float64, device="cuda")
-            dist.all_reduce(el, op=dist.ReduceOp.MAX)
-            exch = ex / args.steps if red.mode == "native" else red.total_ms / max(red.n_calls, 1)
-            return {"ms_per_step": 1e3 * float(el.item()) / args.steps, "exchange_ms_per_step": exch}
-        native_ms = cat_ms.get("exchange", 0.0) / args.steps
-        exchange_modes[reducer.mode] = {"ms_per_step": 1e3 * elapsed / args.steps,
-                                        "exchange_ms_per_step": native_ms if reducer.mode == "native" else
-                                        reducer.total_ms / max(reducer.n_calls, 1)}
-        for alt in ("native", "device"):
-            if alt in exchange_modes:
-                continue
-            try:
-                red_alt = hdist.StatsReducer(eng, device=local_rank, mode=alt, single_rank_exchange=args.force_dist)
-            except RuntimeError:            # not available on every rank (agreed collectively): nothing to time
-                continue
-            exchange_modes[alt] = timed_mode(red_alt)
-        gathered = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
-        dist.all_gather(gathered, torch.tensor([cat_ms["mxm_algebra"] / args.steps], dtype=torch.float64, device="cuda"))
-        repl_all = [float(g.item()) for g in gathered]
+        exchange_modes = hdist.exchange_mode_sweep(
+            eng, step, reducer, args.steps, args.warmup, fence, local_rank, elapsed, cat_ms,
+            make_reducer=lambda alt: hdist.StatsReducer(eng, device=local_rank, mode=alt, single_rank_exchange=args.force_dist))
+        repl_all = [r[0] for r in hdist.gather_floats([cat_ms["mxm_algebra"] / args.steps], world, local_rank)]
 
     if rank == 0:
         pairs_rows = rows_rank * Q                               # (row, latent) pairs per step on this rank
@@ -307,6 +258,16 @@ def main():
             # "native" = ncclAllReduce issued by the library on the engine's stream (device time, HIP events around pack +
             # all-reduce + unpack); "device" = torch.distributed on the aliased wire buffer (host wall time incl. its syncs)
             line["allreduce_ms_per_step"] = exchange_modes[reducer.mode]["exchange_ms_per_step"]
+            line["allreduce_frac_of_step"] = line["allreduce_ms_per_step"] / line["ms_per_step"]
+            # the dominant kernel's roofline on EVERY rank (its own rows, its own HIP-event launch durations): a straggler shows here
+            line["roofline_per_rank"] = [
+                {"rank": r, "rows": int(rows_r), "launches": int(n_r), "avg_launch_ms": ms_r / max(n_r, 1.0),
+                 "achieved": (2.0 * rows_r * Q * M * M * args.steps / (ms_r / 1e3) / 1e12) if ms_r > 0 else 0.0,
+                 "frac": (2.0 * rows_r * Q * M * M * args.steps / (ms_r / 1e3) / 1e12 / PEAK_FP64_MFMA_TFLOPS) if ms_r > 0 else 0.0,
+                 "unit": "TFLOP/s", "bound": "mfma", "peak": PEAK_FP64_MFMA_TFLOPS}
+                for r, (ms_r, n_r, rows_r) in enumerate(fwd_rank)]
+            line["replicated_frac_of_step"] = line["replicated_ms"] / line["ms_per_step"]
+            line["n_gt_1_rccl_executed_before_this_run"] = False   # README: no N > 1 RCCL step had run anywhere before the driver's
             line["allreduce_bytes"] = 8 * int(eng.wire_buffer()[1])
             line["reducer_mode"] = reducer.mode
             line["exchange_modes_ms_per_step"] = exchange_modes
@@ -329,10 +290,7 @@ def main():
         print(json.dumps(line))
         sys.stdout.flush()
     if distm:
-        if reducer is not None:
-            reducer.close()                 # ncclCommDestroy of the library's own communicator, on every rank, before torch's
-        dist.barrier()
-        dist.destroy_process_group()
+        hdist.teardown(reducer)             # ncclCommDestroy of the library's own communicator, on every rank, before torch's
 
 
 def kuf_alone(N, M, Q, in_step_gbs, in_step_ms, in_step_launches):

@@ -258,3 +258,113 @@ def sharded_elbo_grad(engine, reducer, rank, world, row_begin=None, row_end=None
     if reducer is not None:
         reducer()
     return engine.step_finish(want_dL_dS=want_dL_dS)
+
+
+# ---- the control flow of `bench.py --gpus N` (kept here so that the CPU tests can run the SAME code under gloo with a stand-in engine:
+# ---- tests/test_dist_cpu.py::test_world8_bench_control_flow -- N > 1 has never executed on hardware) -------------
+def _tensor_device(device):
+    import torch
+    return torch.device("cpu") if device is None else torch.device("cuda", int(device))
+
+
+def max_over_ranks(value, device=None):
+    """MAX all-reduce of one float64 (the bench contract's max-over-ranks timing).  `device=None`: CPU tensors (gloo)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_tensor_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_floats(values, world, device=None):
+    """all_gather of a short float64 vector: returns a list (one entry per rank) of lists."""
+    import torch
+    import torch.distributed as dist
+    dev = _tensor_device(device)
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    return [[float(x) for x in g.cpu().tolist()] for g in got]
+
+
+def make_step(eng, prm, reducer, distributed):
+    """One bench step as a closure.  world > 1, default: the engine holds its own RCCL communicator ("native") and
+    hmogp_elbo_grad_sharded IS the step (row pass -> pack / ncclAllReduce / unpack on the engine's stream -> replicated finish, one
+    host sync at the end); the other modes go begin -> reducer -> finish."""
+    def step(red=reducer):
+        if not distributed:
+            return eng.elbo_grad(**prm)
+        if red.mode == "native":
+            return eng.elbo_grad(sharded=True, **prm)
+        eng.step_begin(**prm)
+        red()
+        return eng.step_finish()
+    return step
+
+
+def timed_steps(step, eng, steps, fence, reducer=None):
+    """EXACTLY `steps` steps between two fences (barrier + device synchronisation, supplied by the caller); per-family kernel
+    milliseconds (HIP-event spans of the engine) summed over them.  Returns (elapsed_s_this_rank, cat_ms, cat_n, step_walls,
+    closing_fence_ms, last_out)."""
+    import time
+    if reducer is not None:
+        reducer.total_ms, reducer.n_calls = 0.0, 0
+    t0 = time.perf_counter()
+    cat_ms, cat_n, step_walls, out = {}, {}, [], None
+    for _ in range(steps):
+        ts = time.perf_counter()
+        out = step()
+        step_walls.append(1e3 * (time.perf_counter() - ts))
+        ms, nl = eng.timings()
+        for k in ms:
+            cat_ms[k] = cat_ms.get(k, 0.0) + ms[k]
+            cat_n[k] = cat_n.get(k, 0) + nl[k]
+    tf = time.perf_counter()
+    fence()
+    elapsed = time.perf_counter() - t0
+    return elapsed, cat_ms, cat_n, step_walls, 1e3 * (time.perf_counter() - tf), out
+
+
+def exchange_mode_sweep(eng, step, reducer, steps, warmup, fence, device, elapsed, cat_ms, alternatives=("native", "device"),
+                        make_reducer=None):
+    """N > 1: the same steps with the OTHER exchange modes every rank can do (reported, never `value`).  Every rank walks the same
+    list in the same order; a mode that is not available on every rank is skipped on every rank (StatsReducer agrees collectively
+    and raises RuntimeError everywhere).  Returns {mode: {"ms_per_step", "exchange_ms_per_step"}} including the default mode's entry
+    computed from the main timed loop (`elapsed` = max over ranks, seconds; `cat_ms` = this rank's kernel-family sums)."""
+    import time
+    modes = {}
+    native_ms = cat_ms.get("exchange", 0.0) / steps
+    modes[reducer.mode] = {"ms_per_step": 1e3 * elapsed / steps,
+                           "exchange_ms_per_step": native_ms if reducer.mode == "native" else reducer.total_ms / max(reducer.n_calls, 1)}
+    for alt in alternatives:
+        if alt in modes:
+            continue
+        try:
+            red_alt = make_reducer(alt)
+        except RuntimeError:            # not available on every rank (agreed collectively): nothing to time
+            continue
+        for _ in range(max(1, warmup)):
+            step(red_alt)
+        fence()
+        t0, ex = time.perf_counter(), 0.0
+        red_alt.total_ms, red_alt.n_calls = 0.0, 0
+        for _ in range(steps):
+            step(red_alt)
+            ex += eng.timings()[0].get("exchange", 0.0)
+        fence()
+        el = max_over_ranks(time.perf_counter() - t0, device)
+        exch = ex / steps if red_alt.mode == "native" else red_alt.total_ms / max(red_alt.n_calls, 1)
+        modes[alt] = {"ms_per_step": 1e3 * el / steps, "exchange_ms_per_step": exch}
+        if red_alt.owns_comm:           # (a communicator created for this pass only)
+            red_alt.close()
+    return modes
+
+
+def teardown(reducer):
+    """Teardown order of a distributed run: the library's own communicator first (ncclCommDestroy on every rank), then a barrier,
+    then torch's process group."""
+    import torch.distributed as dist
+    if reducer is not None:
+        reducer.close()
+    dist.barrier()
+    dist.destroy_process_group()

@@ -273,3 +273,178 @@ def test_one_rank_dry_run_switches():
     assert r["native"] == ("native", (1, 0), 1)
     assert r["host"][0] == "host" and r["host"][1] == 1 and np.array_equal(r["host"][2], np.arange(10) * 1.0)
     assert r["default_skips"] == ("host", 0)
+
+
+# ---- [r6] world size 8: the control flow of `bench.py --gpus 8` under gloo -------------------------------------
+# bench.py's step closure, timed loop, max-over-ranks timing, per-rank gathers, exchange-mode sweep and teardown are functions of
+# hetmogp_amd/dist.py (make_step / timed_steps / max_over_ranks / gather_floats / exchange_mode_sweep / teardown); bench.py calls them
+# with the HIP engine and RCCL, this test with a stand-in engine whose row pass / finish are the oracle's and gloo.  What it pins:
+# shard_ranges on C4's shape (8 tasks, 8 likelihood families, Q = 4; ragged tasks, one with FEWER rows than ranks), the
+# collective-safe negotiation at 8 ranks, that every rank walks the same mode list, results == the single-process oracle on every
+# rank, and the teardown order (library communicator -> barrier -> process group).  N > 1 RCCL itself has never executed anywhere.
+C4_SPECS = [("HetGaussian", {}), ("Categorical", {"K": 5}), ("Beta", {}), ("Exponential", {}), ("Gaussian", {"sigma": 0.5}),
+            ("Bernoulli", {}), ("Poisson", {}), ("Gamma", {})]
+C4_ROWS = [13, 9, 8, 5, 16, 11, 21, 10]          # rows per task: none divisible by 8 but two, one shorter than the world
+
+
+def _load_by_path(name, rel):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, *rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class _OracleEngine(object):
+    """The engine surface bench.py's distributed branch touches, played by the oracle (local_stats = the same additive bundle the HIP
+    row pass produces, finish = the replicated post-processing).  The wire format here is the plain bundle."""
+
+    def __init__(self, so, hd, prob, X, Y, rank, world, log):
+        self.so, self.hd, self.prob, self.rank, self.world, self.log = so, hd, prob, rank, world, log
+        self.X, self.Y = X, Y                      # THIS rank's rows only, as bench.py uploads them
+        self.T, self.N = prob["T"], [x.shape[0] for x in X]
+        self.comm, self.bundle, self.u, self.prm = (0, -1), None, None, None
+        self._ms = {}
+
+    # -- evaluation
+    def step_begin(self, **prm):
+        import time
+        t0 = time.perf_counter()
+        self.prm = prm
+        self.u = self.so.u_algebra(prm, self.prob)
+        t1 = time.perf_counter()
+        self.bundle, _ = self.so.local_stats(prm, self.prob, self.u, self.X, self.Y, None)
+        self._ms = {"mxm_algebra": 1e3 * (t1 - t0), "forward_gemm": 1e3 * (time.perf_counter() - t1), "exchange": 0.0}
+
+    def step_finish(self, want_dL_dS=False):
+        return self.so.finish(self.prm, self.prob, self.u, self.bundle)
+
+    def step_exchange(self):                       # "native": stands in for pack -> ncclAllReduce -> unpack on the engine's stream
+        import time
+        assert self.comm == (self.world, self.rank), "exchange without a communicator spanning the group"
+        t0 = time.perf_counter()
+        self.bundle = self.hd.all_reduce_host(self.bundle)
+        self._ms["exchange"] = 1e3 * (time.perf_counter() - t0)
+
+    def elbo_grad(self, sharded=False, **prm):
+        self.step_begin(**prm)
+        if sharded:
+            self.step_exchange()
+        return self.step_finish()
+
+    def timings(self):
+        return dict(self._ms), {k: 1 for k in self._ms}
+
+    # -- exchange surface
+    def wire_buffer(self):
+        return 0, self.so.stats_layout(self.prob)["size"]
+
+    def wire_pack(self):
+        pass
+
+    def wire_unpack(self):
+        pass
+
+    def wire_read(self):
+        return self.bundle.copy()
+
+    def wire_write(self, v):
+        self.bundle = np.array(v, dtype=float)
+
+    def comm_info(self):
+        return self.comm
+
+    def comm_init(self, nranks, rank, uid):
+        assert len(uid) == 128
+        self.comm = (nranks, rank)
+        self.log.append("comm_init")
+
+    def comm_destroy(self):
+        self.comm = (0, -1)
+        self.log.append("comm_destroy")
+
+
+def _world8_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    hd = _load_by_path("hm_dist", ("hetmogp_amd", "dist.py"))
+    syn = _load_by_path("hm_syn", ("hetmogp_amd", "synthetic.py"))
+    from oracle import svmogp_oracle as so
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T, Q, M, P = len(C4_SPECS), 4, 12, 1
+    prm, X, Y = syn.make_case(C4_SPECS, C4_ROWS, M=M, Q=Q, P=P, seed=20260934)
+    prob = so.make_problem(C4_SPECS, Q, M, P)
+    rb, re = hd.shard_ranges([0] * T, C4_ROWS, rank, world)
+    log = []
+    eng = _OracleEngine(so, hd, prob, [x[b:e] for x, b, e in zip(X, rb, re)], [y[b:e] for y, b, e in zip(Y, rb, re)], rank, world, log)
+    rows_rank = sum(e - b for b, e in zip(rb, re))
+    api = (lambda: True, lambda: bytes(range(128)))
+    reducer = hd.StatsReducer(eng)                                 # gloo: "host" is the only default candidate
+    step = hd.make_step(eng, prm, reducer, True)
+
+    def fence():
+        dist.barrier()
+    steps, warmup = 2, 1
+    for _ in range(warmup):
+        out = step()
+    fence()
+    elapsed, cat_ms, cat_n, walls, closing, out = hd.timed_steps(step, eng, steps, fence, reducer)
+    mine = elapsed
+    elapsed = hd.max_over_ranks(elapsed)
+    fwd_rank = hd.gather_floats([cat_ms["forward_gemm"], float(cat_n["forward_gemm"]), float(rows_rank)], world)
+    modes = hd.exchange_mode_sweep(eng, step, reducer, steps, warmup, fence, None, elapsed, cat_ms,
+                                   make_reducer=lambda alt: hd.StatsReducer(eng, mode=alt, native_api=api))
+    repl = [r[0] for r in hd.gather_floats([cat_ms["mxm_algebra"] / steps], world)]
+    out_native = hd.make_step(eng, prm, None, False)()             # (plain single-rank call on this rank's rows: differs from the sum)
+    log.append("before_teardown")
+    hd.teardown(reducer)
+    log.append("group_alive=%s" % dist.is_initialized())
+    q.put((rank, dict(elbo=float(out["elbo"]), g_Z=np.asarray(out["g_Z"]), g_W=np.asarray(out["g_W"]), g_L_u=np.asarray(out["g_L_u"]),
+                      rows=[int(r[2]) for r in fwd_rank], launches=[int(r[1]) for r in fwd_rank], modes=sorted(modes),
+                      mode_ms=modes, repl_n=len(repl), elapsed_max=elapsed, elapsed_mine=mine, n_calls=reducer.n_calls,
+                      local_only_elbo=float(out_native["elbo"]), log=log, rb=rb, re=re, n_walls=len(walls))))
+
+
+@pytest.mark.timeout(600)
+def test_world8_bench_control_flow():
+    import torch.multiprocessing as mp
+    syn = _load_by_path("hm_syn_parent", ("hetmogp_amd", "synthetic.py"))
+    from oracle import svmogp_oracle as so
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=500) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    T, Q, M, P = len(C4_SPECS), 4, 12, 1
+    prm, X, Y = syn.make_case(C4_SPECS, C4_ROWS, M=M, Q=Q, P=P, seed=20260934)
+    want = so.elbo_grad_fused(prm, so.make_problem(C4_SPECS, Q, M, P), X, Y)
+    # the shards tile every task exactly, also the 5-row task (three ranks hold none of its rows)
+    for t in range(T):
+        cuts = [(res[r]["rb"][t], res[r]["re"][t]) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == C4_ROWS[t] and all(cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
+    assert sum(1 for r in range(world) if res[r]["re"][3] == res[r]["rb"][3]) == 3
+    for r in range(world):
+        o = res[r]
+        assert abs(o["elbo"] - want["elbo"]) <= 1e-10 * abs(want["elbo"]), (r, o["elbo"], want["elbo"])
+        for k in ("g_Z", "g_W", "g_L_u"):
+            assert np.max(np.abs(o[k] - want[k])) <= 1e-9 * np.max(np.abs(want[k])), (r, k)
+        assert o["rows"] == [sum(res[k]["re"][t] - res[k]["rb"][t] for t in range(T)) for k in range(world)] and sum(o["rows"]) == sum(C4_ROWS)
+        assert o["launches"] == [2] * world and o["n_walls"] == 2 and o["repl_n"] == world
+        assert o["modes"] == ["host", "native"]                       # same list on every rank: "device" is refused collectively under gloo
+        assert o["elapsed_max"] >= o["elapsed_mine"] - 1e-12 and o["elapsed_max"] == res[0]["elapsed_max"]
+        assert o["n_calls"] == 2                                      # the timed loop reset the counters after the warm-up
+        assert abs(o["local_only_elbo"] - want["elbo"]) > 1e-6 * abs(want["elbo"])   # (a rank alone sees an eighth of the rows)
+        # teardown order: the sweep's "native" communicator was created and destroyed by the sweep itself; nothing is destroyed after
+        # the process group
+        assert o["log"] == ["comm_init", "comm_destroy", "before_teardown", "group_alive=False"], o["log"]
+        assert all(v["ms_per_step"] > 0 and v["exchange_ms_per_step"] >= 0 for v in o["mode_ms"].values())
+    assert len({res[r]["elbo"] for r in range(world)}) == 1           # bit-identical replicas (same reduction order on every rank)
