@@ -671,6 +671,7 @@ def other_configs(args):
     eng.close()
     # C3 -- SVI streaming: N_all = 1M rows per task, contiguous minibatches of 8192 rows per task and step
     res.append(svi_config(args, K))
+    res.append(vem_c1_notebook(args))
     # C4 -- the share of ONE of 8 ranks: 125 000 of 1M rows of each of the 8 tasks, Q = 4, Df = 14
     c4 = [("HetGaussian", {}), ("Categorical", {"K": 5}), ("Beta", {}), ("Exponential", {}), ("Gaussian", {"sigma": 0.5}),
           ("Bernoulli", {}), ("Poisson", {}), ("Gamma", {})]
@@ -728,6 +729,53 @@ def other_configs(args):
                         "solves with true 32-column substitution steps, their in-block updates fused into the substitution launches)"})
     eng.close()
     return res
+
+
+def vem_c1_notebook(args):
+    """[r6] VERDICT r5 item 2(i): the batch VEM driver a user of the reference runs (util.py:284-315: alternating L-BFGS-B over
+    q(u) and over the hyper-parameters, <= 100 iterations each) on BASELINE config 1's shape with the NOTEBOOK's own
+    hyper-parameters (demo.ipynb cell 7: lengthscale 0.05, variance 0.5, Z = linspace(0, 1, M)) -- l / h = 2.45, cond(K_uu) ~ 1e12:
+    the regime in which GPy's jitchol decides the numbers.  Model built as the north-star spells it; strict_qf='auto' by default."""
+    import warnings
+    import numpy as np
+    import hetmogp_amd as H
+    from hetmogp_amd.kern import RBF
+    from hetmogp_amd.synthetic import make_case
+    c1 = [("HetGaussian", {}), ("Bernoulli", {}), ("Categorical", {"K": 3})]
+    N, M, Q, P, iters = 1000, 50, 2, 1, 5
+    prm, X, Y = make_case(c1, [N] * 3, M=M, Q=Q, P=P, seed=20260930)
+    lik = H.HetLikelihood([H.HetGaussian(), H.Bernoulli(), H.Categorical(K=3)])
+    np.random.seed(7)
+    kern = [RBF(P, variance=0.5, lengthscale=0.05) for _ in range(Q)]
+    Z = np.linspace(0.0, 1.0, M)[:, None]
+    with warnings.catch_warnings(record=True) as wlog:
+        warnings.simplefilter("always")
+        guard = _StdoutToStderr()
+        guard.__enter__()
+        try:
+            model = H.HetMOGP(X, [y.reshape(-1, 1) for y in Y], Z, kern, lik, lik.generate_metadata())
+            e0 = float(model.log_likelihood()[0, 0])
+            ev0, sev0 = model.evaluations, model.strict_evaluations
+            t0 = time.perf_counter()
+            H.vem_algorithm(model, stochastic=False, vem_iters=iters)
+            wall = time.perf_counter() - t0
+        finally:
+            guard.__exit__()
+    ev, sev = model.evaluations - ev0, model.strict_evaluations - sev0
+    return {"workload": "T1: batch VEM trajectory, C1 shape [HetGaussian,Bernoulli,Categorical(3)], N_t=1000, M=50, Q=2 with the "
+                        "notebook's hyper-parameters (lengthscale 0.05 on linspace(0,1,50), variance 0.5)",
+            "driver": "hetmogp_amd.vem_algorithm(model, stochastic=False, vem_iters=5) on HetMOGP(X, Y, Z, kern_list, likelihood, "
+                      "Y_metadata) -- util.py:284-315; constructor default strict_qf='auto'",
+            "vem_iters": iters, "wall_s": wall, "evaluations": ev, "ms_per_evaluation": 1e3 * wall / max(ev, 1),
+            "ms_per_step": 1e3 * wall / max(ev, 1), "steps_per_s": ev / wall,
+            "strict_evaluations": sev, "strict_share": sev / float(max(ev, 1)), "strict_switches": int(model.strict_switches),
+            "strict_now_at_end": bool(model._strict_now), "elbo_start": e0, "elbo_end": float(model.log_likelihood()[0, 0]),
+            "cond_est_last": [float(c) for c in model.last["cond_est"]], "rungs_last": [int(r) for r in model.last["rungs"]],
+            "ill_conditioned_warnings": len([w for w in wlog if "ill-conditioned" in str(w.message)]),
+            "note": "evaluations = parameters_changed() calls of the L-BFGS-B line searches (a repeated evaluation at a default -> strict "
+                    "switch counts once); strict evaluations run the regular kernels (solve-based forms), the others the fused "
+                    "small-model path; lengthscale stays frozen in the first E-step only (util.py:285), so the optimiser may leave "
+                    "the ill-conditioned regime by itself"}
 
 
 def svi_config(args, K):
@@ -813,7 +861,62 @@ def svi_config(args, K):
     ng_ms = 1e3 * (time.perf_counter() - t0) / n_it
     ng_elbo = float(model2._log_marginal_likelihood[0, 0])
     it2.close()
-    return {"workload": "C3: SVI streaming, T=4 [Gaussian,Bernoulli,Poisson,Gamma], N_all=1000000 rows/task resident, minibatch "
+    # (d) [r6] what a user of the reference's OWN driver sees: util.vem_algorithm(model, stochastic=True) -- the
+    # façade's restatement of util.py:316-329: lengthscale and kappa frozen, variance / W free, Adadelta(step_rate 0.01, momentum
+    # 0.9), 4 x E / 1 x M gating -- on a model built exactly as the north-star spells it (constructor default strict_qf="auto"),
+    # for >= 200 iterations.  Z is frozen by hand (`model.Z.fix()`, as a user of the reference has to: its stochastic branch
+    # never looks at optZ): with Z free the FIRST M-step of Adadelta moves every inducing point by 0.01 sqrt(1e-4 / 0.1) = 3.2e-4
+    # = a third of the M = 1024 grid spacing in the direction of its gradient's sign, neighbouring inducing points collapse,
+    # cond(K_uu) goes 5 -> 1e6 within five iterations and the ELBO to -inf (the reference's S_q = I start makes
+    # K_uu^-1 S K_uu^-1 explode; same arithmetic in the reference): profiles/r06_svi_traj_probe.txt.
+    #   traj       from lengthscale = 1.0 x inducing spacing (well conditioned: the default path throughout)
+    #   traj_lad   from lengthscale = 4.0 x inducing spacing (cond(K_uu) ~ 1e7, GPy's jitter rung 0): what "auto" costs where it acts
+    import warnings
+    del model, model2
+    gc.collect()
+    h = 1.0 / (M - 1)
+
+    def trajectory(ell_over_h, n_traj):
+        np.random.seed(1)
+        kern3 = [RBF(P, variance=float(prm["variance"][q]), lengthscale=ell_over_h * h) for q in range(Q)]
+        model3 = H.HetMOGP(X, [y[:, None] for y in Y], prm["Z"][:, :P].copy(), kern3, lik, lik.generate_metadata(), batch_size=B)
+        model3.Z.fix()
+        ev0, sev0 = model3.evaluations, model3.strict_evaluations
+        failed = None
+        with warnings.catch_warnings(record=True) as wlog:
+            warnings.simplefilter("always")
+            guard = _StdoutToStderr()
+            guard.__enter__()
+            try:
+                t0 = time.perf_counter()
+                try:
+                    H.vem_algorithm(model3, stochastic=True, vem_iters=n_traj - 1, verbose=False)   # (the callback stops at n_iter > vem_iters)
+                except Exception as exc:                                                         # noqa: BLE001
+                    failed = "%s: %s" % (type(exc).__name__, exc)
+                traj_s = time.perf_counter() - t0
+            finally:
+                guard.__exit__()
+        ev, sev = model3.evaluations - ev0, model3.strict_evaluations - sev0
+        done = ev if failed else n_traj
+        r = {"driver": "hetmogp_amd.vem_algorithm(model, stochastic=True, vem_iters=%d) on HetMOGP(X, Y, Z, kern_list, likelihood, "
+                       "Y_metadata, batch_size=8192), model.Z.fix() -- util.py:316-329 / svmogp.py:168-217; constructor default "
+                       "strict_qf='auto'" % (n_traj - 1),
+             "start": "lengthscale = %.1f x inducing spacing (all latents), variance %s, S_q = I, m_q ~ 2.5 N(0,1) (svmogp.py:66-69)"
+                      % (ell_over_h, [round(float(v), 3) for v in prm["variance"]]),
+             "iterations": done, "failed": failed, "ms_per_iteration": 1e3 * traj_s / max(done, 1), "iterations_per_s": done / traj_s,
+             "evaluations": ev, "strict_evaluations": sev, "strict_share": sev / float(max(ev, 1)),
+             "strict_switches": int(model3.strict_switches), "strict_now_at_end": bool(model3._strict_now),
+             "cond_est_last": [float(c) for c in model3.last["cond_est"]], "rungs_last": [int(r_) for r_ in model3.last["rungs"]],
+             "elbo_first": float(model3.elbo[0, 0]), "elbo_last": float(model3.elbo[max(done - 1, 0), 0]),
+             "ill_conditioned_warnings": len([w for w in wlog if "ill-conditioned" in str(w.message)]),
+             "optimizer": "DeviceAdadelta (q(u) and its accumulators resident in HBM; iterates bit-identical to the host loop)"}
+        del model3
+        gc.collect()
+        return r
+    traj = trajectory(1.0, max(200, 5 * K))
+    traj_lad = trajectory(4.0, 60)
+    return {"svi_reference_driver_trajectory": traj, "svi_reference_driver_trajectory_ladder_regime": traj_lad,
+            "workload": "C3: SVI streaming, T=4 [Gaussian,Bernoulli,Poisson,Gamma], N_all=1000000 rows/task resident, minibatch "
                         "8192 rows/task/step, M=1024, Q=3",
             "ms_per_step": ms, "steps_per_s": 1e3 / ms, "flops_executed": fl, "tflops": fl / ms / 1e9,
             "frac_of_peak": fl / ms / 1e9 / PEAK_FP64_MFMA_TFLOPS, "dominant_kernel": dk, "dominant_kernel_ms": dms,

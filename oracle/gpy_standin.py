@@ -175,8 +175,42 @@ class Param(np.ndarray):
         self._fixed[0] = False
 
 
+# paramz's Logexp transformation (transformations.py; SURVEY appendix A, restated): positive parameters are optimised through
+# theta = log(1 + e^x); _lim_val = 36, the commented-out epsilon of the original is not added
+_LOGEXP_LIM = 36.0
+
+
+def logexp_f(x):
+    return np.where(x > _LOGEXP_LIM, x, np.log1p(np.exp(np.clip(x, -_LIM_VAL, _LOGEXP_LIM))))
+
+
+def logexp_finv(f):
+    return np.where(f > _LOGEXP_LIM, f, np.log(np.expm1(f)))
+
+
+def logexp_gradfactor(f):
+    return np.where(f > _LOGEXP_LIM, 1.0, -np.expm1(-f))
+
+
+class _Selection(object):
+    """What `model['<regexp>']` returns as far as the reference uses it (util.py:285-315: `.fix()` / `.unfix()`)."""
+
+    def __init__(self, params):
+        self.params = params
+
+    def fix(self):
+        [p.fix() for p in self.params]
+
+    def unfix(self):
+        [p.unfix() for p in self.params]
+
+
 class SparseGP(object):
-    """Stand-in for GPy.core.SparseGP as used by svmogp.py:56-58 (dummy X/Y, Z as a Param)."""
+    """Stand-in for GPy.core.SparseGP as used by svmogp.py:56-58 (dummy X/Y, Z as a Param) and -- [r6] -- for the paramz surface the
+    reference's SVI driver touches (svmogp.py:188-199 `self._grads(parameters)`, util.py:285-329 `model['.*.kappa'].fix()`,
+    `model.optimizer_array`): parameter order = link order (svmogp.py:71-75: Z at index 0, m_u, L_u, kernels, B_q), fixed parameters
+    leave the flat vector, positive ones (RBF variance / lengthscale, Coregionalize kappa) go through Logexp, `_grads(x)` sets the
+    vector (firing parameters_changed) and returns the gradient of the objective -log_likelihood.  SURVEY appendix A, last row."""
 
     def __init__(self, X, Y, Z, kernel, likelihood, mean_function=None, X_variance=None,
                  inference_method=None, name="sparse gp", Y_metadata=None, normalizer=False):
@@ -190,7 +224,55 @@ class SparseGP(object):
         self._linked = []
 
     def link_parameter(self, p, index=None):
-        self._linked.append(p)
+        if index is None:
+            self._linked.append(p)
+        else:
+            self._linked.insert(index, p)
+
+    def _leaves(self):
+        """[(hierarchy name without the model's, Param, positive?)] in link order."""
+        out, seen = [], {}
+        for p in self._linked:
+            if isinstance(p, Param):
+                out.append((p.name, p, False))
+                continue
+            n = seen.get(p.name, 0)                     # paramz disambiguates equal names: rbf, rbf_1, ...
+            seen[p.name] = n + 1
+            base = p.name if n == 0 else "%s_%d" % (p.name, n)
+            if isinstance(p, RBF):
+                out += [(base + ".variance", p.variance, True), (base + ".lengthscale", p.lengthscale, True)]
+            else:
+                out += [(base + ".W", p.W, False), (base + ".kappa", p.kappa, True)]
+        return out
+
+    def __getitem__(self, pattern):
+        import re
+        rx = re.compile(pattern)
+        hit = [p for name, p, _ in self._leaves() if rx.match(name)]
+        if not hit:
+            raise AttributeError(pattern)
+        return _Selection(hit)
+
+    @property
+    def optimizer_array(self):
+        return np.concatenate([logexp_finv(np.ravel(p)) if pos else np.ravel(np.asarray(p)).copy()
+                               for _, p, pos in self._leaves() if not p.is_fixed])
+
+    @optimizer_array.setter
+    def optimizer_array(self, x):
+        i = 0
+        for _, p, pos in self._leaves():
+            if p.is_fixed:
+                continue
+            v = np.asarray(x[i:i + p.size], dtype=float).reshape(p.shape)
+            np.asarray(p)[...] = logexp_f(v) if pos else v
+            i += p.size
+        self.parameters_changed()
+
+    def _grads(self, x):
+        self.optimizer_array = x
+        return -np.concatenate([np.ravel(p.gradient) * (logexp_gradfactor(np.ravel(np.asarray(p))) if pos else 1.0)
+                                for _, p, pos in self._leaves() if not p.is_fixed])
 
     def link_parameters(self, *ps):
         self._linked.extend(ps)
@@ -364,6 +446,37 @@ class LatentFunctionInference(object):
     pass
 
 
+class Adadelta(object):
+    """climin 0.1a1 `Adadelta` as util.py:327-329 drives it (restated): in place on `wrt`, `minimize_until(cb)`
+    stops when `cb(info)` is true, `info['n_iter']` 1-based."""
+
+    def __init__(self, wrt, fprime, step_rate=1, decay=0.9, momentum=0, offset=1e-4, args=None):
+        self.wrt, self.fprime = wrt, fprime
+        self.step_rate, self.decay, self.momentum, self.offset = step_rate, decay, momentum, offset
+        self.gms, self.sms, self.step = np.zeros_like(wrt), np.zeros_like(wrt), np.zeros_like(wrt)
+        self.n_iter = 0
+
+    def __iter__(self):
+        while True:
+            d, o, m = self.decay, self.offset, self.momentum
+            step1 = self.step * m
+            self.wrt -= step1
+            gradient = self.fprime(self.wrt)
+            self.gms = (d * self.gms) + (1 - d) * gradient ** 2
+            step2 = np.sqrt(self.sms + o) / np.sqrt(self.gms + o) * gradient * self.step_rate
+            self.wrt -= step2
+            self.step = step1 + step2
+            self.sms = (d * self.sms) + (1 - d) * self.step ** 2
+            self.n_iter += 1
+            yield dict(n_iter=self.n_iter, gradient=gradient, args=(), kwargs={})
+
+    def minimize_until(self, criterions):
+        criterions = criterions if isinstance(criterions, (list, tuple)) else [criterions]
+        for info in self:
+            if any(c(info) for c in criterions):
+                return info
+
+
 def install():
     """Inject the stand-in modules. Idempotent."""
     if "GPy" in sys.modules and getattr(sys.modules["GPy"], "_hetmogp_standin", False):
@@ -396,7 +509,7 @@ def install():
     pl = mod("GPy.plotting", matplot_dep=pl_mpl)
     gpy = mod("GPy", util=util, likelihoods=liks, kern=kern, inference=inf, core=core, plotting=pl,
               _hetmogp_standin=True)
-    mod("climin")
+    mod("climin", Adadelta=Adadelta)
     # scipy.misc.logsumexp / np.int were removed from the installed SciPy / NumPy
     import scipy.special
     if "scipy.misc" not in sys.modules:

@@ -26,6 +26,11 @@ Fixture families:
                         (the _raw_predict_f route factorises the N x N K_ff of the TRAINING inputs).  Relies on the
                         stand-in's restated GPy `Posterior` (lazy woodbury_vector / woodbury_inv) and kernel input
                         slicing ("GPy-unpinned"); the inputs are spaced so that no K_ff needs jitter (rungs recorded).
+  svi_traj_<case>.npz f1  13 consecutive iterations of the reference's own SVI driver -- util.vem_algorithm(stochastic=True)
+                        (util.py:316-329) over SVMOGP.stochastic_grad / new_batch / callback (svmogp.py:168-217) and
+                        draw_mini_slices (util.py:52-72); paramz (`_grads`, `optimizer_array`, Logexp, regexp fix) and climin's
+                        Adadelta are the stand-in's restatements ("paramz/climin-unpinned"); slice bounds, E/M gating, ELBO,
+                        optimiser vector and gradient per iteration.
 """
 import json
 import os
@@ -643,6 +648,89 @@ def gen_reference_ladder(stand, inf, util, hl, svmogp, liks):
                for key in ("elbo", "g_m_u", "g_L_u", "g_Z", "g_variance", "g_lengthscale", "g_W", "g_kappa")})
 
 
+def gen_svi_trajectory(stand, util, hl, svmogp, liks):
+    """[r6] Row f1 of SURVEY 8: the reference's OWN SVI driver -- `util.vem_algorithm(model, stochastic=True)`
+    (util.py:316-329) over its own `SVMOGP.stochastic_grad` / `new_batch` / `set_data` / `callback` (svmogp.py:168-217) and
+    `draw_mini_slices` (util.py:52-72) -- run for 13 consecutive iterations (vem_iters = 12: the callback stops at n_iter > 12) on
+    the config-2 mix with contiguous minibatches of 16 rows (the 17-row task yields a 16-row and a ONE-row batch in turn).  What the
+    stand-in supplies underneath is the paramz surface (`_grads`, `optimizer_array`, `model['<regexp>'].fix()`, Logexp) and climin's
+    Adadelta recurrence (oracle/gpy_standin.py, restated from SURVEY appendix A); everything that decides WHICH rows, WHICH gating
+    and WHICH gradients an iteration sees is the reference's code.  Recorded per iteration: the slice bounds of every task, the
+    (vem_step, ve_count) the evaluation ran under, model.log_likelihood() after it, the optimiser vector the gradient was taken at
+    and that gradient; at the end `model.elbo` as the callback wrote it and the optimiser's final vector."""
+    import random
+    (_, specs, Ns, M, Q, P, cs, _, _) = INF_CASES[2]
+    batch_size, vem_iters, step_rate = 16, 12, 0.01
+    rng = np.random.RandomState(977)
+    c = build_case(rng, specs, Ns, M, Q, P, cs, False, False)
+    T = len(specs)
+    likelihood = hl.HetLikelihood([make_lik(liks, s) for s in specs])
+    Y_metadata = likelihood.generate_metadata()
+    Df = likelihood.num_output_functions(Y_metadata)
+    kern_list = util.latent_functions_prior(Q, lenghtscale=c["lengthscale"], variance=c["variance"], input_dim=P)
+    W_list = [c["W"][q][:, None].copy() for q in range(Q)]
+    np.random.seed(4321)
+    random.seed(17)
+    model = svmogp.SVMOGP(X=c["X"], Y=c["Y"], Z=c["Z"][:, :P].copy(), kern_list=kern_list, likelihood=likelihood,
+                          Y_metadata=Y_metadata, batch_size=batch_size, W_list=W_list)
+    model.q_u_means[...] = c["m_u"]
+    model.q_u_chols[...] = c["L_flat"]
+    model.Z[...] = c["Z"]
+    model.parameters_changed()
+    slices = [[] for _ in range(T)]
+
+    def recording_slicer(gen, t):               # (observes what the reference's own generator yields; changes nothing)
+        for sl in gen:
+            slices[t].append((sl.start, min(sl.stop, Ns[t])))
+            yield sl
+    model.slicer_list = [recording_slicer(g_, t) for t, g_ in enumerate(model.slicer_list)]
+    trace = []
+    ref_stochastic_grad = model.stochastic_grad
+
+    def recording_grad(x):
+        before = (int(bool(model.vem_step)), int(model.ve_count))
+        g_ = ref_stochastic_grad(x)
+        trace.append(dict(before=before, after=(int(bool(model.vem_step)), int(model.ve_count)), x=np.array(x, copy=True),
+                          g=np.array(g_, copy=True), elbo=float(np.ravel(model.log_likelihood())[0]),
+                          batch_scale=list(model.batch_scale)))
+        return g_
+    model.stochastic_grad = recording_grad
+    captured = {}
+    ref_adadelta = sys.modules["climin"].Adadelta
+
+    def capturing_adadelta(*a, **kw):            # (keeps a handle on the optimiser util.py:327 creates: its final `wrt`)
+        captured["opt"] = ref_adadelta(*a, **kw)
+        captured["x0"] = np.array(captured["opt"].wrt, copy=True)
+        return captured["opt"]
+    sys.modules["climin"].Adadelta = capturing_adadelta
+    try:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", DeprecationWarning)      # svmogp.py:203 assigns a (1,) array to a scalar slot
+            util.vem_algorithm(model, stochastic=True, vem_iters=vem_iters, step_rate=step_rate)
+    finally:
+        sys.modules["climin"].Adadelta = ref_adadelta
+    n_it = len(trace)
+    assert n_it == vem_iters + 1 and all(len(s_) == n_it for s_ in slices), (n_it, [len(s_) for s_ in slices])
+    out = {}
+    for t in range(T):
+        out["Xall_%d" % t], out["Yall_%d" % t] = c["X"][t], c["Y"][t]
+    np.savez_compressed(
+        os.path.join(OUT, "svi_traj_config2.npz"), spec=json.dumps(specs), T=T, M=M, Q=Q, P=P, Df=Df,
+        Z=c["Z"], variance=c["variance"], lengthscale=c["lengthscale"], W=c["W"], W0=c["W"], kappa=np.zeros((Q, Df)),
+        m_u=c["m_u"], L_flat=c["L_flat"], batch_size=batch_size, vem_iters=vem_iters, step_rate=step_rate, momentum=0.9,
+        free=json.dumps([n for n, p_, _ in model._leaves() if not p_.is_fixed]),
+        slice_begin=np.array([[slices[t][i][0] for t in range(T)] for i in range(n_it)]),
+        slice_end=np.array([[slices[t][i][1] for t in range(T)] for i in range(n_it)]),
+        gate_before=np.array([tr["before"] for tr in trace]), gate_after=np.array([tr["after"] for tr in trace]),
+        batch_scale=np.array([tr["batch_scale"] for tr in trace]),
+        elbo_trace=np.array([tr["elbo"] for tr in trace]), x_eval=np.stack([tr["x"] for tr in trace]),
+        g_eval=np.stack([tr["g"] for tr in trace]), x0=captured["x0"], x_final=np.array(captured["opt"].wrt, copy=True),
+        model_elbo=np.asarray(model.elbo, dtype=float), **out)
+    print("svi trajectory: %d iterations, gates %s, ELBO %.6f -> %.6f" % (
+        n_it, "".join("E" if tr["before"][0] else "M" for tr in trace), trace[0]["elbo"], trace[-1]["elbo"]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     stand, inf, util, hl, svmogp, liks = _import_reference()
@@ -652,6 +740,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "ladder":       # only the jitter-ladder family
         gen_reference_ladder(stand, inf, util, hl, svmogp, liks)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "svi":          # only the SVI trajectory
+        gen_svi_trajectory(stand, util, hl, svmogp, liks)
+        return
     gen_likelihoods(liks)
     gen_predictive(liks)
     gen_cov(stand, util)
@@ -660,6 +751,7 @@ def main():
     gen_model_predict(stand, util, hl, svmogp, liks)
     gen_reference_real_sizes(stand, inf, util, hl, svmogp, liks)
     gen_reference_ladder(stand, inf, util, hl, svmogp, liks)
+    gen_svi_trajectory(stand, util, hl, svmogp, liks)
 
 
 if __name__ == "__main__":
