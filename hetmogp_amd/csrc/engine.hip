@@ -50,6 +50,8 @@ hmogp_engine::~hmogp_engine() {
     if (e) (void)hipEventDestroy(e);
   if (hstage) (void)hipHostFree(hstage);
   if (h_info) (void)hipHostFree(h_info);
+  if (h_cond) (void)hipHostFree(h_cond);
+  if (ev_cond) (void)hipEventDestroy(ev_cond);
   if (st2_own) (void)hipStreamDestroy(st2_own);
   if (st3_own) (void)hipStreamDestroy(st3_own);
   if (st) (void)hipStreamDestroy(st);
@@ -232,8 +234,16 @@ void hmogp_engine::ensure_workspace(long long rows) {
 
 void hmogp_engine::ensure_strict_workspace() {
   if (!strict) return;
-  Dm.ensure(sizeof(double) * (long long)M * M * Q, true);
+  const long long MMs = (long long)M * M;
+  D2.ensure(sizeof(double) * MMs * Q, true), dcond.ensure(sizeof(double) * HMOGP_MAXQ, true);
+  if (!h_cond) HIP_TRY(hipHostMalloc((void**)&h_cond, sizeof(double) * HMOGP_MAXQ, hipHostMallocDefault));
+  if (!ev_cond) HIP_TRY(hipEventCreateWithFlags(&ev_cond, hipEventDisableTiming));
+  Dm.ensure(sizeof(double) * MMs * Q, true), Wq.ensure(sizeof(double) * MMs * Q, true), Lsy.ensure(sizeof(double) * MMs * Q, true);
+  rdiag.ensure(sizeof(double) * (long long)M * Q, true), w3.ensure(sizeof(double) * (long long)M * Q, true);
+  sVst = ((2LL * M + 1) * M + 1) & ~1LL;
+  Vst.ensure(sizeof(double) * sVst * Q, true);
   if (ws_strict_rows >= ws_rows) return;
+  trsmpart.ensure(sizeof(double) * 8 * ws_rows * Q);
   Ah.ensure(sizeof(double) * ws_rows * M * Q);
   vpg.ensure(sizeof(double) * ws_rows * Q, true), vcg.ensure(sizeof(double) * ws_rows * Q, true);
   ws_strict_rows = ws_rows;
@@ -463,9 +473,20 @@ void hmogp_engine::finish_enqueue(hmogp_outputs* out) {
   {
     Scope sc(this, CAT_MM, 0);
     launch_mirror_lower(Hq(0), Q, M, per_q, st);                   // the row pass / the exchange fill the lower triangle
-    if (strict) {   // the bundle already holds dVE_dS = A^T diag(beta) A and dVE_dmu = A^T alpha (svmogp_inf.py:144-148)
+    if (strict && strict_two) {   // two-solve form: the bundle already holds dVE_dS = A^T diag(beta) A and dVE_dmu = A^T alpha (svmogp_inf.py:144-148)
       HIP_TRY(hipMemcpy2DAsync(G.p, sizeof(double) * MM, Hq(0), sizeof(double) * per_q, sizeof(double) * MM, Q, hipMemcpyDeviceToDevice, st));
       HIP_TRY(hipMemcpy2DAsync(Kr.p, sizeof(double) * M, Hq(0) + oR, sizeof(double) * per_q, sizeof(double) * M, Q, hipMemcpyDeviceToDevice, st));
+    } else if (strict) {
+      // [r6] one-solve form: the bundle holds H = X^T diag(beta) X and r = X^T alpha with X = K^ Luu^-T (both additive over rows and
+      // ranks); dVE_dS = A^T diag(beta) A = Luu^-T H Luu^-1 and dVE_dmu = A^T alpha = Luu^-T r (svmogp_inf.py:144-148) follow by two
+      // backward row-solves on M x M: [H ; r^T] Luu^-1 (M + 1 rows; its last row is (Luu^-T r)^T), transpose, once more, mirror.
+      HIP_TRY(hipMemcpy2DAsync(Vst.p, sizeof(double) * sVst, Hq(0), sizeof(double) * per_q, sizeof(double) * MM, Q, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemcpy2DAsync(Vst.d() + MM, sizeof(double) * sVst, Hq(0) + oR, sizeof(double) * per_q, sizeof(double) * M, Q, hipMemcpyDeviceToDevice, st));
+      potrs_rows_inplace(Vst.d(), sVst, Luu.d(), MM, M, M + 1, Q, st, Lsy.d(), nullptr, rdiag.d(), nullptr, 2, lsym_valid);
+      HIP_TRY(hipMemcpy2DAsync(Kr.p, sizeof(double) * M, Vst.d() + MM, sizeof(double) * sVst, sizeof(double) * M, Q, hipMemcpyDeviceToDevice, st));
+      launch_transpose_batched(Vst.d(), sVst, G.d(), MM, Q, M, st);
+      potrs_rows_inplace(G.d(), MM, Luu.d(), MM, M, M, Q, st, Lsy.d(), nullptr, rdiag.d(), nullptr, 2, lsym_valid);
+      launch_mirror_lower(G.d(), Q, M, MM, st);
     } else {
       mm(Hq(0), false, Kuui.d(), true, HK.d(), 1.0, per_q);          // H K^-1
       mm(Kuui.d(), false, HK.d(), true, G.d(), 1.0, -1, -1, nullptr, 0, 0, true);  // G = K^-1 H K^-1 (dVE_dS, svmogp_inf.py:148):

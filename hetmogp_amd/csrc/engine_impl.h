@@ -144,8 +144,22 @@ void jitchol_batched(const double* Kuu, double* Luu, int Q, int M, const double*
 // GEMMs (alpha = -1, beta = 1) -- backward stable like LAPACK's dtrsm.  Used by the strict q(f) mode and hmogp_potrs_rows.
 // `Vsrc` (optional, same layout as V): the right-hand sides; they reach V either by a copy in front of the solve or -- where every
 // launch of the forward solve is one of the specialised ones -- through the FIRST touch of each column (no copy: 8.4 ms at H).
-void potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL, int M, long long n, int Q, hipStream_t st,
-                        double* Lsym = nullptr, const double* Vsrc = nullptr);
+// [r6] `rdiag` (Q x M scratch) offers the solve to the one-launch-per-block kernels of trsm_panel.hip (needs `Lsym`, M a multiple of
+// 128, n >= 1024); with `stats` the LAST direction's epilogue also leaves the row statistics sp = (result) . vec and
+// sk = rowsum(result .* K) -- or rowsum(result .* result) when K is null -- (partials: launch_trsm_stats_combine).
+// `dirs`: 1 = forward substitution only (V <- V Luu^-T), 2 = backward only (V <- V Luu^-1), 3 = both (dpotrs).
+// `lsym_ready`: Lsym and rdiag already hold the images of THIS factor (the engine prepares them once per factorisation).
+// Returns true iff the statistics were produced.
+struct TrsmRowStats {
+  const double* K = nullptr;     // same layout as V, or null
+  const double* vec = nullptr;   // element (column j, batch q) at vec[q * vecB + j * vecS]
+  long long vecB = 0, vecS = 1;
+  double* part = nullptr;        // [Q][sPart]: [2 statistics][4 wave columns][ld]
+  long long sPart = 0, ld = 0;
+};
+bool potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL, int M, long long n, int Q, hipStream_t st,
+                        double* Lsym = nullptr, const double* Vsrc = nullptr, double* rdiag = nullptr,
+                        const TrsmRowStats* stats = nullptr, int dirs = 3, bool lsym_ready = false);
 
 // ------------------------------------------------------------------------------------ RCCL, resolved at run time
 // The exchange step of a row-sharded run is ONE ncclAllReduce on the engine's own stream.  librccl is not a
@@ -188,7 +202,21 @@ struct hmogp_engine {
   // g_W / g_kappa / g_Z once GPy's jitter ladder is taken, cond ~ 1e7).  ~2x the step time at the headline size (2.5x in round 5, 3.3x in its first version); for parity in that regime.
   bool strict = false;         // ... of the CURRENT / last evaluation: strict_cfg (the config flag) or hmogp_params.eval_flags
   bool strict_cfg = false;
-  DevBuf Dm, Ah, vpg, vcg;
+  DevBuf Dm, Ah, vpg, vcg, rdiag, trsmpart;
+  // [r6] one-solve form: Wq = Luu^-1 L_q, Dm = Luu^-1 (S Kuu^-1 - I), w3 = Luu^-1 m (strict_stack / strict_unstack), Vst = the
+  // stacked right-hand sides of that M x M solve and of the two that turn X^T diag(beta) X, X^T alpha into dVE_dS, dVE_dmu (finish)
+  // Which form an evaluation takes: the literal TWO-solve form of round 5 (A = dpotrs on the n x M side, D2 = S K_uu^-1 - I) when it
+  // needs P~ (hyper-parameter / Z gradients: see u_algebra) or when the condition estimate of ITS OWN K_uu (variance max diag
+  // K_uu^-1, read back behind the factorisation: one host wait the latency-bound chain covers) is beyond 1e6 -- the regime where only
+  // multiples of the reference's own sensitivity can be asserted; the ONE-solve form otherwise (E-steps, predictions).
+  bool strict_two = false, cond_two = false;   // cond_two: the conditioning half of the decision (kept with a cached K_uu chain)
+  double* h_cond = nullptr;    // page-locked landing buffer of the early condition estimate
+  hipEvent_t ev_cond = nullptr;
+  DevBuf D2, dcond;
+  DevBuf Wq, w3, Vst, Lsy;
+  long long sVst = 0;
+  bool lsym_valid = false;     // Lsy / rdiag belong to the current Luu
+  void strict_factor_images();
   unsigned quirks = HMOGP_QUIRKS_REFERENCE;
   std::vector<double> h_Z, kuu_key;
   std::vector<int> rung_request, kuu_rung;

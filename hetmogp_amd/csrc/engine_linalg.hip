@@ -101,8 +101,9 @@ void jitchol_batched(const double* Kuu, double* Luu, int Q, int M, const double*
   jitchol_resolve(Kuu, Luu, Q, M, diag_mean, rung_io, d_info, d_jit, dscr, st, js);
 }
 
-void potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL, int M, long long n, int Q, hipStream_t st,
-                        double* Lsym, const double* Vsrc) {
+bool potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL, int M, long long n, int Q, hipStream_t st,
+                        double* Lsym, const double* Vsrc, double* rdiag, const TrsmRowStats* stats, int dirs, bool lsym_ready) {
+  const bool fwd = (dirs & 1) != 0, bwd = (dirs & 2) != 0;
   // C[:, c0:c0+nc] -= V[:, a0:a0+k] op(B)   (op(B) = Luu[c0.., a0..]^T for the forward solve, Luu[a0.., c0..] for the backward one)
   // [r5] `role` 1 offers the update to the specialised 8-wave kernel (gemm_rowpass.hip, C -= A B form: 128-column updates with a
   // k-major B); it falls back to the general kernel by itself.  The forward solve's B is the TRANSPOSE of a block of Luu: with
@@ -123,10 +124,45 @@ void potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL
     g.c_src = c_src ? c_src + c0 : nullptr;
     launch_gemm_rowpass_or_general(g, st);
   };
-  const bool sym = Lsym != nullptr && n >= 4096 && sL == (long long)M * M;
-  if (sym) {
+  // (the mirrored factor pays off from a few thousand rows on; the one-launch-per-block kernels also take the replicated
+  //  M x M solves of the one-solve strict form -- 2 M + 1 and M + 1 rows -- where they replace 40 launches per direction by 8)
+  const bool sym = Lsym != nullptr && n >= (rdiag ? 1024 : 4096) && sL == (long long)M * M;
+  if (sym && !lsym_ready) {
     HIP_TRY(hipMemcpyAsync(Lsym, Luu, sizeof(double) * sL * Q, hipMemcpyDeviceToDevice, st));
     launch_mirror_lower(Lsym, Q, M, sL, st);       // Lsym[k][j] = Luu[j][k] above the diagonal
+  }
+  // [r6] ONE launch per 128-column block and direction (trsm_panel.hip): the block's long-K update and the substitution inside it
+  // with the 128 x 128 tile in the accumulators throughout -- the right-hand sides are read once (from `Vsrc` by the forward
+  // solve: no copy) and written once per solve, and the backward solve's epilogue forms the row statistics of A on the way out.
+  // 16 launches at M = 1024 where round 5 needed 80; the round-5 path below stays for ragged M, short passes and A/B runs.
+  if (sym && rdiag) {
+    TrsmPanelArgs pa;
+    pa.V = V, pa.sV = sV, pa.ldv = M, pa.Lsym = Lsym, pa.sL = sL, pa.ldl = M, pa.rdiag = rdiag, pa.sR = M, pa.n = n, pa.M = M, pa.Q = Q;
+    pa.Vsrc = Vsrc;
+    if (trsm_panel_eligible(pa)) {
+      if (!lsym_ready) launch_rdiag(Luu, sL, M, Q, rdiag, M, st);
+      auto with_stats = [&]() {
+        if (!stats) return;
+        pa.st_K = stats->K, pa.st_vec = stats->vec, pa.st_vecB = stats->vecB, pa.st_vecS = stats->vecS, pa.st_part = stats->part,
+        pa.st_sPart = stats->sPart, pa.st_ld = stats->ld;
+      };
+      if (fwd) {
+        if (!bwd) with_stats();
+        for (int J0 = 0; J0 < M; J0 += 128) {                   // X Luu^T = V   (forward over the column blocks)
+          pa.j0 = J0;
+          launch_trsm_panel(0, pa, st);
+        }
+        pa.Vsrc = nullptr;
+      }
+      if (bwd) {
+        with_stats();
+        for (int J0 = M - 128; J0 >= 0; J0 -= 128) {            // A Luu = X     (backward)
+          pa.j0 = J0;
+          launch_trsm_panel(1, pa, st);
+        }
+      }
+      return stats != nullptr;
+    }
   }
   // Two-level blocking: the bulk of the flops sits in updates of 128 columns at a time (full MFMA tiles: an update of a 32-column
   // block alone uses a quarter of a 128 x 128 tile), the 32-column substitution steps and their short updates stay inside a
@@ -142,7 +178,7 @@ void potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL
   // first touch instead of a copy: every 128-column update of the forward solve must be taken by the specialised kernel (the
   // general one has no separate source) and every block's first substitution launch by the row-coalesced one
   bool first_touch = false;
-  if (Vsrc) {
+  if (Vsrc && fwd) {
     static const bool ft_env = [] {   // HMOGP_STRICT_FIRST_TOUCH=0: copy the right-hand sides in front of the solve (A/B runs)
       const char* e = getenv("HMOGP_STRICT_FIRST_TOUCH");
       return !(e && e[0] == '0');
@@ -157,7 +193,12 @@ void potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL
       for (int q = 0; q < Q; ++q)
         HIP_TRY(hipMemcpyAsync(V + q * sV, Vsrc + q * sV, sizeof(double) * n * M, hipMemcpyDeviceToDevice, st));
   }
-  for (int J0 = 0; J0 < M; J0 += NB) {                        // X Luu^T = V   (forward over the columns)
+  if (Vsrc && !fwd) {           // (a backward-only solve has no first-touch launches: its right-hand sides are copied)
+    first_touch = false;
+    for (int q = 0; q < Q; ++q)
+      HIP_TRY(hipMemcpyAsync(V + q * sV, Vsrc + q * sV, sizeof(double) * n * M, hipMemcpyDeviceToDevice, st));
+  }
+  for (int J0 = 0; fwd && J0 < M; J0 += NB) {                 // X Luu^T = V   (forward over the columns)
     const int J1 = std::min(M, J0 + NB);
     if (J0 > 0) {
       if (sym) update(J0, J1 - J0, 0, J0, Lsym + J0, 1, first_touch ? Vsrc : nullptr);   // op(B)[k][j] = Luu[J0 + j][k] = Lsym[k][J0 + j]
@@ -173,7 +214,7 @@ void potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL
       launch_trsm_diag(0, V, sV, Luu, sL, M, j0, nb, n, Q, st);
     }
   }
-  for (int J0 = ((M - 1) / NB) * NB; J0 >= 0; J0 -= NB) {     // A Luu = X     (backward over the columns)
+  for (int J0 = ((M - 1) / NB) * NB; bwd && J0 >= 0; J0 -= NB) {   // A Luu = X     (backward over the columns)
     const int J1 = std::min(M, J0 + NB);
     if (J1 < M) update(J0, J1 - J0, J1, M - J1, Luu + (long long)J1 * M + J0, 1);
     for (int j0 = J0 + ((J1 - J0 - 1) / 32) * 32; j0 >= J0; j0 -= 32) {
@@ -186,6 +227,7 @@ void potrs_rows_inplace(double* V, long long sV, const double* Luu, long long sL
       launch_trsm_diag(1, V, sV, Luu, sL, M, j0, nb, n, Q, st);
     }
   }
+  return false;
 }
 
 }  // namespace hmogp_detail

@@ -102,15 +102,22 @@ void hmogp_engine::u_algebra() {
   // goes straight on while the host waits for `info` alone (an event, not the stream) and then enqueues the row pass
   // behind ~0.6 ms of queued work -- no host round trip in the latency-bound chain.  If a latent did fail (GPy's jitter
   // ladder is needed: rare), the ladder runs synchronously as before and the same launches are simply issued again.
+  bool cond_pending = false;     // set by tail(): an early condition estimate is on its way (strict mode, new factor)
+  if (!kuu_hit) lsym_valid = false;             // (a new factor: its mirrored image / pivot reciprocals are rebuilt by the first strict use)
   auto tail = [&](bool first) {
     if (!kuu_hit && strict) {
       // strict mode: K_uu^-1 = dpotrs(Luu, I) by the blocked substitution, lower triangle mirrored like GPy's dpotri wrapper
       // (util.py:199).  The merge-based triangular inverse below is ~100x further from LAPACK's dpotri where it matters here
       // (|K_uu^-1 K_uu - I| 8.6e-8 against 3e-10 at cond 1e7) -- invisible at cond <= 1e5, 2e-8 of g_W / g_Z at 1e7.
       if (first) HIP_TRY(hipStreamWaitEvent(st, ev_zero, 0));
+      strict_factor_images();                     // [r6] the mirrored factor + its pivots' reciprocals: once per factorisation
       launch_identity(Kuui.d(), Q, M, st);
-      potrs_rows_inplace(Kuui.d(), MM, Luu.d(), MM, M, M, Q, st);
+      potrs_rows_inplace(Kuui.d(), MM, Luu.d(), MM, M, M, Q, st, Lsy.d(), nullptr, rdiag.d(), nullptr, 3, true);
       launch_mirror_lower(Kuui.d(), Q, M, MM, st);
+      launch_cond_probe(Kuui.d(), dvar.d(), Q, M, dcond.d(), st);      // which strict form: see strict_two (engine_impl.h)
+      HIP_TRY(hipMemcpyAsync(h_cond, dcond.p, sizeof(double) * Q, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipEventRecord(ev_cond, st));
+      cond_pending = true;
     } else if (!kuu_hit) {
       if (first) HIP_TRY(hipStreamWaitEvent(st, ev_zero, 0));     // (tmpA zeroed on the third stream, above)
       launch_trtri_batched(Luu.d(), tmpA.d(), tmpB.d(), Q, M, st, first);
@@ -119,7 +126,16 @@ void hmogp_engine::u_algebra() {
     launch_gemv_batched(Kuui.d(), dmu.d(), a.d(), Q, M, 1, Q, st);  // a = K_uu^-1 m
     HIP_TRY(hipStreamWaitEvent(st, ev_S, 0));
     mm(Kuui.d(), false, S.d(), true, KiS.d());
-    if (strict) launch_strict_d(KiS.d(), Dm.d(), Q, M, st);        // S K_uu^-1 - I   (svmogp_inf.py:157-158)
+    if (strict) {
+      // [r6] one-solve form: the right factors of A m, A L_q and A (S K_uu^-1 - I) (svmogp_inf.py:216-217, :157-159) with the
+      // BACKWARD half of dpotrs already inside them -- one forward row-solve of 2 M + 1 rows on the M x M side instead of a second
+      // pass of substitutions over the n x M side:  Wq = Luu^-1 L_q,  Dm = Luu^-1 (S K_uu^-1 - I),  w3 = Luu^-1 m
+      if (!lsym_valid) strict_factor_images();   // (cached K_uu chain whose factor was last used by a default-mode evaluation)
+      launch_strict_stack(L.d(), KiS.d(), dmu.d(), Vst.d(), sVst, Q, M, st);
+      potrs_rows_inplace(Vst.d(), sVst, Luu.d(), MM, M, 2LL * M + 1, Q, st, Lsy.d(), nullptr, rdiag.d(), nullptr, 1, true);
+      launch_strict_unstack(Vst.d(), sVst, Wq.d(), Dm.d(), w3.d(), Q, M, st);
+      launch_strict_d(KiS.d(), D2.d(), Q, M, st);                    // S K_uu^-1 - I: the two-solve form's right factor (:157-158)
+    }
     mm(KiS.d(), false, Kuui.d(), true, KSK.d());
     launch_sub(KSK.d(), Kuui.d(), C.d(), MM * Q, st);             // C = K^-1 S K^-1 - K^-1
     launch_tri_fold(C.d(), Ctri.d(), Q, M, st);                   // x^T Ctri x == x^T C x with a triangular matrix
@@ -139,9 +155,29 @@ void hmogp_engine::u_algebra() {
     for (int q = 0; q < Q; ++q) failed = failed || js.info[q] != 0;
     if (failed) {
       jitchol_resolve(Kuu.d(), Luu.d(), Q, M, h_var.data(), rung.data(), dinfo.as<int>(), djit.d(), dscr.d(), st, js);
+      lsym_valid = false;
       tail(false);
     }
     if (cache_kuu) kuu_key.swap(key), kuu_rung = rung, kuu_key_valid = true;
+  }
+  if (strict && cond_pending) {     // (the device is still busy with the rest of the chain: this wait costs no device time)
+    HIP_TRY(hipEventSynchronize(ev_cond));
+    cond_two = false;
+    for (int q = 0; q < Q; ++q) cond_two = cond_two || !(h_cond[q] <= 1e6);
+  }
+  if (strict) {
+    static const int force = [] {   // HMOGP_STRICT_FORM=1 | 2: force the one-solve / two-solve form (A/B runs)
+      const char* e = getenv("HMOGP_STRICT_FORM");
+      return e ? atoi(e) : 0;
+    }();
+    // P~ = A (S Kuu^-1 - I) -- needed by the K_uf-side gradients (hyper-parameters, Z) only -- is the one product that must be formed
+    // from A itself: as X (Luu^-1 (S Kuu^-1 - I)) its rounding error is sqrt(cond(K_uu)) times larger (the factors are 3e3 x 3e10
+    // where A's and D's are 1 x 1e7 at cond 1e7; measured at M = 1024, rung 0: g_Z 4e-8 instead of 2e-10 of its scale between two
+    // valid summation orders, 6 x the element-wise criterion on its small entries).  So: evaluations that need P~ take the
+    // two-solve form, E-steps (q(u) gradients only) and predictions the one-solve form -- unless K_uu is beyond the estimate 1e6.
+    strict_two = cond_two || (group_mask & (HMOGP_GROUP_HYPER | HMOGP_GROUP_Z)) != 0;
+    if (force == 1) strict_two = false;
+    if (force == 2) strict_two = true;
   }
 }
 
@@ -214,6 +250,14 @@ void hmogp_engine::stage_pool_inputs(const std::vector<Seg>& pl, hipStream_t str
                            hipMemcpyDeviceToDevice, stream));
 }
 
+void hmogp_engine::strict_factor_images() {
+  const long long MM = (long long)M * M;
+  HIP_TRY(hipMemcpyAsync(Lsy.p, Luu.p, sizeof(double) * MM * Q, hipMemcpyDeviceToDevice, st));
+  launch_mirror_lower(Lsy.d(), Q, M, MM, st);       // Lsy[k][j] = Luu[j][k] above the diagonal
+  launch_rdiag(Luu.d(), MM, M, Q, rdiag.d(), M, st);
+  lsym_valid = true;
+}
+
 void hmogp_engine::strict_forward(long long n, const double* X, bool grads, bool hyper) {
   const long long MM = (long long)M * M, ldn = ws_rows, sK = ldn * M;
   Scope sc(this, CAT_FWD, 4 * ((M + 31) / 32) + (grads ? 4 : 2));
@@ -227,14 +271,34 @@ void hmogp_engine::strict_forward(long long n, const double* X, bool grads, bool
     g.role = 1;                       // (no fused statistics: fs_part stays null) the specialised 8-wave forward kernel where the
     launch_gemm_rowpass_or_general(g, st);   // shape allows it -- incl. its triangular-fold pairing for T = A L_q -- else the general one
   };
-  potrs_rows_inplace(Ah.d(), sK, Luu.d(), MM, M, n, Q, st, tmpB.d(), Kh.d());   // A = dpotrs(Luu, K^T)^T   (svmogp_inf.py:214-215; tmpB: free here)
-  // T = A L_q = dtrmm(L_q^T, R)^T (:217) is only ever consumed as rowsum(T .* T) (:218): where the specialised fold kernel takes
+  // [r6] ONE-SOLVE FORM.  The reference forms R = dpotrs(Luu, K^T) (svmogp_inf.py:214) -- a forward and a backward substitution over
+  // all n rows -- and then R^T m, dtrmm(L_q^T, R), sum(R * K^T), (:216-218) and R^T-sided products for the gradients (:144-161).  Here
+  // only the FORWARD half touches the n x M side: X = K^ Luu^-T (into `Ah`); the backward half sits inside the M x M right factors
+  // Wq / Dm / w3 (u_algebra) and inside the two M x M solves that turn X^T diag(beta) X, X^T alpha into dVE_dS, dVE_dmu (finish):
+  //   A m = X w3,  A L_q = X Wq,  rowsum(A .* K^) = rowsum(X .* X)  (K^ = X Luu^T),  A (S Kuu^-1 - I) = X Dm.
+  // Same quantities, every one through triangular solves against Luu (never through K^-1 S K^-1 - K^-1, whose cancellation is
+  // what costs the default path cond(K_uu) digits); n M^2 flops and two passes over the n x M matrix less than two solves.
+  // Against the reference's own runs in the ladder regime the two forms are equally close (oracle prototype).
+  // The solve's epilogue leaves p = X w3 and rowsum(X .* X) where the one-launch-per-block kernels take it (trsm_panel.hip).
+  TrsmRowStats ts;
+  ts.part = trsmpart.d(), ts.sPart = 8 * ldn, ts.ld = ldn;
+  if (strict_two) ts.K = Kh.d(), ts.vec = dmu.d(), ts.vecB = 1, ts.vecS = Q;        // two-solve form: p = A m, rowsum(A .* K^)
+  else ts.K = nullptr, ts.vec = w3.d(), ts.vecB = M, ts.vecS = 1;                    // one-solve form: p = X w3, rowsum(X .* X)
+  static const bool ts_env = [] {   // HMOGP_TRSM_STATS=0: the statistics by strict_rowstats_kernel (A/B runs)
+    const char* e = getenv("HMOGP_TRSM_STATS");
+    return !(e && e[0] == '0');
+  }();
+  const bool stats_fused = potrs_rows_inplace(Ah.d(), sK, Luu.d(), MM, M, n, Q, st, Lsy.d(), Kh.d(), rdiag.d(), ts_env ? &ts : nullptr,
+                                              strict_two ? 3 : 1, lsym_valid);
+  const double* Bt = strict_two ? L.d() : Wq.d();       // right factor of T:  A L_q  |  X (Luu^-1 L_q)      (both lower triangular)
+  const double* Bp = strict_two ? D2.d() : Dm.d();      // right factor of P~: A (S Kuu^-1 - I)  |  X (Luu^-1 (S Kuu^-1 - I))
+  // T = A L_q = X Wq = dtrmm(L_q^T, R)^T (:217) is only ever consumed as rowsum(T .* T) (:218): where the specialised fold kernel takes
   // the product, its epilogue forms that sum from the accumulators and T is neither written nor read back (2 x 19.7 GB at H)
   bool t2_fused = false;
   {
     GemmArgs g;
     g.A = Ah.d(), g.lda = M, g.a_kmajor = 0, g.sA = sK;
-    g.B = L.d(), g.ldb = M, g.b_kmajor = 1, g.sB = MM, g.b_tri = +1;
+    g.B = Bt, g.ldb = M, g.b_kmajor = 1, g.sB = MM, g.b_tri = +1;
     g.C = Pt.d(), g.ldc = M, g.sC = sK;
     g.M = (int)n, g.N = M, g.K = M;
     g.nbatch = Q;
@@ -250,20 +314,23 @@ void hmogp_engine::strict_forward(long long n, const double* X, bool grads, bool
       launch_combine_parts(fwdpart.d(), nparts * tiles, n, nullptr, vct.d(), nullptr, nullptr, st, Q, g.fs_sPart, ldn);
       t2_fused = true;
     } else {
-      rows_gemm(Ah.d(), L.d(), 1, +1, Pt.d());
+      rows_gemm(Ah.d(), Bt, 1, +1, Pt.d());
     }
   }
   StrictRows sr;
   sr.M = M, sr.Q = Q, sr.P = P, sr.ldz = Q * P, sr.n = n, sr.ldn = ldn, sr.sK = sK, sr.sZ = P;
-  sr.Kh = Kh.d(), sr.Ah = Ah.d(), sr.Tt = Pt.d(), sr.Pt = Pt.d(), sr.mu = dmu.d(), sr.a = a.d();
+  sr.Kh = Kh.d(), sr.Ah = Ah.d(), sr.Tt = Pt.d(), sr.Pt = Pt.d(), sr.mu = dmu.d(), sr.w3 = strict_two ? nullptr : w3.d(), sr.a = a.d();
   sr.X = X, sr.Z = dZ.d(), sr.ell = dell.d();
   sr.p = vp.d(), sr.c = vc.d(), sr.pg = vpg.d(), sr.cg = vcg.d(), sr.pt = hyper ? vpt.d() : nullptr, sr.ct = hyper ? vct.d() : nullptr;
   sr.phase = 0;
   sr.t2 = t2_fused ? vct.d() : nullptr;           // (vct: free until phase 1 writes the r2-weighted twin into it)
-  launch_strict_rowstats(sr, st);                 // p = A m, c = rowsum(T^2) - rowsum(A .* K^)   (:216, :218)
+  if (stats_fused && t2_fused)                    // p = A m, c = rowsum(T^2) - rowsum(A .* K^)   (:216, :218)
+    launch_trsm_stats_combine(trsmpart.d(), ts.sPart, ldn, 4, n, Q, vct.d(), vp.d(), vc.d(), ldn, st);
+  else
+    launch_strict_rowstats(sr, st);
   sr.t2 = nullptr;
   if (!grads) return;
-  rows_gemm(Ah.d(), Dm.d(), 1, 0, Pt.d());        // P~ = A (S Kuu^-1 - I)                      (:157-161)
+  rows_gemm(Ah.d(), Bp, 1, 0, Pt.d());            // P~ = A (S Kuu^-1 - I) = X Dm               (:157-161)
   sr.phase = 1;
   launch_strict_rowstats(sr, st);                 // K^ a, rowsum(P~ .* K^) and their r2-weighted twins
 }

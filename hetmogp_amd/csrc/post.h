@@ -6,7 +6,13 @@ void launch_add_diag_copy(const double* src, double* dst, int Q, int M, const do
 void launch_sub(const double* A, const double* B, double* C, long long n, hipStream_t s);
 void launch_tri_fold(const double* C, double* T, int Q, int M, hipStream_t s);  // T = tril(C) + tril(C^T, -1)
 void launch_identity(double* A, int Q, int M, hipStream_t s);   // A[q] = I
-void launch_strict_d(const double* KiS, double* D, int Q, int M, hipStream_t s);  // D = KiS^T - I  (strict q(f))
+void launch_strict_d(const double* KiS, double* D, int Q, int M, hipStream_t s);  // D = KiS^T - I  (strict q(f), two-solve form)
+// [r6] strict q(f), one-solve form: V[q] = [ L_q^T ; Kuu^-1 S - I ; m_q^T ] (2 M + 1 rows of M, stride sV) for ONE forward row-solve
+// against Luu, and its result taken apart: W = Luu^-1 L_q, W2 = Luu^-1 (S Kuu^-1 - I) (both k-major = row-major), w3 = Luu^-1 m
+void launch_strict_stack(const double* L, const double* KiS, const double* mu, double* V, long long sV, int Q, int M, hipStream_t s);
+void launch_strict_unstack(const double* V, long long sV, double* W, double* W2, double* w3, int Q, int M, hipStream_t s);
+void launch_cond_probe(const double* Kuui, const double* var, int Q, int M, double* out, hipStream_t s);  // out[q] = var_q max diag
+void launch_transpose_batched(const double* A, long long sA, double* B, long long sB, int Q, int M, hipStream_t s);  // B[q] = A[q]^T
 #define KL_BLOCKS 64
 // out[(q*KL_BLOCKS + b)*5 + {0..4}] = block partials of sum(Kuui.*S), m^T a, sum log|diag Luu|, sum log|diag L|,
 // #inf(Sqi) (Sqi may be nullptr); the host adds the KL_BLOCKS partials in order

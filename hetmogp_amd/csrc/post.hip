@@ -37,6 +37,74 @@ __global__ void strict_d_kernel(const double* __restrict__ KiS, double* __restri
   D[o + (long long)r * M + c] = KiS[o + (long long)c * M + r] - (r == c ? 1.0 : 0.0);
 }
 
+// [r6] strict q(f), one-solve form.  With X = K^ Luu^-T (the FORWARD substitution of the reference's dpotrs, svmogp_inf.py:214) the
+// second half of that solve moves from the n x M side onto the M x M side:
+//   A m = X (Luu^-1 m),   A L_q = X (Luu^-1 L_q),   A (S Kuu^-1 - I) = X (Luu^-1 (S Kuu^-1 - I))
+// The three right factors come out of ONE forward row-solve V Luu^T = [ L_q^T ; Kuu^-1 S - I ; m^T ]  (2 M + 1 rows):
+//   rows [0, M)  -> (Luu^-1 L_q)^T,  rows [M, 2 M) -> (Luu^-1 (S Kuu^-1 - I))^T,  row 2 M -> (Luu^-1 m)^T.
+// stack: V[q][i][j] = L[q][j][i] | V[q][M + i][j] = KiS[q][i][j] - (i == j) | V[q][2 M][j] = mu[j][q]     (32 x 32 LDS tiles)
+__global__ __launch_bounds__(256) void strict_stack_kernel(const double* __restrict__ L, const double* __restrict__ KiS,
+                                                           const double* __restrict__ mu, double* __restrict__ V, long long sV,
+                                                           int M, int Q) {
+  __shared__ double tile[32][33];
+  const int q = blockIdx.z, bi = blockIdx.y * 32, bj = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long long MM = (long long)M * M;
+  double* Vq = V + q * sV;
+  for (int r = ty; r < 32; r += 8)                                    // block 0: transpose of L_q
+    tile[r][tx] = (bj + r < M && bi + tx < M) ? L[q * MM + (long long)(bj + r) * M + bi + tx] : 0.0;
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (bi + r < M && bj + tx < M) Vq[(long long)(bi + r) * M + bj + tx] = tile[tx][r];
+  for (int r = ty; r < 32; r += 8)                                    // block 1: Kuu^-1 S - I
+    if (bi + r < M && bj + tx < M)
+      Vq[(long long)(M + bi + r) * M + bj + tx] = KiS[q * MM + (long long)(bi + r) * M + bj + tx] - (bi + r == bj + tx ? 1.0 : 0.0);
+  if (blockIdx.y == 0 && ty == 0 && bj + tx < M) Vq[2LL * M * M + bj + tx] = mu[(long long)(bj + tx) * Q + q];
+}
+// unstack: W[q][i][j] = V[q][j][i],  W2[q][i][j] = V[q][M + j][i],  w3[q][j] = V[q][2 M][j]
+__global__ __launch_bounds__(256) void strict_unstack_kernel(const double* __restrict__ V, long long sV, double* __restrict__ W,
+                                                             double* __restrict__ W2, double* __restrict__ w3, int M) {
+  __shared__ double tile[2][32][33];
+  const int q = blockIdx.z, bi = blockIdx.y * 32, bj = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long long MM = (long long)M * M;
+  const double* Vq = V + q * sV;
+  for (int r = ty; r < 32; r += 8) {
+    const bool in = bj + r < M && bi + tx < M;
+    tile[0][r][tx] = in ? Vq[(long long)(bj + r) * M + bi + tx] : 0.0;
+    tile[1][r][tx] = in ? Vq[(long long)(M + bj + r) * M + bi + tx] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (bi + r < M && bj + tx < M) {
+      W[q * MM + (long long)(bi + r) * M + bj + tx] = tile[0][tx][r];
+      W2[q * MM + (long long)(bi + r) * M + bj + tx] = tile[1][tx][r];
+    }
+  if (blockIdx.y == 0 && ty == 0 && bj + tx < M) w3[(long long)q * M + bj + tx] = Vq[2LL * M * M + bj + tx];
+}
+// B[q][j][i] = A[q][i][j]   (batched M x M transpose, strides sA / sB)
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ A, long long sA, double* __restrict__ B, long long sB,
+                                                        int M) {
+  __shared__ double tile[32][33];
+  const int q = blockIdx.z, bi = blockIdx.y * 32, bj = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = (bi + r < M && bj + tx < M) ? A[q * sA + (long long)(bi + r) * M + bj + tx] : 0.0;
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (bj + r < M && bi + tx < M) B[q * sB + (long long)(bj + r) * M + bi + tx] = tile[tx][r];
+}
+
+// out[q] = variance_q * max_i (K_uu^-1)_ii  -- the condition estimate of hmogp_outputs.cond_est, early (strict q(f): which form)
+__global__ __launch_bounds__(256) void cond_probe_kernel(const double* __restrict__ Kuui, const double* __restrict__ var, int M,
+                                                         double* __restrict__ out) {
+  __shared__ double sm[4];
+  const int q = blockIdx.x, t = threadIdx.x;
+  double k = 0.0;
+  for (int i = t; i < M; i += 256) k = fmax(k, Kuui[(long long)q * M * M + (long long)i * M + i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) k = fmax(k, __shfl_xor(k, o, 64));
+  if ((t & 63) == 0) sm[t >> 6] = k;
+  __syncthreads();
+  if (t == 0) out[q] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3])) * var[q];
+}
+
 // T = tril(C) + tril(C^T, -1): the lower-triangular matrix with x^T T x == x^T C x (C need not be exactly symmetric).
 // With it the quadratic forms k^T C k of the forward contraction cost half the products (GemmArgs::b_tri).
 __global__ void tri_fold_kernel(const double* __restrict__ C, double* __restrict__ T, int M) {
@@ -343,6 +411,18 @@ void launch_identity(double* A, int Q, int M, hipStream_t s) {
 }
 void launch_strict_d(const double* KiS, double* D, int Q, int M, hipStream_t s) {
   hipLaunchKernelGGL(strict_d_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, KiS, D, M);
+}
+void launch_cond_probe(const double* Kuui, const double* var, int Q, int M, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(cond_probe_kernel, dim3(Q), dim3(256), 0, s, Kuui, var, M, out);
+}
+void launch_strict_stack(const double* L, const double* KiS, const double* mu, double* V, long long sV, int Q, int M, hipStream_t s) {
+  hipLaunchKernelGGL(strict_stack_kernel, dim3((M + 31) / 32, (M + 31) / 32, Q), dim3(256), 0, s, L, KiS, mu, V, sV, M, Q);
+}
+void launch_strict_unstack(const double* V, long long sV, double* W, double* W2, double* w3, int Q, int M, hipStream_t s) {
+  hipLaunchKernelGGL(strict_unstack_kernel, dim3((M + 31) / 32, (M + 31) / 32, Q), dim3(256), 0, s, V, sV, W, W2, w3, M);
+}
+void launch_transpose_batched(const double* A, long long sA, double* B, long long sB, int Q, int M, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((M + 31) / 32, (M + 31) / 32, Q), dim3(256), 0, s, A, sA, B, sB, M);
 }
 void launch_tri_fold(const double* C, double* T, int Q, int M, hipStream_t s) {
   hipLaunchKernelGGL(tri_fold_kernel, dim3((M + 255) / 256, M, Q), dim3(256), 0, s, C, T, M);

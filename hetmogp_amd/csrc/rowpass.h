@@ -50,7 +50,8 @@ struct StrictRows {
   int phase = 0, M = 0, Q = 1, P = 1, ldz = 0;
   long long n = 0, ldn = 0, sK = 0, sZ = 0;
   const double *Kh = nullptr, *Ah = nullptr, *Tt = nullptr, *Pt = nullptr;   // [Q][sK] row-major n x M
-  const double* mu = nullptr;     // [M][Q] q_u_means
+  const double* mu = nullptr;     // [M][Q] q_u_means                     (two-solve form: Ah holds A = K^ Kuu^-1)
+  const double* w3 = nullptr;     // [Q][M] Luu^-1 m_q  ([r6] one-solve form: Ah holds X = K^ Luu^-T; nullptr = two-solve form)
   const double* a = nullptr;      // [Q][M] Kuu^-1 m
   const double *X = nullptr, *Z = nullptr, *ell = nullptr;
   double *p = nullptr, *c = nullptr, *pg = nullptr, *cg = nullptr, *pt = nullptr, *ct = nullptr;   // [Q][ldn]
@@ -63,6 +64,32 @@ void launch_strict_rowstats(const StrictRows& a, hipStream_t s);
 void launch_trsm_diag(int dir, double* V, long long sV, const double* L, long long sL, int M, int j0, int nb, long long n, int Q,
                       hipStream_t s, int u0 = 0, int u1 = 0, const double* Vsrc = nullptr);
 bool trsm_diag_can_fuse(const double* V, long long sV, int M);
+// [r6] one 128-column block of the same solves as ONE launch: long-K update + in-tile substitution (trsm_panel.hip)
+struct TrsmPanelArgs {
+  double* V = nullptr;             // [Q][sV]: n x M row-major (ldv), solved in place
+  const double* Vsrc = nullptr;    // optional: this block's right-hand sides are read from here (first touch of the forward solve)
+  long long sV = 0;
+  int ldv = 0;
+  const double* Lsym = nullptr;    // [Q][sL]: the factor mirrored into a full symmetric image (launch_mirror_lower), ldl
+  long long sL = 0;
+  int ldl = 0;
+  const double* rdiag = nullptr;   // [Q][sR]: 1 / Luu[j][j]  (launch_rdiag)
+  long long sR = 0;
+  long long n = 0;
+  int M = 0, j0 = 0, Q = 1;
+  // row statistics of the solved tile in the epilogue of the LAST direction a caller runs (nullptr: none):
+  //   sp += tile . st_vec[columns],   sk += rowsum(tile .* st_K)  -- or rowsum(tile .* tile) when st_K is null
+  const double* st_K = nullptr;    // same layout as V
+  const double* st_vec = nullptr;  // element (column j, batch q) at st_vec[q * st_vecB + j * st_vecS]
+  long long st_vecB = 0, st_vecS = 1;
+  double* st_part = nullptr;       // [Q][st_sPart]: [2 statistics][4 wave columns][st_ld]
+  long long st_sPart = 0, st_ld = 0;
+};
+bool trsm_panel_eligible(const TrsmPanelArgs& g);
+void launch_trsm_panel(int dir, const TrsmPanelArgs& g, hipStream_t s);
+void launch_rdiag(const double* L, long long sL, int M, int Q, double* out, long long sR, hipStream_t s);
+void launch_trsm_stats_combine(const double* part, long long sPart, long long ld, int nparts, long long n, int Q, const double* t2,
+                               double* p, double* c, long long ldn, hipStream_t s);
 
 // [r4] every segment (task x row range) of a pool in one launch -- small models only: the weights are read from device memory
 #define HMOGP_QUAD_MULTI 8

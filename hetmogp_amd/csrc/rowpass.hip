@@ -1013,8 +1013,9 @@ void launch_sum_cols(const double* v, int Q, int M, double* dst, long long sDst,
 }
 
 // ---- strict q(f) (HMOGP_CFG_STRICT_QF): row statistics of the solve-based forms of svmogp_inf.py:212-218 ------------------------
-// One wave per row.  phase 0:  p = A m_q,  c = rowsum(T .* T) - rowsum(A .* K^)    with A = K^ Kuu^-1 (two triangular products
-// against Luu^-1), T = A L_q  ==  the reference's  sum(square(dtrmm(L_q^T, R)), 0) - sum(R * Kfu^T, 0)  with R = dpotrs(Luu, Kfu^T).
+// One wave per row.  phase 0:  p = A m_q,  c = rowsum(T .* T) - rowsum(A .* K^)    with A = K^ Kuu^-1, T = A L_q  ==  the reference's
+// sum(square(dtrmm(L_q^T, R)), 0) - sum(R * Kfu^T, 0)  with R = dpotrs(Luu, Kfu^T) -- [r6] through X = K^ Luu^-T alone:
+// p = X (Luu^-1 m), rowsum(A .* K^) = rowsum(X .* X), T = X (Luu^-1 L_q)  (the fallback of trsm_panel.hip's fused statistics).
 // phase 1:  pg = K^ a,  cg = rowsum(P~ .* K^)  and their r2-weighted twins pt, ct, with P~ = A (S Kuu^-1 - I): what the reference's
 // dL_dKmn (svmogp_inf.py:157-161) reduces to against K^ in svmogp.py:116-156.
 template <int P>
@@ -1027,11 +1028,14 @@ __global__ __launch_bounds__(256) void strict_rowstats_kernel(StrictRows a) {
   if (a.phase == 0) {
     const double* ah = a.Ah + q * a.sK + n * M;
     double sp = 0.0, st = 0.0, sk = 0.0;
+    // [r6] one-solve form: `Ah` holds X = K^ Luu^-T;  A m = X (Luu^-1 m) = X w3,  rowsum(A .* K^) = rowsum(X .* X)
+    // (two-solve form, a.w3 == nullptr: `Ah` holds A itself -- p = A m, rowsum(A .* K^))
+    const double* w3 = a.w3 ? a.w3 + (long long)q * M : nullptr;
     if (a.t2) {        // rowsum(T .* T) came out of the product's epilogue (gemm_rowpass.hip, fs_sq): T was never stored
       for (int m = lane; m < M; m += 64) {
         const double av = ah[m];
-        sp += av * a.mu[(long long)m * a.Q + q];
-        sk += av * kh[m];
+        sp += av * (w3 ? w3[m] : a.mu[(long long)m * a.Q + q]);
+        sk += av * (w3 ? av : kh[m]);
       }
       sp = wave_sum(sp), sk = wave_sum(sk);
       if (lane == 0) a.p[q * a.ldn + n] = sp, a.c[q * a.ldn + n] = a.t2[q * a.ldn + n] - sk;
@@ -1040,9 +1044,9 @@ __global__ __launch_bounds__(256) void strict_rowstats_kernel(StrictRows a) {
     const double* tt = a.Tt + q * a.sK + n * M;
     for (int m = lane; m < M; m += 64) {
       const double av = ah[m], tv = tt[m];
-      sp += av * a.mu[(long long)m * a.Q + q];
+      sp += av * (w3 ? w3[m] : a.mu[(long long)m * a.Q + q]);
       st += tv * tv;
-      sk += av * kh[m];
+      sk += av * (w3 ? av : kh[m]);
     }
     sp = wave_sum(sp), st = wave_sum(st), sk = wave_sum(sk);
     if (lane == 0) a.p[q * a.ldn + n] = sp, a.c[q * a.ldn + n] = st - sk;

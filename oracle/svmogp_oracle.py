@@ -315,6 +315,15 @@ def u_algebra(prm, prob, forced_rungs=None):
         u["C"].append(Kuui[q] @ S_q @ Kuui[q] - Kuui[q])
         if prob.get("strict_qf"):      # the engine's HMOGP_CFG_STRICT_QF algebra (see local_stats)
             u["D"].append(S_q @ Kuui[q] - np.eye(M))                   # svmogp_inf.py:157-158 (tmp / 2)
+    # [r6] which strict form (engine_impl.h: strict_two): "one_solve" = the engine's E-step / prediction form while the condition
+    # estimate variance max diag(Kuu^-1) of every latent is <= 1e6; anything else truthy = the literal two-solve form
+    sq = prob.get("strict_qf")
+    if sq:
+        est = max(float(prm["variance"][q] * np.max(np.diag(Kuui[q]))) for q in range(Q))
+        # (the engine also takes the two-solve form whenever an evaluation needs P~, i.e. hyper-parameter / Z gradients: formed as
+        #  X (Luu^-1 D) its rounding error is sqrt(cond) times A D's.  The oracle computes every gradient group in one go, so
+        #  strict_qf=True means the two-solve form here too; "one_solve" = the E-step / prediction form.)
+        u["strict_two"] = sq != "one_solve" or not (est <= 1e6)
     return u
 
 
@@ -322,8 +331,11 @@ def local_stats(prm, prob, u, X, Y, batch_scale=None):
     """Row pass over this shard's rows (additive over shards).  Returns the flat statistic bundle.
 
     prob["strict_qf"] = True restates the engine's HMOGP_CFG_STRICT_QF mode: q(f) and the row side of the gradients through
-    A = K^ Kuu^-1 formed by two triangular solves against Luu (the reference's dpotrs, svmogp_inf.py:214-218), the bundle's H / r
-    slots then hold dVE_dS = A^T diag(beta) A and dVE_dmu = A^T alpha (:144-148) and P~ = A (S Kuu^-1 - I) (:157-161)."""
+    triangular solves against Luu (the reference's dpotrs, svmogp_inf.py:214-218) -- since round 6 with only the FORWARD half of
+    that solve on the n x M side (X = K^ Luu^-T; see the branch below), the bundle's H / r slots hold X^T diag(beta) X and X^T alpha
+    and `finish` turns them into dVE_dS / dVE_dmu (:144-148); P~ = A (S Kuu^-1 - I) = X (Luu^-1 (S Kuu^-1 - I)) (:157-161).
+    Beyond a condition estimate of 1e6 (and with prob["strict_qf"] = "two_solves"): the literal two-solve form (A = dpotrs, H = A^T
+    diag(beta) A in the bundle), as in round 5; prob["strict_qf"] = "one_solve" forces the other one."""
     Q, M, P, T, Df = prob["Q"], prob["M"], prob["P"], prob["T"], prob["Df"]
     lay = stats_layout(prob)
     batch_scale = [1.0] * T if batch_scale is None else list(batch_scale)
@@ -344,7 +356,22 @@ def local_stats(prm, prob, u, X, Y, batch_scale=None):
             ell = prm["lengthscale"][q]
             r2 = rbf_r2_scaled(Xt, Zq, ell)
             K = prm["variance"][q] * np.exp(-0.5 * r2)
-            if strict:
+            if strict and not u["strict_two"]:
+                # [r6] the engine's strict mode (HMOGP_CFG_STRICT_QF) since round 6, while the condition estimate of K_uu is <= 1e6
+                # (u_algebra: strict_two): ONE triangular solve on the n x M side.  With X = K^ Luu^-T
+                # (forward substitution of dpotrs, svmogp_inf.py:214) the second half of the solve moves onto the M x M side:
+                #   A m = X (Luu^-1 m),  A L_q = X (Luu^-1 L_q),  rowsum(A .* K^) = rowsum(X .* X)  (K^ = X Luu^T),
+                #   A (S Kuu^-1 - I) = X (Luu^-1 (S Kuu^-1 - I)),  A^T diag(b) A = Luu^-T (X^T diag(b) X) Luu^-1 (finish)
+                # -- the same quantities as the reference's forms, each through triangular SOLVES against Luu (never through the
+                # explicit difference K^-1 S K^-1 - K^-1 whose cancellation costs the default path cond(K_uu) digits).
+                Xm = scipy.linalg.solve_triangular(u["Luu"][q], K.T, lower=True).T
+                PP = Xm @ scipy.linalg.solve_triangular(u["Luu"][q], u["D"][q], lower=True)
+                Tm = Xm @ scipy.linalg.solve_triangular(u["Luu"][q], u["L"][q], lower=True)
+                Am.append(Xm)
+                p.append(Xm @ scipy.linalg.solve_triangular(u["Luu"][q], prm["m_u"][:, q], lower=True))
+                c.append(np.sum(Tm * Tm, 1) - np.sum(Xm * Xm, 1))
+                pg.append(K @ u["a"][q]), cg.append(np.sum(PP * K, 1))
+            elif strict:
                 V = scipy.linalg.solve_triangular(u["Luu"][q], K.T, lower=True)                  # two triangular SOLVES
                 A = scipy.linalg.solve_triangular(u["Luu"][q], V, lower=True, trans="T").T       # (= dpotrs, :214)
                 PP = A @ u["D"][q]
@@ -427,7 +454,12 @@ def finish(prm, prob, u, stats, stochastic=False, vem_step=True, z_fixed=False):
         S_qi, _ = potri_sym(L_q)
         if np.any(np.isinf(S_qi)):
             raise ValueError("Sqi: Cholesky representation unstable")
-        if prob.get("strict_qf"):      # the bundle already holds dVE_dS and dVE_dmu
+        if prob.get("strict_qf") and not u["strict_two"]:   # the bundle holds X^T diag(beta) X, X^T alpha (X = K^ Luu^-T)
+            Y1 = scipy.linalg.solve_triangular(u["Luu"][q], H, lower=True, trans="T")            # Luu^-T H
+            G = scipy.linalg.solve_triangular(u["Luu"][q], Y1.T, lower=True, trans="T")          # Luu^-T H Luu^-1 (H symmetric)
+            G = 0.5 * (G + G.T)
+            Kr = scipy.linalg.solve_triangular(u["Luu"][q], r, lower=True, trans="T")
+        elif prob.get("strict_qf"):      # the bundle already holds dVE_dS and dVE_dmu
             G, Kr = H, r
         else:
             G = Ki @ H @ Ki

@@ -279,3 +279,46 @@ def test_strict_equals_default_where_K_uu_is_well_conditioned():
         assert rel_norm(a[k], g[k]) < 1e-8, k
     for k in qa:
         assert rel_norm(qa[k], qb[k]) < 1e-9, k
+
+
+@pytest.mark.parametrize("name", ["lad_h_mix_M128_ladder.npz", "lad_c1_offset_rung1.npz", "ref_h_mix_M128.npz"])
+def test_strict_e_step_one_solve_form_vs_reference_run(name):
+    """[r6] The strict mode's ONE-SOLVE form (E-steps and predictions: X = K^ Luu^-T only, the backward half of the reference's dpotrs
+    moved onto M x M factors) against the reference's own runs where GPy's jitter ladder is taken: ELBO, KL and the q(u)
+    gradients of an evaluation with group_mask = QU -- what `stochastic_grad` asks for in 4 of 5 SVI iterations (svmogp.py:188-199)
+    and every L-BFGS iteration of a VE step (util.py:294-306) -- under the element-wise 1e-5 criterion; q(f) through predict_f; and
+    the proof that it IS another form: its bundle's H slot holds X^T diag(beta) X, not A^T diag(beta) A."""
+    from hetmogp_amd import _lib
+    from hetmogp_amd.engine import Engine
+    from oracle import svmogp_oracle as so
+    g = np.load(os.path.join(GOLDEN, name))
+    prm, prob, X, Y, bs = so.load_case(g)
+    args = dict(Z=prm["Z"], m_u=prm["m_u"], L_flat=prm["L_flat"], variance=prm["variance"], lengthscale=prm["lengthscale"],
+                W=prm["W"], kappa=prm["kappa"], W0=prm.get("W0"), batch_scale=bs)
+    e = Engine(prob["specs"], prob["Q"], prob["M"], prob["P"], strict_qf=True)
+    e.set_data(X, Y)
+    out = e.elbo_grad(group_mask=_lib.GROUP_QU, **args)
+    if "rungs" in g.files:
+        assert out["rungs"] == [int(r) for r in g["rungs"]]
+    for k in ("elbo", "KL", "g_m_u", "g_L_u"):
+        assert rel_norm(out[k], g[k]) < 1e-7, (k, rel_norm(out[k], g[k]))
+        assert elementwise_excess(out[k], g[k]) <= 1.0, (k, elementwise_excess(out[k], g[k]))
+    assert not np.any(out["g_Z"]) and not np.any(out["g_W"])
+    for t in range(prob["T"]):
+        m, v = e.predict_f(X[t])
+        for d in range(prob["Df"]):
+            if prob["f_index"][d] == t:
+                assert elementwise_excess(m[:, d], g["m_fd_%d" % d][:, 0]) <= 1.0, ("m_fd", d)
+                assert elementwise_excess(v[:, d], g["v_fd_%d" % d][:, 0]) <= 1.0, ("v_fd", d)
+    # the two forms leave different statistics in the bundle (and the same gradients after `finish`)
+    M, Q = prob["M"], prob["Q"]
+    e.step_begin(group_mask=_lib.GROUP_QU, **args)
+    h_one = e.stats_read()[2 + prob["Df"]:2 + prob["Df"] + M * M].copy()
+    one = e.step_finish()
+    e.step_begin(group_mask=_lib.GROUP_ALL, **args)
+    h_two = e.stats_read()[2 + prob["Df"]:2 + prob["Df"] + M * M].copy()
+    two = e.step_finish()
+    assert rel_norm(h_one, h_two) > 1e-3
+    for k in ("elbo", "g_m_u", "g_L_u"):
+        assert rel_norm(one[k], two[k]) < 1e-8, (k, rel_norm(one[k], two[k]))
+    e.close()
