@@ -713,20 +713,47 @@ def other_configs(args):
           800000, 3, 1024, ms, cat, out, tag="HD", finite=bool(np.isfinite(out["elbo"])),
           note="timing record only: K_uu at this lengthscale is numerically singular, the ELBO is not a parity quantity")
     eng.close()
-    # HS -- the headline workload in the STRICT q(f) mode (HMOGP_CFG_STRICT_QF, DESIGN 6a: the reference's solve-based forms through
-    # blocked triangular solves; what parity in the jitter-ladder regime costs).  Reported beside `value`, never mixed into it.
+    # HS / HSE -- the headline workload in the STRICT q(f) mode (HMOGP_CFG_STRICT_QF, DESIGN 6a / 13: the reference's solve-based forms;
+    # what parity in the jitter-ladder regime costs).  Reported beside `value`, never mixed into it.  HS = a full-gradient evaluation
+    # (two-solve form: A = dpotrs on the n x M side), HSE = an evaluation that asks for the q(u) gradients only (one-solve form).
+    # [r6] per-kernel `roofline` entries: engine timing categories 9 / 10 separate the triangular solves and the
+    # strict row statistics from the products (HIP events of this run).
     prm, X, Y = make_case(SPECS, [200000] * 4, M=1024, Q=3, P=1, seed=20260929)
     eng = Engine(SPECS, 3, 1024, 1, reuse_outputs=True, strict_qf=True)
     eng.set_data(X, Y)
-    ms, cat, out = _time_steps(eng, prm, min(K, 3), warmup=1)
-    fl_strict = (5.0 + 1.0) * 800000 * 3 * 1024 ** 2 + 20.0 * 3 * 1024 ** 3   # two solves n M^2 each, T n M^2, P~ 2 n M^2, Gram n M^2
-    res.append({"workload": "HS: headline workload in the strict q(f) mode (HMOGP_CFG_STRICT_QF)", "ms_per_step": ms,
-                "steps_per_s": 1e3 / ms, "flops_executed": fl_strict, "tflops": fl_strict / ms / 1e9,
-                "frac_of_peak": fl_strict / ms / 1e9 / PEAK_FP64_MFMA_TFLOPS,
-                "kernel_ms_per_step": {k: round(v, 4) for k, v in cat.items()}, "elbo": out["elbo"], "steps": min(K, 3),
-                "cond_est": [float(c) for c in out["cond_est"]], "ill_conditioned": bool(out["ill_conditioned"]),
-                "note": "parity mode, not the headline: 6 n Q M^2 contraction flops instead of 3 n Q M^2 (two blocked triangular "
-                        "solves with true 32-column substitution steps, their in-block updates fused into the substitution launches)"})
+    nqm2 = 800000.0 * 3 * 1024 ** 2
+    from hetmogp_amd import _lib as _hl
+
+    def strict_entry(tag, name, mask, solves, flops_rows, note):
+        ms, cat, out = _time_steps(eng, prm, min(K, 3), warmup=1, group_mask=mask)
+        fl = flops_rows * nqm2 + 20.0 * 3 * 1024 ** 3
+
+        def rl(kernel, bound, work, unit_ms, peak, unit):
+            ach = work / (unit_ms / 1e3) / (1e12 if unit == "TFLOP/s" else 1e9) if unit_ms > 0 else 0.0
+            return {"kernel": kernel, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                    "ms_per_step": unit_ms, "traffic": None}
+        prod = (1.0 + (2.0 if mask != _hl.GROUP_QU else 0.0)) * nqm2          # T = A L_q (fold: n M^2) [+ P~ = A D: 2 n M^2]
+        rls = [rl("trsm_panel_kernel<0|1> (%d blocked triangular solve(s): long-K update + in-tile substitution per 128-column block)"
+                  % solves, "mfma", solves * nqm2, cat["trsm_solves"], PEAK_FP64_MFMA_TFLOPS, "TFLOP/s"),
+               rl("rowpass_fold_pair_kernel (T = A L_q, rowsum(T^2) in the epilogue)%s" %
+                  (" + rowpass_gemm_kernel<1> (P~ = A (S Kuu^-1 - I))" if mask != _hl.GROUP_QU else ""), "mfma", prod,
+                  cat["forward_gemm"], PEAK_FP64_MFMA_TFLOPS, "TFLOP/s"),
+               rl("rowpass_gemm_kernel<2> (Gram of A / of X, lower tiles)", "mfma", nqm2, cat["gram_gemm"], PEAK_FP64_MFMA_TFLOPS,
+                  "TFLOP/s")]
+        if cat.get("strict_rowstats", 0.0) > 0:
+            stat_bytes = (8.0 * 800000 * 3 * 1024 * 2) if mask != _hl.GROUP_QU else 8.0 * 800000 * 3 * 10   # phase 1 streams K^ and P~
+            rls.append(rl("strict_rowstats_kernel / trsm_stats_combine_kernel", "hbm", stat_bytes, cat["strict_rowstats"], PEAK_HBM_GBS,
+                          "GB/s"))
+        res.append({"workload": name, "ms_per_step": ms, "steps_per_s": 1e3 / ms, "flops_executed": fl, "tflops": fl / ms / 1e9,
+                    "frac_of_peak": fl / ms / 1e9 / PEAK_FP64_MFMA_TFLOPS, "roofline": rls,
+                    "kernel_ms_per_step": {k: round(v, 4) for k, v in cat.items()}, "elbo": out["elbo"], "steps": min(K, 3),
+                    "cond_est": [float(c) for c in out["cond_est"]], "ill_conditioned": bool(out["ill_conditioned"]), "note": note})
+    strict_entry("HS", "HS: headline workload in the strict q(f) mode (HMOGP_CFG_STRICT_QF), full gradients", _hl.GROUP_ALL, 2, 6.0,
+                 "parity mode, not the headline: 6 n Q M^2 contraction flops instead of 3 n Q M^2 (two blocked triangular solves -- ONE "
+                 "launch per 128-column block and direction since round 6: 298.7 ms in BENCH_r05 --, T = A L_q, P~ = A D, Gram of A)")
+    strict_entry("HSE", "HSE: headline workload in the strict q(f) mode, q(u) gradients only (an E-step: group_mask = QU)", _hl.GROUP_QU,
+                 1, 3.0, "one-solve form (round 6): only the forward substitution X = K^ Luu^-T touches the n x M side; "
+                 "3 n Q M^2 contraction flops (solve, T = X (Luu^-1 L_q), Gram of X)")
     eng.close()
     return res
 

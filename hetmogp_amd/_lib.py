@@ -10,12 +10,12 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMOGP_LIB_PATH") or os.path.join(_HERE, "libhetmogp_hip.so")   # (override: A/B experiments)
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 # likelihood ids (class names of the reference's likelihoods/<name>.py)
 LIK_GAUSSIAN, LIK_BERNOULLI, LIK_HETGAUSSIAN, LIK_CATEGORICAL, LIK_POISSON, LIK_EXPONENTIAL, LIK_GAMMA, LIK_BETA = range(8)
 LIK_IDS_BY_NAME = dict(Gaussian=0, Bernoulli=1, HetGaussian=2, Categorical=3, Poisson=4, Exponential=5, Gamma=6, Beta=7)
 E_INVALID, E_NO_DEVICE, E_NOT_PD, E_SQI_UNSTABLE, E_STATE, E_COMM = -1, -2, -3, -4, -5, -6
-NTIMINGS = 9
+NTIMINGS = 11
 COMM_ID_BYTES = 128
 FLAG_V_NEGATIVE = 1
 FLAG_ILL_CONDITIONED = 2

@@ -94,7 +94,7 @@ struct DevBuf {
 
 constexpr int FWD_PARTS = GEMM_MAX_FWD_PARTS;  // buffer sizing: partials of the fused row statistics per 128-column tile
 
-enum { CAT_TOTAL = 0, CAT_RBF, CAT_FWD, CAT_ROWSTATS, CAT_QUAD, CAT_GRAM, CAT_COLSTATS, CAT_MM, CAT_EXCHANGE, NCAT };
+enum { CAT_TOTAL = 0, CAT_RBF, CAT_FWD, CAT_ROWSTATS, CAT_QUAD, CAT_GRAM, CAT_COLSTATS, CAT_MM, CAT_EXCHANGE, CAT_TRSM, CAT_STRICT_STATS, NCAT };
 static_assert(NCAT == HMOGP_NTIMINGS, "hmogp_last_timings layout");
 
 struct Task {

@@ -260,7 +260,6 @@ void hmogp_engine::strict_factor_images() {
 
 void hmogp_engine::strict_forward(long long n, const double* X, bool grads, bool hyper) {
   const long long MM = (long long)M * M, ldn = ws_rows, sK = ldn * M;
-  Scope sc(this, CAT_FWD, 4 * ((M + 31) / 32) + (grads ? 4 : 2));
   auto rows_gemm = [&](const double* A_, const double* B_, int b_kmajor, int b_tri, double* C_) {
     GemmArgs g;
     g.A = A_, g.lda = M, g.a_kmajor = 0, g.sA = sK;
@@ -288,14 +287,19 @@ void hmogp_engine::strict_forward(long long n, const double* X, bool grads, bool
     const char* e = getenv("HMOGP_TRSM_STATS");
     return !(e && e[0] == '0');
   }();
-  const bool stats_fused = potrs_rows_inplace(Ah.d(), sK, Luu.d(), MM, M, n, Q, st, Lsy.d(), Kh.d(), rdiag.d(), ts_env ? &ts : nullptr,
-                                              strict_two ? 3 : 1, lsym_valid);
+  bool stats_fused = false;
+  {
+    Scope sc(this, CAT_TRSM, (strict_two ? 2 : 1) * ((M + 127) / 128));
+    stats_fused = potrs_rows_inplace(Ah.d(), sK, Luu.d(), MM, M, n, Q, st, Lsy.d(), Kh.d(), rdiag.d(), ts_env ? &ts : nullptr,
+                                     strict_two ? 3 : 1, lsym_valid);
+  }
   const double* Bt = strict_two ? L.d() : Wq.d();       // right factor of T:  A L_q  |  X (Luu^-1 L_q)      (both lower triangular)
   const double* Bp = strict_two ? D2.d() : Dm.d();      // right factor of P~: A (S Kuu^-1 - I)  |  X (Luu^-1 (S Kuu^-1 - I))
   // T = A L_q = X Wq = dtrmm(L_q^T, R)^T (:217) is only ever consumed as rowsum(T .* T) (:218): where the specialised fold kernel takes
   // the product, its epilogue forms that sum from the accumulators and T is neither written nor read back (2 x 19.7 GB at H)
   bool t2_fused = false;
   {
+    Scope sc(this, CAT_FWD, 2);
     GemmArgs g;
     g.A = Ah.d(), g.lda = M, g.a_kmajor = 0, g.sA = sK;
     g.B = Bt, g.ldb = M, g.b_kmajor = 1, g.sB = MM, g.b_tri = +1;
@@ -324,13 +328,20 @@ void hmogp_engine::strict_forward(long long n, const double* X, bool grads, bool
   sr.p = vp.d(), sr.c = vc.d(), sr.pg = vpg.d(), sr.cg = vcg.d(), sr.pt = hyper ? vpt.d() : nullptr, sr.ct = hyper ? vct.d() : nullptr;
   sr.phase = 0;
   sr.t2 = t2_fused ? vct.d() : nullptr;           // (vct: free until phase 1 writes the r2-weighted twin into it)
-  if (stats_fused && t2_fused)                    // p = A m, c = rowsum(T^2) - rowsum(A .* K^)   (:216, :218)
-    launch_trsm_stats_combine(trsmpart.d(), ts.sPart, ldn, 4, n, Q, vct.d(), vp.d(), vc.d(), ldn, st);
-  else
-    launch_strict_rowstats(sr, st);
+  {
+    Scope sc(this, CAT_STRICT_STATS, 1);
+    if (stats_fused && t2_fused)                  // p = A m, c = rowsum(T^2) - rowsum(A .* K^)   (:216, :218)
+      launch_trsm_stats_combine(trsmpart.d(), ts.sPart, ldn, 4, n, Q, vct.d(), vp.d(), vc.d(), ldn, st);
+    else
+      launch_strict_rowstats(sr, st);
+  }
   sr.t2 = nullptr;
   if (!grads) return;
-  rows_gemm(Ah.d(), Bp, 1, 0, Pt.d());            // P~ = A (S Kuu^-1 - I) = X Dm               (:157-161)
+  {
+    Scope sc(this, CAT_FWD, 1);
+    rows_gemm(Ah.d(), Bp, 1, 0, Pt.d());          // P~ = A (S Kuu^-1 - I)                      (:157-161)
+  }
+  Scope sc(this, CAT_STRICT_STATS, 1);
   sr.phase = 1;
   launch_strict_rowstats(sr, st);                 // K^ a, rowsum(P~ .* K^) and their r2-weighted twins
 }

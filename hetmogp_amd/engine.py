@@ -387,7 +387,7 @@ class Engine(object):
         n = np.zeros(_lib.NTIMINGS, dtype=np.int64)
         check(lib.hmogp_last_timings(self._h, _p(ms), n.ctypes.data_as(_lib.c_int64_p)), self._h)
         names = ["total", "rbf_cross_cov", "forward_gemm", "rowstats_combine", "quadrature", "gram_gemm", "colstats_reduce",
-                 "mxm_algebra", "exchange"]
+                 "mxm_algebra", "exchange", "trsm_solves", "strict_rowstats"]   # (the last two: strict q(f) mode only, ABI v8)
         return dict(zip(names, ms.tolist())), dict(zip(names, n.tolist()))
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMOGP_ABI_VERSION 7
+#define HMOGP_ABI_VERSION 8
 
 /* likelihood ids (class names of /root/reference/likelihoods/<name>.py) */
 enum {
@@ -118,8 +118,14 @@ typedef struct {
    A (S K_uu^-1 - I) at :144-161); the default path uses the algebraically equal explicit C_q = K_uu^-1 S K_uu^-1 - K_uu^-1, which
    differs from that by ~cond(K_uu) * 2^-53.  Once GPy's jitter ladder is taken (cond ~ 1e7) the default path's g_W / g_kappa / g_Z
    are 1e-4 .. 1e-3 away from the reference's; with this flag the engine follows the reference's forms (two blocked triangular
-   solves against Luu, the Gram of A, ...) and stays within 1e-5 element-wise there (tests/test_gpu_ladder.py).  ~2.5x the step
-   time, regular kernels only (no fused small-model path), excludes HMOGP_CFG_EXACT_ZERO_WINDOWS.  bench.py never sets it.   */
+   solves against Luu, the Gram of A, ...) and stays within 1e-5 element-wise there (tests/test_gpu_ladder.py).  Regular kernels
+   only (no fused small-model path), excludes HMOGP_CFG_EXACT_ZERO_WINDOWS.  bench.py's `value` never uses it.
+   (ABI v8) Cost at the headline size: 2.25x the default step for a full-gradient evaluation (269 vs 119.5 ms; 2.5x in ABI v7),
+   1.6x for an evaluation that asks for the q(u) gradients only (136 vs 84 ms): such evaluations, and hmogp_predict_f, take the
+   ONE-SOLVE form -- only the forward substitution X = K_fu Luu^-T touches the n x M side, the backward half of dpotrs sits in
+   M x M factors (A m = X (Luu^-1 m), A L_q = X (Luu^-1 L_q), rowsum(A .* K_fu) = rowsum(X .* X), A^T diag(b) A =
+   Luu^-T (X^T diag(b) X) Luu^-1) -- while every evaluation that needs A (S K_uu^-1 - I) (hyper-parameter / Z gradients) or whose
+   own K_uu is beyond the condition estimate 1e6 keeps the literal two-solve form.                              */
 #define HMOGP_CFG_NO_SMALL_PATH 4u /* ABI v5: keep the regular kernels and three streams also for small models (M <= 64 would
                                     * otherwise take the fused small-model kernels, M <= 128 with <= 65536 rows one stream): A/B
                                     * comparisons of the two paths inside one process (tests)                                */
@@ -151,7 +157,8 @@ typedef struct {
   const int32_t* forced_rung; /* [Q] or NULL: -2 = run GPy's jitter ladder, -1 = no jitter,
                                  k>=0 = jitter mean(diag)*1e-6*10^k (compare CPU/GPU at equal rung)   */
   uint32_t group_mask;        /* HMOGP_GROUP_*                                                        */
-  uint32_t eval_flags;        /* HMOGP_EVAL_* of THIS evaluation (0 = none)                 (ABI version 6) */
+  uint32_t eval_flags;        /* HMOGP_EVAL_* of THIS evaluation (0 = none; (ABI v8) unknown bits are refused
+                                 with HMOGP_E_INVALID: zero the struct before filling it)   (ABI version 6) */
 } hmogp_params;
 #define HMOGP_EVAL_STRICT_QF 1u /* run this evaluation in the strict q(f) mode (see HMOGP_CFG_STRICT_QF) whatever the engine was
    created with: lets a caller re-evaluate, and go on evaluating, in that mode once hmogp_outputs.flags reported
@@ -309,9 +316,11 @@ int hmogp_qu_adadelta(hmogp_handle h, int32_t phase, double step_rate, double mo
  * N x M x M contraction incl. its fused row-statistics epilogue (ONE kernel per launch, all latents of a task chunk),
  * [3] combine of the row-statistic partials, [4] quadrature, [5] weighted Gram contraction (ONE kernel per launch),
  * [6] column statistics + slab reductions, [7] replicated M x M algebra, [8] the in-library exchange step (pack + RCCL
- * all-reduce + unpack; 0 without a communicator).  launches[i] = kernel launches behind out[i].  Both arrays hold
- * HMOGP_NTIMINGS entries (8 before ABI version 4).                                                                  */
-#define HMOGP_NTIMINGS 9
+ * all-reduce + unpack; 0 without a communicator), [9] the triangular solves of the strict q(f) mode (trsm_panel_kernel /
+ * trsm_diag_kernel + their update GEMMs; [2] then holds the mode's products T = A L_q and P~ = A (S K_uu^-1 - I) only),
+ * [10] the strict mode's row-statistic kernels (0 in the default mode).  launches[i] = kernel launches behind out[i].  Both
+ * arrays hold HMOGP_NTIMINGS entries (8 before ABI version 4, 9 before ABI version 8).                                */
+#define HMOGP_NTIMINGS 11
 int hmogp_last_timings(hmogp_handle h, double* out_ms /* [HMOGP_NTIMINGS] */, int64_t* launches /* [HMOGP_NTIMINGS] or NULL */);
 
 /* ---- inner protocol, debug / parity mode (small N only) ------------------------------------------------ */

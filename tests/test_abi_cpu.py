@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(lib, n), "libhetmogp_hip.so does not export %s" % n
     lib.hmogp_abi_version.restype = ctypes.c_int
     header_version = int(re.search(r"#define HMOGP_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
-    assert lib.hmogp_abi_version() == header_version == 7
+    assert lib.hmogp_abi_version() == header_version == 8
 
 
 def test_ctypes_binding_matches_header(built):
