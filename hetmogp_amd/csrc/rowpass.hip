@@ -316,11 +316,15 @@ __device__ __forceinline__ void quad_body(const QuadArgs& a, unsigned blk, QuadS
       cq[q] = (valid && q < Q) ? cc[q * a.ldn + n] : 0.0;
     }
   }
+  // (the loops over a row's functions are unrolled to HMOGP_MAXJ with a guard: a run-time trip count indexes mu / vv / the LikOut
+  //  arrays dynamically and parks them in scratch -- 144 bytes per lane in EVERY quad_kernel / var_exp_kernel instantiation, r5)
   if (a.out_mu && lead) {
-    for (int j = 0; j < J; ++j) {
-      a.out_mu[n * J + j] = mu[j];
-      a.out_v[n * J + j] = vv[j];
-    }
+#pragma unroll
+    for (int j = 0; j < HMOGP_MAXJ; ++j)
+      if (j < J) {
+        a.out_mu[n * J + j] = mu[j];
+        a.out_v[n * J + j] = vv[j];
+      }
   }
   const double s = lead ? s_scale : 0.0;  // non-owning lanes contribute zeros
   o.ve *= s;
@@ -330,10 +334,12 @@ __device__ __forceinline__ void quad_body(const QuadArgs& a, unsigned blk, QuadS
     o.gv[j] *= s;
   }
   if (a.out_gm && lead) {
-    for (int j = 0; j < J; ++j) {
-      a.out_gm[n * J + j] = o.gm[j];
-      a.out_gv[n * J + j] = o.gv[j];
-    }
+#pragma unroll
+    for (int j = 0; j < HMOGP_MAXJ; ++j)
+      if (j < J) {
+        a.out_gm[n * J + j] = o.gm[j];
+        a.out_gv[n * J + j] = o.gv[j];
+      }
   }
   emit(0, o.ve);
   emit(1, (lead && neg) ? 1.0 : 0.0);
@@ -383,7 +389,6 @@ __global__ __launch_bounds__(256) void quad_kernel(QuadArgs a) {
 // SGPRs, one wave per SIMD); the sets of the BASELINE configurations get instantiations of their own (C1's
 // {HetGaussian, Bernoulli, Categorical(3)}: see the register table in DESIGN 11e), any other set the all-inclusive one.
 constexpr unsigned qm_bit(int lik, int dimf) { return lik == HMOGP_LIK_CATEGORICAL ? 1u << (8 + dimf) : 1u << lik; }
-constexpr unsigned QM_ALL = 0x1FFFFu & ~(1u << HMOGP_LIK_CATEGORICAL) & ~(1u << 8);
 constexpr unsigned QM_C1 = qm_bit(HMOGP_LIK_HETGAUSSIAN, 0) | qm_bit(HMOGP_LIK_BERNOULLI, 0) | qm_bit(HMOGP_LIK_CATEGORICAL, 2);
 constexpr unsigned QM_H4 = qm_bit(HMOGP_LIK_GAUSSIAN, 0) | qm_bit(HMOGP_LIK_BERNOULLI, 0) | qm_bit(HMOGP_LIK_POISSON, 0) |
                            qm_bit(HMOGP_LIK_GAMMA, 0);
@@ -435,7 +440,14 @@ __global__ __launch_bounds__(256) void quad_multi_kernel(QuadMulti m) {
 // ---- colstats: thread = 2 columns, block = 512 columns x `rows` rows ----------------------------------------
 // STRICT (HMOGP_CFG_STRICT_QF only): r = A^T alpha from a second matrix and quirk Q10's r == 0 gating -- kept out of the hot-path
 // instantiation, which has to fit 64 registers to run beside the Gram.
-template <int P, bool STRICT, bool SL>
+// [r6] WIN = false (no exact-zero windows: the default): the row loop's bounds are the same for every lane, so what a row contributes
+// besides its K^ / P~ entries -- alpha, alpha0, beta0 and the input x_n -- is WAVE-UNIFORM.  Read through the constant address
+// space at uniform addresses those values arrive in SGPRs (s_load; v_fma_f64 takes an SGPR pair as a source) instead of being
+// broadcast into 6 + 2 P vector registers per lane: P = 2 ... 4 fit their 64 registers without a spill (2 - 64 spilled before; P = 2
+// is BASELINE config 5's path: column statistics 7.6 -> 4.6 ms per step there).  WIN = true keeps the per-lane bounds and vector
+// loads: the windows mode, and P = 1, which never spilled and is 10 % faster with them (launch_colstats).
+#define HM_CONST(p) ((const __attribute__((address_space(4))) double*)(uintptr_t)(p))
+template <int P, bool STRICT, bool SL, bool WIN>
 __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restrict__ Kh, const double* __restrict__ Pt,
                                                        const double* __restrict__ a, const double* __restrict__ alpha,
                                                        const double* __restrict__ alpha0, const double* __restrict__ beta0,
@@ -472,7 +484,7 @@ __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restri
   const long long nsplit = (N + rows - 1) / rows;
   for (long long sp = blockIdx.y; sp < nsplit; sp += gridDim.y) {
     long long n0 = sp * rows, n1 = min(N, n0 + rows);
-    if (colwin) {  // rows outside the exact-zero window of this 128-column block contribute exact zeros
+    if (WIN && colwin) {  // rows outside the exact-zero window of this 128-column block contribute exact zeros
       n0 = max(n0, (long long)colwin[2 * (c >> 7)]);
       n1 = min(n1, (long long)colwin[2 * (c >> 7) + 1]);
     }
@@ -496,7 +508,7 @@ __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restri
           q1 = two ? Pt[n * M + c + 1] : 0.0;
         }
       }
-      const double al = alpha[n];
+      const double al = WIN ? alpha[n] : HM_CONST(alpha)[n];
       if (STRICT) {   // strict q(f): r = A^T alpha with A = K^ Kuu^-1 (dVE_dmu of svmogp_inf.py:144 as the reference forms it)
         r0 += Ar[n * M + c] * al;
         r1 += (two ? Ar[n * M + c + 1] : 0.0) * al;
@@ -505,7 +517,7 @@ __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restri
         r1 += k1 * al;
       }
       if (want_e) {
-        const double al0 = alpha0[n], be0 = 2.0 * beta0[n];
+        const double al0 = WIN ? alpha0[n] : HM_CONST(alpha0)[n], be0 = 2.0 * (WIN ? beta0[n] : HM_CONST(beta0)[n]);
         double e0 = (al0 * a0 + be0 * q0) * k0, e1 = (al0 * a1 + be0 * q1) * k1;
         // Quirk Q10 (STRICT only): GPy's gradients_X drops the entries whose COMPUTED distance -- the expanded form |x|^2 + |z|^2 -
         // 2 x.z, clipped -- is exactly 0.  That needs |x - z|^2 below a few ulp of |z|^2: un-centred inputs, or, at 1e6 rows per
@@ -515,7 +527,7 @@ __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restri
         if (STRICT) {
           double xv[P];
 #pragma unroll
-          for (int p = 0; p < P; ++p) xv[p] = X[n * P + p];
+          for (int p = 0; p < P; ++p) xv[p] = WIN ? X[n * P + p] : HM_CONST(X)[n * P + p];
           const double xsq = sumsq<P>(xv);
           if (rbf_r2_fast<P>(xv, xsq, z0, zs0, 1.0) == 0.0) e0 = 0.0;
           if (rbf_r2_fast<P>(xv, xsq, z1, zs1, 1.0) == 0.0) e1 = 0.0;
@@ -523,7 +535,7 @@ __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restri
         double q20 = 0.0, q21 = 0.0;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-          const double x = X[n * P + p];
+          const double x = WIN ? X[n * P + p] : HM_CONST(X)[n * P + p];
           const double dx0 = x - z0[p], dx1 = x - z1[p];
           d0[p] += e0 * dx0;
           d1[p] += e1 * dx1;
@@ -701,10 +713,12 @@ __global__ __launch_bounds__(256) void var_exp_kernel(int J, double param, long 
   lik_eval<LIK, CATD>(yy, (LIK == HMOGP_LIK_POISSON) ? lgamma(yy + 1.0) : 0.0, mu, vv, param, lane, etab[w], quirks, o);
   if (G == 1 || lane == 0) {
     ve[n] = o.ve;
-    for (int j = 0; j < J; ++j) {
-      dm[n * J + j] = o.gm[j];
-      dv[n * J + j] = o.gv[j];
-    }
+#pragma unroll
+    for (int j = 0; j < HMOGP_MAXJ; ++j)
+      if (j < J) {
+        dm[n * J + j] = o.gm[j];
+        dv[n * J + j] = o.gv[j];
+      }
   }
 }
 
@@ -895,18 +909,25 @@ void launch_quad_multi(const QuadMulti& m_in, hipStream_t s) {
   if (blocks == 0) return;
   unsigned need = 0;
   for (int i = 0; i < m.nseg; ++i) need |= qm_bit(m.seg[i].lik, m.seg[i].dimf);
-  static const bool generic_only = [] {   // HMOGP_QUAD_GENERIC=1: always the all-inclusive instantiation (A/B runs)
-    const char* e = getenv("HMOGP_QUAD_GENERIC");
-    return e && e[0] == '1';
-  }();
 #define QML(MASK)                                                                             \
-  if (!generic_only && (need & ~(MASK)) == 0) {                                               \
+  if ((need & ~(MASK)) == 0) {                                               \
     hipLaunchKernelGGL((quad_multi_kernel<MASK>), dim3(blocks), dim3(256), 0, s, m);          \
     return;                                                                                   \
   }
   QML(QM_C1) QML(QM_C5) QML(QM_H4) QML(QM_LIGHT)
 #undef QML
-  hipLaunchKernelGGL((quad_multi_kernel<QM_ALL>), dim3(blocks), dim3(256), 0, s, m);
+  // [r6] any other likelihood set (BASELINE config 4's eight families ...): one launch for the five cheap families together and one
+  // per expensive family present, each over the SAME block range and segment table -- a block whose segment the instantiation does
+  // not carry returns at once.  The all-inclusive instantiation this replaces is allocated for the worst body it inlines (256 VGPRs +
+  // 38 AGPRs, 321 spilled SGPRs, 144 bytes of scratch, one wave per SIMD) and ran every cheap segment at that occupancy.
+#define QMS(MASK)                                                                             \
+  if ((need & (MASK)) != 0) hipLaunchKernelGGL((quad_multi_kernel<MASK>), dim3(blocks), dim3(256), 0, s, m);
+  QMS(QM_LIGHT)
+  QMS(qm_bit(HMOGP_LIK_GAMMA, 0)) QMS(qm_bit(HMOGP_LIK_BETA, 0))
+  QMS(qm_bit(HMOGP_LIK_CATEGORICAL, 1)) QMS(qm_bit(HMOGP_LIK_CATEGORICAL, 2)) QMS(qm_bit(HMOGP_LIK_CATEGORICAL, 3))
+  QMS(qm_bit(HMOGP_LIK_CATEGORICAL, 4)) QMS(qm_bit(HMOGP_LIK_CATEGORICAL, 5)) QMS(qm_bit(HMOGP_LIK_CATEGORICAL, 6))
+  QMS(qm_bit(HMOGP_LIK_CATEGORICAL, 7)) QMS(qm_bit(HMOGP_LIK_CATEGORICAL, 8))
+#undef QMS
 }
 
 void launch_var_exp(int lik, int J, double param, long long N, const double* y, const double* m, const double* v, double* ve,
@@ -990,8 +1011,15 @@ void launch_colstats(const double* Kh, const double* Pt, const double* a, const 
     grid.y = (unsigned)std::max<long long>(1, std::min<long long>(grid.y, max_blocks / per_y));
   }
 #define HM_COLSTATS(ST, SLV)                                                                                                        \
-  DISPATCH_P(P, hipLaunchKernelGGL((colstats_kernel<PP, ST, SLV>), grid, dim3(256), 0, s, Kh, Pt, a, alpha, alpha0, beta0, X, Z, ldz, \
-                                   N, M, rows, want_z ? 1 : 0, partials, colwin, bt, Ar, ell))
+  do {                                                                                                                            \
+    if (colwin || P == 1) {   /* (P = 1 never spilled, and its vector loads are faster: C2's column statistics 10.8 vs 11.9 ms) */ \
+      DISPATCH_P(P, hipLaunchKernelGGL((colstats_kernel<PP, ST, SLV, true>), grid, dim3(256), 0, s, Kh, Pt, a, alpha, alpha0, beta0, X, \
+                                       Z, ldz, N, M, rows, want_z ? 1 : 0, partials, colwin, bt, Ar, ell));                     \
+    } else {                                                                                                                      \
+      DISPATCH_P(P, hipLaunchKernelGGL((colstats_kernel<PP, ST, SLV, false>), grid, dim3(256), 0, s, Kh, Pt, a, alpha, alpha0, beta0, X, \
+                                       Z, ldz, N, M, rows, want_z ? 1 : 0, partials, colwin, bt, Ar, ell));                     \
+    }                                                                                                                             \
+  } while (0)
   if (Ar && ell) { HM_COLSTATS(true, true); }
   else if (Ar) { HM_COLSTATS(true, false); }
   else if (ell) { HM_COLSTATS(false, true); }
