@@ -740,7 +740,7 @@ def other_configs(args):
                   cat["forward_gemm"], PEAK_FP64_MFMA_TFLOPS, "TFLOP/s"),
                rl("rowpass_gemm_kernel<2> (Gram of A / of X, lower tiles)", "mfma", nqm2, cat["gram_gemm"], PEAK_FP64_MFMA_TFLOPS,
                   "TFLOP/s")]
-        if cat.get("strict_rowstats", 0.0) > 0:
+        if cat.get("strict_rowstats", 0.0) > 0.5:     # (the E-step's only statistic kernel is a 0.04 ms combine: no roofline entry)
             stat_bytes = (8.0 * 800000 * 3 * 1024 * 2) if mask != _hl.GROUP_QU else 8.0 * 800000 * 3 * 10   # phase 1 streams K^ and P~
             rls.append(rl("strict_rowstats_kernel / trsm_stats_combine_kernel", "hbm", stat_bytes, cat["strict_rowstats"], PEAK_HBM_GBS,
                           "GB/s"))
