@@ -381,7 +381,12 @@ int hmogp_potrs_rows(int32_t device, const double* L, int32_t M, const double* B
     dL.ensure(sizeof(double) * M * M), dV.ensure(sizeof(double) * std::max<long long>(1, n) * M);
     HIP_TRY(hipMemcpy(dL.p, L, sizeof(double) * M * M, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dV.p, B, sizeof(double) * n * M, hipMemcpyHostToDevice));
-    potrs_rows_inplace(dV.d(), n * M, dL.d(), (long long)M * M, M, n, 1, nullptr);
+    // [r6] with scratch for the mirrored factor and the pivots' reciprocals the call takes the one-launch-per-block kernels where the
+    // shape allows it (M a multiple of 128, n >= 1024: trsm_panel.hip), else the round-5 path: the building block runs what the
+    // strict mode runs (tests/test_gpu_strict.py::test_potrs_rows_vs_lapack at both kinds of shape)
+    DevBuf dS, dR;
+    dS.ensure(sizeof(double) * M * M), dR.ensure(sizeof(double) * M);
+    potrs_rows_inplace(dV.d(), n * M, dL.d(), (long long)M * M, M, n, 1, nullptr, dS.d(), nullptr, dR.d());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dV.p, sizeof(double) * n * M, hipMemcpyDeviceToHost));
   });

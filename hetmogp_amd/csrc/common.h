@@ -88,6 +88,8 @@ struct GemmArgs {
   int store_c = 1;               // 0: do not write P~ at all (no consumer when the Z gradient is not requested)
   int fs_sq = 0;                 // role 1, specialised kernel: the ONE fused statistic is rowsum(C .* C) of the product itself (slot of
                                  // `c`; fs_a / fs_x / fs_z unused) -- strict q(f): rowsum(T .* T) of T = A L_q without storing T
+  const double* fs_k = nullptr;  // role 1, specialised kernel: the fused row statistics re-read THEIR K^ tile from here (same leading
+                                 // dimension / batch stride as A) instead of from A -- strict q(f): P~ = A D with K^ a, rowsum(P~ .* K^)
   const double* c_src = nullptr; // with c_sub: C = c_src - op(A) op(B) (same leading dimension / batch stride as C; nullptr: C itself)
   int c_sub = 0;                 // role 1, specialised kernel: C -= op(A) op(B)  (set by its launcher for alpha = -1, beta = 1)
   // Triangular operands: op(A) is M x K, op(B) is K x N; the k-loop of tile (i0, j0) is trimmed to the products that

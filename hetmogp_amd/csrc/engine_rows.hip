@@ -325,7 +325,7 @@ void hmogp_engine::strict_forward(long long n, const double* X, bool grads, bool
   sr.M = M, sr.Q = Q, sr.P = P, sr.ldz = Q * P, sr.n = n, sr.ldn = ldn, sr.sK = sK, sr.sZ = P;
   sr.Kh = Kh.d(), sr.Ah = Ah.d(), sr.Tt = Pt.d(), sr.Pt = Pt.d(), sr.mu = dmu.d(), sr.w3 = strict_two ? nullptr : w3.d(), sr.a = a.d();
   sr.X = X, sr.Z = dZ.d(), sr.ell = dell.d();
-  sr.p = vp.d(), sr.c = vc.d(), sr.pg = vpg.d(), sr.cg = vcg.d(), sr.pt = hyper ? vpt.d() : nullptr, sr.ct = hyper ? vct.d() : nullptr;
+  sr.p = vp.d(), sr.c = vc.d(), sr.pg = vpg.d(), sr.cg = vcg.d(), sr.pt = nullptr, sr.ct = nullptr;
   sr.phase = 0;
   sr.t2 = t2_fused ? vct.d() : nullptr;           // (vct: free until phase 1 writes the r2-weighted twin into it)
   {
@@ -337,13 +337,43 @@ void hmogp_engine::strict_forward(long long n, const double* X, bool grads, bool
   }
   sr.t2 = nullptr;
   if (!grads) return;
+  // P~ = A (S Kuu^-1 - I) (:157-161).  [r6] Where the specialised forward kernel takes the product its fused epilogue forms the two
+  // row statistics the gradient code reduces P~ to -- pg = K^ a and cg = rowsum(P~ .* K^) -- from the accumulators and a K^ tile
+  // read through `fs_k` (K^ is not this product's A operand), and the r2-weighted statistic of the lengthscale gradient comes
+  // from the column statistics (colstats<STRICT, SL>: GPy's r2 form): no pass of strict_rowstats_kernel over K^ and P~
+  // (39 GB, 8.7 ms at the headline size).  `hyper` then only says that colstats carries the weight.
+  static const bool p1_env = [] {   // HMOGP_STRICT_P1=0: phase 1 by strict_rowstats_kernel as in round 5 (pg / cg only; A/B runs)
+    const char* e = getenv("HMOGP_STRICT_P1");
+    return !(e && e[0] == '0');
+  }();
+  {
+    GemmArgs g;
+    g.A = Ah.d(), g.lda = M, g.a_kmajor = 0, g.sA = sK;
+    g.B = Bp, g.ldb = M, g.b_kmajor = 1, g.sB = MM;
+    g.C = Pt.d(), g.ldc = M, g.sC = sK;
+    g.M = (int)n, g.N = M, g.K = M;
+    g.nbatch = Q;
+    g.role = 1;
+    const int tiles = (M + 127) / 128;
+    g.fs_part = fwdpart.d(), g.fs_sPart = 4LL * FWD_PARTS * tiles * ldn, g.fs_a = a.d(), g.fs_sA = M, g.fs_k = Kh.d();
+    if (p1_env && gemm_rowpass_would_take(g)) {
+      {
+        Scope sc(this, CAT_FWD, 1);
+        launch_gemm_rowpass_or_general(g, st);
+      }
+      Scope sc(this, CAT_STRICT_STATS, 1);
+      launch_combine_parts(fwdpart.d(), 4 * tiles, n, vpg.d(), vcg.d(), nullptr, nullptr, st, Q, g.fs_sPart, ldn);
+      return;
+    }
+  }
   {
     Scope sc(this, CAT_FWD, 1);
-    rows_gemm(Ah.d(), Bp, 1, 0, Pt.d());          // P~ = A (S Kuu^-1 - I)                      (:157-161)
+    rows_gemm(Ah.d(), Bp, 1, 0, Pt.d());
   }
   Scope sc(this, CAT_STRICT_STATS, 1);
   sr.phase = 1;
-  launch_strict_rowstats(sr, st);                 // K^ a, rowsum(P~ .* K^) and their r2-weighted twins
+  sr.pt = sr.ct = nullptr;                        // (the r2-weighted twins: column statistics now)
+  launch_strict_rowstats(sr, st);                 // K^ a, rowsum(P~ .* K^)
 }
 
 void hmogp_engine::row_pass() {
@@ -379,7 +409,7 @@ void hmogp_engine::row_pass() {
       const char* e = getenv("HMOGP_COL_SL");
       return !(e && e[0] == '0');
     }();
-    const bool col_sl = want_hyper && !strict && !small_rows && col_sl_env;
+    const bool col_sl = want_hyper && !small_rows && col_sl_env;     // ([r6] strict q(f) too: colstats<STRICT> weights with GPy's r2 form)
     // slabs of the column statistics: 256-row splits
     const long long csplit = col_split(n);
     const long long nsp = (n + csplit - 1) / csplit;        // slabs of the column statistics

@@ -286,9 +286,10 @@ __device__ __forceinline__ void rowpass_tile(const GemmArgs& g, int tiles_n, int
     double* stg = flat + w * WSTAGE;              // [2 buffers][NCH chunks][64 lanes][2]
     static_assert(W * WSTAGE <= 4 * TILE_DOUBLES, "epilogue scratch fits the tile buffers");
     const int colq = j0 + wn * WN + 4 * lk;       // + b*16 (+ 2h)
+    const double* __restrict__ Ke = g.fs_k ? g.fs_k + (long long)batch * g.sA : A;   // (strict q(f): K^ is not this product's A operand)
     auto issue = [&](int a) {
       const int grow = min(i0 + wm * 64 + a * 16 + lr, M - 1);
-      const double* src = A + (long long)grow * g.lda + colq;
+      const double* src = Ke + (long long)grow * g.lda + colq;
       double* dst = stg + (a & 1) * (NCH * 128);
 #pragma unroll
       for (int c = 0; c < NCH; ++c)               // chunk c = 2*b + h
@@ -456,6 +457,7 @@ bool gemm_rowpass_eligible(const GemmArgs& g) {
   if (g.nouter != 1 || (!sub && (g.alpha != 1.0 || g.beta != 0.0)) || g.win || g.M_last || g.N_last || g.K_last || g.a_tri) return false;
   if ((g.lda & 1) || (g.ldb & 1) || (g.ldc & 1) || !aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return false;
   if (g.c_src && (!sub || !aligned16(g.c_src))) return false;
+  if (g.fs_k && (g.role != 1 || !g.fs_part || g.fs_sq || !aligned16(g.fs_k))) return false;
   if ((g.sA & 1) || (g.sB & 1) || (g.sC & 1) || (g.sSplit & 1)) return false;
   if (g.role == 1)
     return !g.a_kmajor && g.b_kmajor && !g.lower_only && g.ksplit == 1 && !g.kscale && g.b_tri >= 0 && (g.N % BN) == 0 &&
@@ -498,8 +500,8 @@ bool gemm_rowpass_would_take(const GemmArgs& g) { return rowpass_enabled() && ge
 
 int launch_gemm_rowpass_or_general(const GemmArgs& g, hipStream_t stream) {
   const bool enabled = rowpass_enabled();
-  if (g.fs_sq && !(enabled && gemm_rowpass_eligible(g)))
-    throw HipError{hipErrorInvalidValue, "fs_sq is a statistic of the specialised forward kernel only", __FILE__, __LINE__};
+  if ((g.fs_sq || g.fs_k) && !(enabled && gemm_rowpass_eligible(g)))
+    throw HipError{hipErrorInvalidValue, "fs_sq / fs_k are features of the specialised forward kernel only", __FILE__, __LINE__};
   if (enabled && gemm_rowpass_eligible(g)) {
     launch_gemm_rowpass(g, stream);
     return NWN;

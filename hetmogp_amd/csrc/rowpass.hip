@@ -524,13 +524,15 @@ __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restri
         // task, the odd row within 1.5e-8 |z| of an inducing point (one such row in the full-size C4 test: 4e-8 of one g_Z entry).
         // The default path keeps those terms (they are the mathematically correct ones): an in-loop test, even behind a cheap
         // pre-test, costs this kernel 16 spilled registers -- and it has to fit 64 to run beside the Gram.
+        double g20 = 0.0, g21 = 0.0;     // STRICT: GPy's clipped expanded-form squared distances (unscaled)
         if (STRICT) {
           double xv[P];
 #pragma unroll
           for (int p = 0; p < P; ++p) xv[p] = WIN ? X[n * P + p] : HM_CONST(X)[n * P + p];
           const double xsq = sumsq<P>(xv);
-          if (rbf_r2_fast<P>(xv, xsq, z0, zs0, 1.0) == 0.0) e0 = 0.0;
-          if (rbf_r2_fast<P>(xv, xsq, z1, zs1, 1.0) == 0.0) e1 = 0.0;
+          g20 = rbf_r2_fast<P>(xv, xsq, z0, zs0, 1.0), g21 = rbf_r2_fast<P>(xv, xsq, z1, zs1, 1.0);
+          if (g20 == 0.0) e0 = 0.0;
+          if (g21 == 0.0) e1 = 0.0;
         }
         double q20 = 0.0, q21 = 0.0;
 #pragma unroll
@@ -541,7 +543,10 @@ __global__ __launch_bounds__(256, 8) void colstats_kernel(const double* __restri
           d1[p] += e1 * dx1;
           if (SL) q20 += dx0 * dx0, q21 += dx1 * dx1;
         }
-        if (SL) s20 += e0 * q20, s21 += e1 * q21;
+        // [r6] strict q(f): the r2 weight of the lengthscale statistic in GPy's OWN form -- |x|^2 + |z|^2 - 2 x.z, clipped
+        // (stationary.py `_unscaled_dist`): with un-centred inputs that form loses digits the reference's gradient carries
+        // (lad_c1_offset_rung1) -- instead of sum_p (x_p - z_p)^2.  Replaces the r2-weighted twins of strict_rowstats_kernel.
+        if (SL) s20 += e0 * (STRICT ? g20 : q20), s21 += e1 * (STRICT ? g21 : q21);
       }
     }
     // partial layout per row-split: [ r (M) | dZ (M*P) | s2 (M) ]

@@ -173,6 +173,27 @@ def test_potrs_rows_vs_lapack(M):
         assert np.max(np.abs(out - ref)) <= max(1e-13, bound) * np.max(np.abs(ref)), (M, jitter)
 
 
+@pytest.mark.parametrize("M,n", [(128, 1024), (256, 1500), (384, 2049), (1024, 1153)])
+def test_potrs_rows_panel_kernels_vs_lapack(M, n):
+    """[r6] hmogp_potrs_rows at shapes the one-launch-per-block kernels take (trsm_panel.hip: M a multiple of 128, >= 1024 rows, ragged
+    last row tile): long-K update + in-register 4-column substitution groups against LAPACK's dpotrs, well- and ill-conditioned; and
+    row by row equal to the same call on a 333-row slice (which takes the round-5 kernels): two valid blocked substitutions."""
+    import scipy.linalg as sl
+    from hetmogp_amd.engine import potrs_rows
+    rng = np.random.RandomState(M + n)
+    A = rng.randn(M, M)
+    for jitter in (float(M), 1e-6):
+        K = A @ A.T / M + jitter * np.eye(M)
+        L = np.linalg.cholesky(K)
+        B = rng.randn(n, M)
+        ref = sl.cho_solve((L, True), B.T).T
+        out = potrs_rows(L, B)
+        bound = 50.0 * np.linalg.cond(K) * 2.2e-16
+        assert np.max(np.abs(out - ref)) <= max(1e-13, bound) * np.max(np.abs(ref)), (M, n, jitter)
+        small = potrs_rows(L, B[:333])
+        assert np.max(np.abs(out[:333] - small)) <= max(1e-13, bound) * np.max(np.abs(ref)), (M, n, jitter, "panel vs round-5 kernels")
+
+
 def test_strict_flag_exclusions():
     from hetmogp_amd.engine import Engine
     from hetmogp_amd._lib import InvalidArgument
