@@ -331,6 +331,13 @@ def test_bench_force_dist_one_rank_dry_run():
     assert set(forced["exchange_modes_ms_per_step"]) >= {"native"}
     assert forced["rows_per_rank"] == [4 * 50000] and len(forced["replicated_ms_per_rank"]) == 1
     assert forced["allreduce_bytes"] > 0
+    # [r6] what the first run with N > 1 needs in its line without an edit: the dominant kernel's roofline on
+    # every rank and the exchange / the replicated chain as shares of the step
+    rp = forced["roofline_per_rank"]
+    assert len(rp) == 1 and rp[0]["rank"] == 0 and rp[0]["rows"] == 4 * 50000 and rp[0]["launches"] == 4
+    assert 0.3 < rp[0]["frac"] < 1.0 and rp[0]["bound"] == "mfma" and abs(rp[0]["frac"] - forced["roofline"]["frac"]) < 1e-9
+    assert 0.0 < forced["allreduce_frac_of_step"] < 0.2 and 0.0 < forced["replicated_frac_of_step"] < 0.5
+    assert forced["n_gt_1_rccl_executed_before_this_run"] is False
     assert abs(forced["elbo"] - plain["elbo"]) <= 1e-12 * abs(plain["elbo"])      # same numbers ...
     assert forced["ms_per_step"] < 1.25 * plain["ms_per_step"] + 0.5               # ... in the same time (+ one-rank exchange)
     print("force-dist %.3f ms/step (exchange %.3f) vs plain %.3f ms/step; modes %s" % (
