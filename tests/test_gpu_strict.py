@@ -126,6 +126,18 @@ def test_strict_mode_at_the_headline_M_in_several_pools():
     for k in KEYS:
         assert rel(a[k], want[k]) < 1e-8, (k, rel(a[k], want[k]))
         assert rel(b[k], a[k]) < 1e-10, ("pools", k, rel(b[k], a[k]))
+    # [r6] an E-step at this M: the one-solve form end to end through the one-launch-per-block kernels -- the forward solve of the
+    # 9600-row pool with the fused statistics, the stacked 2 M + 1-row solve of the right factors, and `finish`'s two backward
+    # solves of M + 1 and M rows (ragged last row tile) -- against the oracle's one-solve restatement AND its two-solve one
+    from hetmogp_amd import _lib
+    w1 = so.elbo_grad_fused(prm, dict(prob, strict_qf="one_solve"), X, Y, stochastic=True, vem_step=True)
+    w2 = so.elbo_grad_fused(prm, dict(prob, strict_qf=True), X, Y, stochastic=True, vem_step=True)
+    qu = e1.elbo_grad(group_mask=_lib.GROUP_QU, **prm)
+    ms = e1.timings()[0]
+    assert ms["trsm_solves"] > 0.0 and ms["strict_rowstats"] >= 0.0          # (ABI v8 timing slots)
+    for k in ("elbo", "g_m_u", "g_L_u"):
+        assert rel(qu[k], w1[k]) < 1e-8, ("E-step vs one-solve oracle", k, rel(qu[k], w1[k]))
+        assert rel(qu[k], w2[k]) < 1e-8, ("E-step vs two-solve oracle", k, rel(qu[k], w2[k]))
     e1.close(), e3.close()
 
 
