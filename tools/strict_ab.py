@@ -2,7 +2,9 @@
 """A/B of the strict q(f) mode's triangular solves: round-6 panel kernels (trsm_panel.hip) against the round-5 path
 (HMOGP_TRSM_PANEL=0), same inputs, two processes.  Prints per array max|a-b| / max|b| and the worst element-wise excess over the
 1e-5 criterion; also potrs_rows against scipy's cho_solve for both.
-python tools/strict_ab.py [rows_per_task] [M] [Q] [ell_over_spacing]"""
+python tools/strict_ab.py [rows_per_task] [M] [Q] [ell_over_spacing] [forms]
+`forms` (any 5th argument): compare the ONE-solve form forced for a full-gradient evaluation (HMOGP_STRICT_FORM=1) with the two-solve
+form (HMOGP_STRICT_FORM=2) instead of the two kernel generations."""
 import os
 import subprocess
 import sys
@@ -38,12 +40,16 @@ if __name__ == "__main__":
     Q = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     c = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
     res = {}
+    forms = len(sys.argv) > 5
     with tempfile.TemporaryDirectory() as d:
         for tag, env in (("panel", "1"), ("round5", "0")):
             p = os.path.join(d, tag + ".npz")
+            extra = dict(HMOGP_STRICT_FORM=("1" if tag == "panel" else "2")) if forms else dict(HMOGP_TRSM_PANEL=env)
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", p, str(N), str(M), str(Q), str(c)],
-                                  env=dict(os.environ, HMOGP_TRSM_PANEL=env))
+                                  env=dict(os.environ, **extra))
             res[tag] = dict(np.load(p))
+    if forms:
+        print("(one-solve form forced vs two-solve form)")
     a, b = res["panel"], res["round5"]
     print("N=%d M=%d Q=%d ell/h=%s  rungs %s / %s  cond_est %s" % (N, M, Q, c or "default", a["rungs"], b["rungs"],
                                                                    ["%.2g" % v for v in a["cond"]]))
