@@ -1015,9 +1015,13 @@ void launch_colstats(const double* Kh, const double* Pt, const double* a, const 
     const long long per_y = (long long)grid.x * grid.z;
     grid.y = (unsigned)std::max<long long>(1, std::min<long long>(grid.y, max_blocks / per_y));
   }
+  static const bool scalar_env = [] {   // HMOGP_COLSTATS_SCALAR=0: vector loads of the row values for every P (A/B runs)
+    const char* e = getenv("HMOGP_COLSTATS_SCALAR");
+    return !(e && e[0] == '0');
+  }();
 #define HM_COLSTATS(ST, SLV)                                                                                                        \
   do {                                                                                                                            \
-    if (colwin || P == 1) {   /* (P = 1 never spilled, and its vector loads are faster: C2's column statistics 10.8 vs 11.9 ms) */ \
+    if (colwin || P == 1 || !scalar_env) {   /* (P = 1 never spilled, and its vector loads are faster: C2's column statistics 10.8 vs 11.9 ms) */ \
       DISPATCH_P(P, hipLaunchKernelGGL((colstats_kernel<PP, ST, SLV, true>), grid, dim3(256), 0, s, Kh, Pt, a, alpha, alpha0, beta0, X, \
                                        Z, ldz, N, M, rows, want_z ? 1 : 0, partials, colwin, bt, Ar, ell));                     \
     } else {                                                                                                                      \
