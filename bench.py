@@ -724,8 +724,8 @@ def other_configs(args):
     nqm2 = 800000.0 * 3 * 1024 ** 2
     from hetmogp_amd import _lib as _hl
 
-    def strict_entry(tag, name, mask, solves, flops_rows, note):
-        ms, cat, out = _time_steps(eng, prm, min(K, 3), warmup=1, group_mask=mask)
+    def strict_entry(tag, name, mask, solves, flops_rows, note, prm=prm, **kw):
+        ms, cat, out = _time_steps(eng, prm, min(K, 3), warmup=1, group_mask=mask, **kw)
         fl = flops_rows * nqm2 + 20.0 * 3 * 1024 ** 3
 
         def rl(kernel, bound, work, unit_ms, peak, unit):
@@ -748,9 +748,19 @@ def other_configs(args):
                     "frac_of_peak": fl / ms / 1e9 / PEAK_FP64_MFMA_TFLOPS, "roofline": rls,
                     "kernel_ms_per_step": {k: round(v, 4) for k, v in cat.items()}, "elbo": out["elbo"], "steps": min(K, 3),
                     "cond_est": [float(c) for c in out["cond_est"]], "ill_conditioned": bool(out["ill_conditioned"]), "note": note})
-    strict_entry("HS", "HS: headline workload in the strict q(f) mode (HMOGP_CFG_STRICT_QF), full gradients", _hl.GROUP_ALL, 2, 6.0,
-                 "parity mode, not the headline: 6 n Q M^2 contraction flops instead of 3 n Q M^2 (two blocked triangular solves -- ONE "
-                 "launch per 128-column block and direction since round 6: 298.7 ms in BENCH_r05 --, T = A L_q, P~ = A D, Gram of A)")
+    # HS: the headline parameters (lengthscale ~ inducing spacing, condition estimate 5): a full-gradient strict evaluation takes the
+    # ONE-solve form there (estimate <= 1e5).  HSL: the same shape where the strict mode is actually needed -- lengthscale = 4 x the
+    # inducing spacing, GPy's jitter rung 0 (forced, as the ladder would find it), estimate 5.5e5 -- : the TWO-solve form.
+    strict_entry("HS", "HS: headline workload in the strict q(f) mode (HMOGP_CFG_STRICT_QF), full gradients", _hl.GROUP_ALL, 1, 5.0,
+                 "parity mode, not the headline.  K_uu is well conditioned here (estimate 5), so the evaluation takes the one-solve "
+                 "form (round 6): 5 n Q M^2 contraction flops (one blocked triangular solve, T = X W, P~ = X W2, Gram of X); "
+                 "298.7 ms in BENCH_r05 (two solves, round-5 kernels)")
+    prm_l = dict(prm, lengthscale=np.full(3, 4.0 / 1023.0))
+    strict_entry("HSL", "HSL: headline shape at lengthscale = 4 x inducing spacing (jitter rung 0, cond(K_uu) ~ 1e7), strict q(f) mode, "
+                 "full gradients", _hl.GROUP_ALL, 2, 6.0,
+                 "the regime the strict mode exists for: two-solve form (A = dpotrs on the n x M side: ONE launch per 128-column block "
+                 "and direction), T = A L_q, P~ = A D with the phase-1 statistics in its epilogue, Gram of A; 6 n Q M^2 contraction flops",
+                 prm=prm_l, forced_rung=[0, 0, 0])
     strict_entry("HSE", "HSE: headline workload in the strict q(f) mode, q(u) gradients only (an E-step: group_mask = QU)", _hl.GROUP_QU,
                  1, 3.0, "one-solve form (round 6): only the forward substitution X = K^ Luu^-T touches the n x M side; "
                  "3 n Q M^2 contraction flops (solve, T = X (Luu^-1 L_q), Gram of X)")

@@ -162,20 +162,22 @@ void hmogp_engine::u_algebra() {
   }
   if (strict && cond_pending) {     // (the device is still busy with the rest of the chain: this wait costs no device time)
     HIP_TRY(hipEventSynchronize(ev_cond));
-    cond_two = false;
-    for (int q = 0; q < Q; ++q) cond_two = cond_two || !(h_cond[q] <= 1e6);
+    cond_two = cond_mid = false;
+    for (int q = 0; q < Q; ++q) cond_two = cond_two || !(h_cond[q] <= 1e6), cond_mid = cond_mid || !(h_cond[q] <= 1e5);
   }
   if (strict) {
     static const int force = [] {   // HMOGP_STRICT_FORM=1 | 2: force the one-solve / two-solve form (A/B runs)
       const char* e = getenv("HMOGP_STRICT_FORM");
       return e ? atoi(e) : 0;
     }();
-    // P~ = A (S Kuu^-1 - I) -- needed by the K_uf-side gradients (hyper-parameters, Z) only -- is the one product that must be formed
-    // from A itself: as X (Luu^-1 (S Kuu^-1 - I)) its rounding error is sqrt(cond(K_uu)) times larger (the factors are 3e3 x 3e10
-    // where A's and D's are 1 x 1e7 at cond 1e7; measured at M = 1024, rung 0: g_Z 4e-8 instead of 2e-10 of its scale between two
-    // valid summation orders, 6 x the element-wise criterion on its small entries).  So: evaluations that need P~ take the
-    // two-solve form, E-steps (q(u) gradients only) and predictions the one-solve form -- unless K_uu is beyond the estimate 1e6.
-    strict_two = cond_two || (group_mask & (HMOGP_GROUP_HYPER | HMOGP_GROUP_Z)) != 0;
+    // P~ = A (S Kuu^-1 - I) -- needed by the K_uf-side gradients (hyper-parameters, Z) only -- is the one product whose one-solve
+    // form X (Luu^-1 (S Kuu^-1 - I)) drifts from the reference's ROUNDING as K_uu degrades (its right factor is 3e3 x larger
+    // than A D's and comes out of one more substitution).  Measured at M = 1024 between the two forms of a full-gradient
+    // evaluation (tools/strict_ab.py ... forms): worst element-wise excess over the 1e-5 criterion 5e-4 at estimate 2.5e3,
+    // 1.7e-4 at 5e4, 0.30 at 5.5e5 (jitter rung 0) -- and beyond 50 x the reference's own sensitivity at 1e10 (cond 1e12).
+    // So: an evaluation that needs P~ takes the two-solve form from the estimate 1e5 on (the whole jitter-ladder regime),
+    // every evaluation from 1e6 on; E-steps (q(u) gradients only), predictions and everything below 1e5 the one-solve form.
+    strict_two = cond_two || (cond_mid && (group_mask & (HMOGP_GROUP_HYPER | HMOGP_GROUP_Z)) != 0);
     if (force == 1) strict_two = false;
     if (force == 2) strict_two = true;
   }

@@ -120,12 +120,13 @@ typedef struct {
    are 1e-4 .. 1e-3 away from the reference's; with this flag the engine follows the reference's forms (two blocked triangular
    solves against Luu, the Gram of A, ...) and stays within 1e-5 element-wise there (tests/test_gpu_ladder.py).  Regular kernels
    only (no fused small-model path), excludes HMOGP_CFG_EXACT_ZERO_WINDOWS.  bench.py's `value` never uses it.
-   (ABI v8) Cost at the headline size: 2.25x the default step for a full-gradient evaluation (269 vs 119.5 ms; 2.5x in ABI v7),
-   1.6x for an evaluation that asks for the q(u) gradients only (136 vs 84 ms): such evaluations, and hmogp_predict_f, take the
-   ONE-SOLVE form -- only the forward substitution X = K_fu Luu^-T touches the n x M side, the backward half of dpotrs sits in
-   M x M factors (A m = X (Luu^-1 m), A L_q = X (Luu^-1 L_q), rowsum(A .* K_fu) = rowsum(X .* X), A^T diag(b) A =
-   Luu^-T (X^T diag(b) X) Luu^-1) -- while every evaluation that needs A (S K_uu^-1 - I) (hyper-parameter / Z gradients) or whose
-   own K_uu is beyond the condition estimate 1e6 keeps the literal two-solve form.                              */
+   (ABI v8) Cost at the headline size: 1.6x the default step for an evaluation that asks for the q(u) gradients only (136 vs 84 ms),
+   1.8x for a full-gradient evaluation (212 vs 119.5 ms) while the condition estimate of K_uu is <= 1e5, 2.2x beyond (263 ms; 2.5x in
+   ABI v7).  The first two take the ONE-SOLVE form -- only the forward substitution X = K_fu Luu^-T touches the n x M side, the
+   backward half of dpotrs sits in M x M factors (A m = X (Luu^-1 m), A L_q = X (Luu^-1 L_q), rowsum(A .* K_fu) = rowsum(X .* X),
+   A^T diag(b) A = Luu^-T (X^T diag(b) X) Luu^-1, A (S K_uu^-1 - I) = X (Luu^-1 (S K_uu^-1 - I))) --; an evaluation that needs the last
+   of these (hyper-parameter / Z gradients) of a K_uu beyond the estimate 1e5 -- the jitter-ladder regime -- and every evaluation
+   beyond 1e6 keep the literal two-solve form.                                                                  */
 #define HMOGP_CFG_NO_SMALL_PATH 4u /* ABI v5: keep the regular kernels and three streams also for small models (M <= 64 would
                                     * otherwise take the fused small-model kernels, M <= 128 with <= 65536 rows one stream): A/B
                                     * comparisons of the two paths inside one process (tests)                                */

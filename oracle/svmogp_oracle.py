@@ -320,10 +320,10 @@ def u_algebra(prm, prob, forced_rungs=None):
     sq = prob.get("strict_qf")
     if sq:
         est = max(float(prm["variance"][q] * np.max(np.diag(Kuui[q]))) for q in range(Q))
-        # (the engine also takes the two-solve form whenever an evaluation needs P~, i.e. hyper-parameter / Z gradients: formed as
-        #  X (Luu^-1 D) its rounding error is sqrt(cond) times A D's.  The oracle computes every gradient group in one go, so
-        #  strict_qf=True means the two-solve form here too; "one_solve" = the E-step / prediction form.)
-        u["strict_two"] = sq != "one_solve" or not (est <= 1e6)
+        # (the engine: two-solve form beyond 1e6 always, and beyond 1e5 when the evaluation needs P~, i.e. hyper-parameter / Z
+        #  gradients -- X (Luu^-1 D) drifts from the reference's rounding as K_uu degrades.  The oracle computes every gradient group
+        #  in one go: strict_qf=True mirrors a full-gradient evaluation, "one_solve" an E-step / a prediction.)
+        u["strict_two"] = (sq == "two_solves") or not (est <= (1e6 if sq == "one_solve" else 1e5))
     return u
 
 

@@ -318,7 +318,11 @@ def test_strict_e_step_one_solve_form_vs_reference_run(name):
     e.step_begin(group_mask=_lib.GROUP_ALL, **args)
     h_two = e.stats_read()[2 + prob["Df"]:2 + prob["Df"] + M * M].copy()
     two = e.step_finish()
-    assert rel_norm(h_one, h_two) > 1e-3
+    # (a full-gradient evaluation takes the two-solve form only from the condition estimate 1e5 on: DESIGN 13c)
+    if max(two["cond_est"]) > 1e5:
+        assert rel_norm(h_one, h_two) > 1e-3
+    else:
+        assert rel_norm(h_one, h_two) < 1e-12
     for k in ("elbo", "g_m_u", "g_L_u"):
         assert rel_norm(one[k], two[k]) < 1e-8, (k, rel_norm(one[k], two[k]))
     e.close()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Run a few steps of one BASELINE.json configuration through the C ABI (for rocprofv3 traces / PMC passes):
-    python tools/run_workload.py <H|HE|HS|HSE|HD|C2|C3|C3E|C4|C5> [steps] [warmup]
+    python tools/run_workload.py <H|HE|HS|HSL|HSE|HD|C2|C3|C3E|C4|C5> [steps] [warmup]
 H   headline: T=4 [Gaussian,Bernoulli,Poisson,Gamma], N_t=200000, M=1024, Q=3
 C2  the same at M=512
 C3  one full-gradient evaluation of an 8192-row minibatch out of N_all=1000000 resident rows per task (M=1024, Q=3)
@@ -9,7 +9,8 @@ C4  one rank's share of config 4: 8 tasks x 125000 rows, M=1024, Q=4, Df=14
 C5  2-D, T=2 [Categorical(4),Gaussian], N_t=50000, M=2048, Q=2
 HD  headline shape with a DENSE-valued K^ (lengthscale = 40 inducing spacings, jitter rung 4 forced): no exact zeros
 HE  the E-step of the headline workload (q(u) group only, K_uu chain cached): the fold-pair forward
-HS  the headline workload in the strict q(f) mode (HMOGP_CFG_STRICT_QF), full gradients: the two-solve form
+HS  the headline workload in the strict q(f) mode (HMOGP_CFG_STRICT_QF), full gradients: K_uu well conditioned -> one-solve form
+HSL the same shape at lengthscale = 4 inducing spacings, jitter rung 0 forced (estimate 5.5e5): the two-solve form
 HSE the same with group_mask = QU (an E-step): the one-solve form of round 6"""
 import os
 import sys
@@ -46,6 +47,10 @@ def workload(name):
         return H_SPECS, 200000, 1024, 3, 1, 20260929, dict(group_mask=1), dict(cache_kuu=True), None
     if name == "HS":
         return H_SPECS, 200000, 1024, 3, 1, 20260929, {}, dict(strict_qf=True), None
+    if name == "HSL":
+        def ladder(prm, M):
+            prm["lengthscale"] = np.full_like(prm["lengthscale"], 4.0 / (M - 1))
+        return H_SPECS, 200000, 1024, 3, 1, 20260929, dict(forced_rung=[0, 0, 0]), dict(strict_qf=True), ladder
     if name == "HSE":
         return H_SPECS, 200000, 1024, 3, 1, 20260929, dict(group_mask=1), dict(strict_qf=True), None
     if name == "HD":
