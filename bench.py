@@ -748,19 +748,19 @@ def other_configs(args):
                     "frac_of_peak": fl / ms / 1e9 / PEAK_FP64_MFMA_TFLOPS, "roofline": rls,
                     "kernel_ms_per_step": {k: round(v, 4) for k, v in cat.items()}, "elbo": out["elbo"], "steps": min(K, 3),
                     "cond_est": [float(c) for c in out["cond_est"]], "ill_conditioned": bool(out["ill_conditioned"]), "note": note})
-    # HS: the headline parameters (lengthscale ~ inducing spacing, condition estimate 5): a full-gradient strict evaluation takes the
-    # ONE-solve form there (estimate <= 1e5).  HSL: the same shape where the strict mode is actually needed -- lengthscale = 4 x the
-    # inducing spacing, GPy's jitter rung 0 (forced, as the ladder would find it), estimate 5.5e5 -- : the TWO-solve form.
+    # HS: the headline parameters (lengthscale ~ inducing spacing, condition estimate 2-5).  HSL: the same shape where the strict mode is
+    # actually NEEDED -- lengthscale = 4 x the inducing spacing, GPy's jitter rung 0 (forced, as the ladder would find it), estimate
+    # 5.5e5.  Both take the one-solve form (estimate <= 1e6: DESIGN 13c).
     strict_entry("HS", "HS: headline workload in the strict q(f) mode (HMOGP_CFG_STRICT_QF), full gradients", _hl.GROUP_ALL, 1, 5.0,
-                 "parity mode, not the headline.  K_uu is well conditioned here (estimate 5), so the evaluation takes the one-solve "
-                 "form (round 6): 5 n Q M^2 contraction flops (one blocked triangular solve, T = X W, P~ = X W2, Gram of X); "
-                 "298.7 ms in BENCH_r05 (two solves, round-5 kernels)")
+                 "parity mode, not the headline.  One-solve form (round 6): 5 n Q M^2 contraction flops (ONE blocked triangular solve, "
+                 "T = X W, P~ = X W2 with the phase-1 statistics in its epilogue, Gram of X); 298.7 ms in BENCH_r05 (two solves, "
+                 "round-5 kernels)")
     prm_l = dict(prm, lengthscale=np.full(3, 4.0 / 1023.0))
     strict_entry("HSL", "HSL: headline shape at lengthscale = 4 x inducing spacing (jitter rung 0, cond(K_uu) ~ 1e7), strict q(f) mode, "
-                 "full gradients", _hl.GROUP_ALL, 2, 6.0,
-                 "the regime the strict mode exists for: two-solve form (A = dpotrs on the n x M side: ONE launch per 128-column block "
-                 "and direction), T = A L_q, P~ = A D with the phase-1 statistics in its epilogue, Gram of A; 6 n Q M^2 contraction flops",
-                 prm=prm_l, forced_rung=[0, 0, 0])
+                 "full gradients", _hl.GROUP_ALL, 1, 5.0,
+                 "the regime the strict mode exists for (the default path is 1e-4 ... 1e-3 off in g_W / g_Z / v_fd here): same kernels and "
+                 "form as HS; against the reference-run fixture of this regime (lad_h_mix_M128_ladder) the evaluation is within 0.19 of the "
+                 "element-wise 1e-5 criterion", prm=prm_l, forced_rung=[0, 0, 0])
     strict_entry("HSE", "HSE: headline workload in the strict q(f) mode, q(u) gradients only (an E-step: group_mask = QU)", _hl.GROUP_QU,
                  1, 3.0, "one-solve form (round 6): only the forward substitution X = K^ Luu^-T touches the n x M side; "
                  "3 n Q M^2 contraction flops (solve, T = X (Luu^-1 L_q), Gram of X)")

@@ -205,12 +205,11 @@ struct hmogp_engine {
   DevBuf Dm, Ah, vpg, vcg, rdiag, trsmpart;
   // [r6] one-solve form: Wq = Luu^-1 L_q, Dm = Luu^-1 (S Kuu^-1 - I), w3 = Luu^-1 m (strict_stack / strict_unstack), Vst = the
   // stacked right-hand sides of that M x M solve and of the two that turn X^T diag(beta) X, X^T alpha into dVE_dS, dVE_dmu (finish)
-  // Which form an evaluation takes: the literal TWO-solve form of round 5 (A = dpotrs on the n x M side, D2 = S K_uu^-1 - I) when it
-  // needs P~ (hyper-parameter / Z gradients) AND the condition estimate of ITS OWN K_uu (variance max diag K_uu^-1, read back
-  // behind the factorisation: one host wait the latency-bound chain covers) is beyond 1e5 -- the jitter-ladder regime --, or
-  // whenever the estimate is beyond 1e6, where only multiples of the reference's own sensitivity can be asserted; the ONE-solve
-  // form otherwise (E-steps, predictions, and full-gradient evaluations of a K_uu below 1e5).  u_algebra (engine_rows.hip).
-  bool strict_two = false, cond_two = false, cond_mid = false;   // cond_*: estimate beyond 1e6 / 1e5 (kept with a cached K_uu chain)
+  // Which form an evaluation takes: the ONE-solve form while the condition estimate of ITS OWN K_uu (variance max diag K_uu^-1, read
+  // back behind the factorisation: one host wait the latency-bound chain covers) is <= 1e6 -- everything GPy's jitter rung 0 leaves
+  // behind included --, the literal TWO-solve form of round 5 (A = dpotrs on the n x M side, D2 = S K_uu^-1 - I) beyond, where only
+  // multiples of the reference's own sensitivity can be asserted and the one-solve P~ drifts out of them.  u_algebra (engine_rows.hip).
+  bool strict_two = false, cond_two = false;   // cond_two: estimate beyond 1e6 (kept with a cached K_uu chain)
   double* h_cond = nullptr;    // page-locked landing buffer of the early condition estimate
   hipEvent_t ev_cond = nullptr;
   DevBuf D2, dcond;

@@ -212,10 +212,7 @@ void hmogp_engine::predict_f(const double* Xnew, long long Nnew, double* m, doub
       RbfBatch rbt;
       rbt.nq = Q, rbt.var = dvar.d(), rbt.ell = dell.d(), rbt.sZ = P, rbt.sK = ldn * M;
       launch_rbf(dX.d(), P, n, P, dZ.d(), ldz, M, 0.0, 1.0, Kh.d(), false, st, nullptr, true, &rbt);
-      const bool two = strict_two;
-      strict_two = cond_two;                  // (q(f) alone: the one-solve form unless K_uu is beyond the estimate 1e6)
-      strict_forward(n, dX.d(), false, false);
-      strict_two = two;
+      strict_forward(n, dX.d(), false, false);   // (in the form of the evaluation the prediction is taken from)
     }
     for (int q = 0; q < Q && !strict; ++q) {
       double* kh = Kh.d() + (long long)q * ldn * M;

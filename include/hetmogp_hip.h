@@ -121,12 +121,12 @@ typedef struct {
    solves against Luu, the Gram of A, ...) and stays within 1e-5 element-wise there (tests/test_gpu_ladder.py).  Regular kernels
    only (no fused small-model path), excludes HMOGP_CFG_EXACT_ZERO_WINDOWS.  bench.py's `value` never uses it.
    (ABI v8) Cost at the headline size: 1.6x the default step for an evaluation that asks for the q(u) gradients only (136 vs 84 ms),
-   1.8x for a full-gradient evaluation (212 vs 119.5 ms) while the condition estimate of K_uu is <= 1e5, 2.2x beyond (263 ms; 2.5x in
-   ABI v7).  The first two take the ONE-SOLVE form -- only the forward substitution X = K_fu Luu^-T touches the n x M side, the
-   backward half of dpotrs sits in M x M factors (A m = X (Luu^-1 m), A L_q = X (Luu^-1 L_q), rowsum(A .* K_fu) = rowsum(X .* X),
-   A^T diag(b) A = Luu^-T (X^T diag(b) X) Luu^-1, A (S K_uu^-1 - I) = X (Luu^-1 (S K_uu^-1 - I))) --; an evaluation that needs the last
-   of these (hyper-parameter / Z gradients) of a K_uu beyond the estimate 1e5 -- the jitter-ladder regime -- and every evaluation
-   beyond 1e6 keep the literal two-solve form.                                                                  */
+   1.8x for a full-gradient evaluation (213 vs 119.5 ms; 2.5x in ABI v7) while the condition estimate of K_uu is <= 1e6 -- GPy's whole
+   jitter-ladder regime --, 2.2x beyond (263 ms).  Up to 1e6 an evaluation takes the ONE-SOLVE form: only the forward substitution
+   X = K_fu Luu^-T touches the n x M side, the backward half of dpotrs sits in M x M factors (A m = X (Luu^-1 m), A L_q =
+   X (Luu^-1 L_q), rowsum(A .* K_fu) = rowsum(X .* X), A^T diag(b) A = Luu^-T (X^T diag(b) X) Luu^-1, A (S K_uu^-1 - I) =
+   X (Luu^-1 (S K_uu^-1 - I))); beyond it the literal two-solve form (the two are equally far from the reference's
+   operations up to there, and the one-solve form drifts out of the reference's own sensitivity beyond).                       */
 #define HMOGP_CFG_NO_SMALL_PATH 4u /* ABI v5: keep the regular kernels and three streams also for small models (M <= 64 would
                                     * otherwise take the fused small-model kernels, M <= 128 with <= 65536 rows one stream): A/B
                                     * comparisons of the two paths inside one process (tests)                                */

@@ -315,15 +315,13 @@ def u_algebra(prm, prob, forced_rungs=None):
         u["C"].append(Kuui[q] @ S_q @ Kuui[q] - Kuui[q])
         if prob.get("strict_qf"):      # the engine's HMOGP_CFG_STRICT_QF algebra (see local_stats)
             u["D"].append(S_q @ Kuui[q] - np.eye(M))                   # svmogp_inf.py:157-158 (tmp / 2)
-    # [r6] which strict form (engine_impl.h: strict_two): "one_solve" = the engine's E-step / prediction form while the condition
-    # estimate variance max diag(Kuu^-1) of every latent is <= 1e6; anything else truthy = the literal two-solve form
+    # [r6] which strict form (engine_impl.h: strict_two): the one-solve form while the condition estimate variance max diag(Kuu^-1)
+    # of every latent is <= 1e6, the literal two-solve form beyond
     sq = prob.get("strict_qf")
     if sq:
         est = max(float(prm["variance"][q] * np.max(np.diag(Kuui[q]))) for q in range(Q))
-        # (the engine: two-solve form beyond 1e6 always, and beyond 1e5 when the evaluation needs P~, i.e. hyper-parameter / Z
-        #  gradients -- X (Luu^-1 D) drifts from the reference's rounding as K_uu degrades.  The oracle computes every gradient group
-        #  in one go: strict_qf=True mirrors a full-gradient evaluation, "one_solve" an E-step / a prediction.)
-        u["strict_two"] = (sq == "two_solves") or not (est <= (1e6 if sq == "one_solve" else 1e5))
+        # (the engine's rule: the one-solve form up to the estimate 1e6, the two-solve form beyond; "two_solves" / "one_solve" force)
+        u["strict_two"] = (sq == "two_solves") or (sq != "one_solve" and not (est <= 1e6))
     return u
 
 

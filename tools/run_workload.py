@@ -9,8 +9,8 @@ C4  one rank's share of config 4: 8 tasks x 125000 rows, M=1024, Q=4, Df=14
 C5  2-D, T=2 [Categorical(4),Gaussian], N_t=50000, M=2048, Q=2
 HD  headline shape with a DENSE-valued K^ (lengthscale = 40 inducing spacings, jitter rung 4 forced): no exact zeros
 HE  the E-step of the headline workload (q(u) group only, K_uu chain cached): the fold-pair forward
-HS  the headline workload in the strict q(f) mode (HMOGP_CFG_STRICT_QF), full gradients: K_uu well conditioned -> one-solve form
-HSL the same shape at lengthscale = 4 inducing spacings, jitter rung 0 forced (estimate 5.5e5): the two-solve form
+HS  the headline workload in the strict q(f) mode (HMOGP_CFG_STRICT_QF), full gradients (one-solve form: estimate <= 1e6)
+HSL the same shape at lengthscale = 4 inducing spacings, jitter rung 0 forced (estimate 5.5e5): where the mode is needed
 HSE the same with group_mask = QU (an E-step): the one-solve form of round 6"""
 import os
 import sys
