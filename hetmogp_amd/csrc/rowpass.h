@@ -12,6 +12,7 @@ struct QuadArgs {
   double lik_param = 0.0;
   int dimf = 1, Q = 1;
   long long N = 0;                 // rows of this chunk
+  long long off = 0;               // added to the row index of the [Q][ldn] vectors below (0: the pointers are already offset)
   const double* y = nullptr;       // [N]
   const double* yaux = nullptr;    // [N] gammaln(y+1) (Poisson) or nullptr
   const double* p = nullptr;       // [Q][ldn]  K^ a

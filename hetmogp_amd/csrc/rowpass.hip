@@ -250,6 +250,10 @@ __device__ __forceinline__ void quad_body(const QuadArgs& a, unsigned blk, QuadS
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const long long n = ((long long)blk * 256 + t) / G;
   const bool valid = n < a.N;                       // uniform per wave when G == 64
+  // (row of the pool-wide [Q][ldn] vectors: `a.off` is the segment's offset in the pool when the pointers are NOT pre-offset --
+  //  quad_multi_kernel: eight derived pointers per segment would be 16 more live SGPRs, and the instantiations that carry four or
+  //  five likelihood bodies spilled SGPRs to scratch memory, 68 bytes per lane)
+  const long long nn = n + a.off;
   const bool lead = valid && (G == 1 || lane == 0);  // the lane that owns the row's outputs
   const int Q = a.Q, J = a.dimf;
   const int nscal = 2 + 2 * Q + J + Q * J;
@@ -258,8 +262,8 @@ __device__ __forceinline__ void quad_body(const QuadArgs& a, unsigned blk, QuadS
   double mu[HMOGP_MAXJ], vv[HMOGP_MAXJ], pq[HMOGP_MAXQ], cq[HMOGP_MAXQ];
 #pragma unroll
   for (int q = 0; q < HMOGP_MAXQ; ++q) {
-    pq[q] = (valid && q < Q) ? a.p[q * a.ldn + n] : 0.0;
-    cq[q] = (valid && q < Q) ? a.c[q * a.ldn + n] : 0.0;
+    pq[q] = (valid && q < Q) ? a.p[q * a.ldn + nn] : 0.0;
+    cq[q] = (valid && q < Q) ? a.c[q * a.ldn + nn] : 0.0;
   }
   const double yv = valid ? a.y[n] : 0.0, yauxv = (valid && a.yaux) ? a.yaux[n] : 0.0;
   if (t < HMOGP_MAXQ * HMOGP_MAXJ) {
@@ -312,8 +316,8 @@ __device__ __forceinline__ void quad_body(const QuadArgs& a, unsigned blk, QuadS
     const double* cc = a.pg ? a.cg : a.c;
 #pragma unroll
     for (int q = 0; q < HMOGP_MAXQ; ++q) {
-      pq[q] = (valid && q < Q) ? pp[q * a.ldn + n] : 0.0;
-      cq[q] = (valid && q < Q) ? cc[q * a.ldn + n] : 0.0;
+      pq[q] = (valid && q < Q) ? pp[q * a.ldn + nn] : 0.0;
+      cq[q] = (valid && q < Q) ? cc[q * a.ldn + nn] : 0.0;
     }
   }
   // (the loops over a row's functions are unrolled to HMOGP_MAXJ with a guard: a run-time trip count indexes mu / vv / the LikOut
@@ -358,13 +362,13 @@ __device__ __forceinline__ void quad_body(const QuadArgs& a, unsigned blk, QuadS
           emit(2 + 2 * Q + J + q * J + j, o.gm[j] * pq[q] + 2.0 * wq * (o.gv[j] * cq[q]));  // swk[q][j]
         }
       if (lead) {
-        a.alpha[q * a.ldn + n] = al;
-        a.beta[q * a.ldn + n] = be;
-        a.alpha0[q * a.ldn + n] = al0;
-        a.beta0[q * a.ldn + n] = be0;
+        a.alpha[q * a.ldn + nn] = al;
+        a.beta[q * a.ldn + nn] = be;
+        a.alpha0[q * a.ldn + nn] = al0;
+        a.beta0[q * a.ldn + nn] = be0;
       }
-      const double ptq = (lead && a.pt) ? a.pt[q * a.ldn + n] : 0.0;
-      const double ctq = (lead && a.ct) ? a.ct[q * a.ldn + n] : 0.0;
+      const double ptq = (lead && a.pt) ? a.pt[q * a.ldn + nn] : 0.0;
+      const double ctq = (lead && a.ct) ? a.ct[q * a.ldn + nn] : 0.0;
       emit(2 + 2 * q, al0 * pq[q] + 2.0 * be0 * cq[q]);  // sa_q
       emit(3 + 2 * q, al0 * ptq + 2.0 * be0 * ctq);      // sl_q
     }
@@ -405,13 +409,13 @@ __global__ __launch_bounds__(256) void quad_multi_kernel(QuadMulti m) {
   QuadArgs a;
   a.lik = g.lik, a.lik_param = g.lik_param, a.dimf = g.dimf, a.Q = m.Q, a.N = g.N;
   a.y = g.y, a.yaux = g.yaux;
-  a.p = m.p + g.off, a.c = m.c + g.off, a.pt = m.pt ? m.pt + g.off : nullptr, a.ct = m.ct ? m.ct + g.off : nullptr;
+  a.p = m.p, a.c = m.c, a.pt = m.pt, a.ct = m.ct, a.off = g.off;
   a.ldn = m.ldn;
   a.Wd = m.Wd, a.W0d = m.W0d, a.kapd = m.kapd, a.vard = m.vard, a.scaled = m.scale_base + g.t;
   a.Df = m.Df, a.d0 = g.d0;
   a.pg = a.cg = nullptr;
   a.quirks = m.quirks;
-  a.alpha = m.alpha + g.off, a.beta = m.beta + g.off, a.alpha0 = m.alpha0 + g.off, a.beta0 = m.beta0 + g.off;
+  a.alpha = m.alpha, a.beta = m.beta, a.alpha0 = m.alpha0, a.beta0 = m.beta0;
   a.partials = m.partials + g.part0;
   a.out_mu = a.out_v = a.out_gm = a.out_gv = nullptr;
   const unsigned blk = blockIdx.x - g.blk0;

@@ -267,11 +267,6 @@ __global__ __launch_bounds__(NT, 4) void trsm_panel_kernel(TrsmPanelArgs g) {
     const double* __restrict__ vec = g.st_vec + (long long)batch * g.st_vecB;
     double* part = g.st_part + (long long)batch * g.st_sPart;    // [2][4][ld]
     const bool first = DIR == 0 ? j0 == 0 : j0 + BN >= M;         // the first block of this direction
-    double mv[NB][4];
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) mv[b][r] = vec[(long long)(j0 + wn * WN + b * 16 + 4 * lk + r) * g.st_vecS];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const long long row = i0 + wm * 64 + a * 16 + lr;
@@ -284,9 +279,11 @@ __global__ __launch_bounds__(NT, 4) void trsm_panel_kernel(TrsmPanelArgs g) {
           const f64x2 k01 = *reinterpret_cast<const f64x2*>(krow + b * 16), k23 = *reinterpret_cast<const f64x2*>(krow + b * 16 + 2);
           kv[0] = k01.x, kv[1] = k01.y, kv[2] = k23.x, kv[3] = k23.y;
         }
+        // (the lane's 4 entries of `vec` are re-read per slice: cache hits, and 16 registers less than holding all 8 across the loop)
+        const double* vp = vec + (long long)(j0 + wn * WN + b * 16 + 4 * lk) * g.st_vecS;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          sp = fma(acc[a][b][r], mv[b][r], sp);
+          sp = fma(acc[a][b][r], vp[(long long)r * g.st_vecS], sp);
           sk = fma(acc[a][b][r], kv[r], sk);
         }
       }
